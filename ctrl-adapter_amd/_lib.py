@@ -1,0 +1,129 @@
+"""ctypes binding of libctrlhip.so (the C ABI declared in include/ctrl_hip.h).
+
+There is no fallback: if the shared library is missing or fails to load, importing the product path
+raises.  PyTorch is used only for device memory and streams; every tensor crosses this boundary as a
+raw device pointer.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctrlhip.so")
+
+F32, F16, BF16 = 0, 1, 2
+
+
+class IGemmSeg(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("ld", C.c_int64), ("col_begin", C.c_int32), ("ncols", C.c_int32),
+                ("fmt", C.c_int32), ("dtype", C.c_int32), ("L", C.c_int32), ("pad_", C.c_int32)]
+
+
+class IGemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("mode", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32),
+                ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+                ("stride", C.c_int32), ("up", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32), ("pad0_", C.c_int32),
+                ("W", C.c_void_p), ("M", C.c_int32), ("Nout", C.c_int32), ("Ktot", C.c_int32), ("pad1_", C.c_int32),
+                ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_ld", C.c_int32), ("rows_per_img", C.c_int32),
+                ("res", C.c_void_p), ("ldres", C.c_int64), ("scale", C.c_float), ("geglu", C.c_int32),
+                ("nseg", C.c_int32), ("pad2_", C.c_int32), ("seg", IGemmSeg * 3)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("ldq", C.c_int64), ("K", C.c_void_p), ("ldk", C.c_int64),
+                ("Vt", C.c_void_p), ("Lkpad", C.c_int32), ("pad0_", C.c_int32),
+                ("O", C.c_void_p), ("ldo", C.c_int64),
+                ("B", C.c_int32), ("heads", C.c_int32), ("D", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
+                ("scale", C.c_float)]
+
+
+class TAttnDesc(C.Structure):
+    _fields_ = [("QKV", C.c_void_p), ("ld", C.c_int64), ("O", C.c_void_p), ("ldo", C.c_int64),
+                ("Bc", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32), ("heads", C.c_int32),
+                ("scale", C.c_float), ("pad0_", C.c_int32)]
+
+
+class TensorRef(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
+class ControlNetConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("conditioning_channels", C.c_int32),
+                ("block_out_channels", C.c_int32 * 4), ("down_block_has_attn", C.c_int32 * 4),
+                ("layers_per_block", C.c_int32), ("num_attention_heads", C.c_int32),
+                ("cross_attention_dim", C.c_int32), ("cond_embed_channels", C.c_int32 * 4),
+                ("norm_eps", C.c_float)]
+
+
+class AdapterConfig(C.Structure):
+    _fields_ = [("backbone_sdxl", C.c_int32), ("num_blocks", C.c_int32), ("num_adapters_per_location", C.c_int32),
+                ("cross_attention_dim", C.c_int32),
+                ("add_spatial_resnet", C.c_int32), ("add_temporal_resnet", C.c_int32),
+                ("add_spatial_transformer", C.c_int32), ("add_temporal_transformer", C.c_int32),
+                ("loc_A", C.c_int32), ("loc_B", C.c_int32), ("loc_C", C.c_int32), ("loc_D", C.c_int32),
+                ("loc_M", C.c_int32)]
+
+
+# every symbol include/ctrl_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "ctrl_abi_version", "ctrl_last_error", "ctrl_prof_begin", "ctrl_prof_end", "ctrl_prof_count", "ctrl_prof_get",
+    "ctrl_op_igemm", "ctrl_op_flash_attn", "ctrl_op_temporal_attn", "ctrl_op_gn_stats", "ctrl_op_gn_apply",
+    "ctrl_op_layernorm", "ctrl_op_nchw_to_nhwc", "ctrl_op_nhwc_to_nchw", "ctrl_avgpool_nchw",
+    "ctrl_op_timestep_sincos", "ctrl_op_linear_small", "ctrl_op_blend", "ctrl_op_add_rowvec",
+    "ctrl_op_conv3x3_direct", "ctrl_op_pack_conv_w", "ctrl_op_pack_conv_w_direct", "ctrl_op_pack_linear_w",
+    "ctrl_op_pack_vec",
+    "ctrl_controlnet_param_count", "ctrl_controlnet_param_spec", "ctrl_controlnet_create",
+    "ctrl_controlnet_destroy", "ctrl_controlnet_forward",
+    "ctrl_adapter_param_count", "ctrl_adapter_param_spec", "ctrl_adapter_create", "ctrl_adapter_destroy",
+    "ctrl_adapter_forward",
+    "ctrl_router_weights", "ctrl_router_merge",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libctrlhip.so once.  Raises if it is missing -- there is no CPU/eager fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libctrlhip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The HIP path has no fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ctrl_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            fn = getattr(_lib, name)
+            if name not in ("ctrl_last_error", "ctrl_controlnet_destroy", "ctrl_adapter_destroy"):
+                fn.restype = C.c_int
+        _lib.ctrl_controlnet_destroy.restype = None
+        _lib.ctrl_adapter_destroy.restype = None
+        if _lib.ctrl_abi_version() != 1:
+            raise RuntimeError("libctrlhip ABI version mismatch")
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().ctrl_last_error()
+        raise RuntimeError("libctrlhip: " + (msg.decode() if msg else "unknown error"))
+
+
+def dtype_code(t):
+    import torch
+    if t == torch.float32:
+        return F32
+    if t == torch.float16:
+        return F16
+    if t == torch.bfloat16:
+        return BF16
+    raise ValueError("unsupported dtype %s (float32, float16, bfloat16 are supported)" % t)
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

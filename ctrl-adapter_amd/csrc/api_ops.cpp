@@ -1,0 +1,77 @@
+// extern "C" op-level entry points of libctrlhip (thin: validate, cast, forward to the op layer).
+#include "ops.h"
+
+#define S(stream) ((hipStream_t)(stream))
+#define H(p) ((half_t*)(p))
+#define CH(p) ((const half_t*)(p))
+
+extern "C" {
+int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream) {
+    CTRL_CHECK(d != nullptr, "igemm: null descriptor");
+    return op_igemm(*d, S(stream));
+}
+int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream) {
+    CTRL_CHECK(d != nullptr, "flash_attn: null descriptor");
+    return op_flash_attn(*d, S(stream));
+}
+int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream) {
+    CTRL_CHECK(d != nullptr, "temporal_attn: null descriptor");
+    return op_temporal_attn(*d, S(stream));
+}
+int ctrl_op_gn_stats(const void* x, float* stats, int imgs, int rows_per_img, int C, int G, void* stream) {
+    return op_gn_stats(CH(x), stats, imgs, rows_per_img, C, G, S(stream));
+}
+int ctrl_op_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
+                     int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream) {
+    return op_gn_apply(CH(x), stats, gamma, beta, H(y), imgs, rows_per_img, C, G, eps, silu, S(stream));
+}
+int ctrl_op_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                      int M, int C, float eps, void* stream) {
+    return op_layernorm(CH(x), ldx, gamma, beta, H(y), ldy, M, C, eps, S(stream));
+}
+int ctrl_op_nchw_to_nhwc(const void* x, int dtype, void* y, int N, int C, int HW, void* stream) {
+    return op_nchw_to_nhwc(x, dtype, H(y), N, C, HW, S(stream));
+}
+int ctrl_op_nhwc_to_nchw(const void* x, void* y, int dtype, int N, int C, int HW, float scale, void* stream) {
+    return op_nhwc_to_nchw(CH(x), y, dtype, N, C, HW, scale, S(stream));
+}
+int ctrl_avgpool_nchw(const void* x, void* y, int dtype, int NC, int Hin, int Win, int Hout, int Wout, void* stream) {
+    return op_avgpool_nchw(x, y, dtype, NC, Hin, Win, Hout, Wout, S(stream));
+}
+int ctrl_op_timestep_sincos(const float* t, int t_count, float* out, int N, int dim, void* stream) {
+    return op_timestep_sincos(t, t_count, out, N, dim, S(stream));
+}
+int ctrl_op_linear_small(const float* x, int64_t ldx, const void* w, const float* b, float* out, int64_t ldo,
+                         int M, int N, int K, int in_silu, int out_silu, void* stream) {
+    return op_linear_small(x, ldx, CH(w), b, out, ldo, M, N, K, in_silu, out_silu, S(stream));
+}
+int ctrl_op_blend(const void* xs, const void* xt, const float* mix, void* y, size_t n, void* stream) {
+    return op_blend(CH(xs), CH(xt), mix, H(y), n, S(stream));
+}
+int ctrl_op_add_rowvec(const void* x, const float* v, int64_t ldv, void* y, size_t M, int C, int rows_per_img, int vmod, void* stream) {
+    return op_add_rowvec(CH(x), v, ldv, H(y), M, C, rows_per_img, vmod, S(stream));
+}
+int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w, const float* bias, void* out,
+                           int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, void* stream) {
+    return op_conv3x3_direct(in, in_dtype, in_nchw, w, bias, H(out), N, Cin, Cout, Hin, Win, stride, silu, S(stream));
+}
+int ctrl_op_pack_conv_w(const void* w, int dtype, void* out, int Cout, int Cin, int taps, void* stream) {
+    return op_pack_conv_w(w, dtype, H(out), Cout, Cin, taps, S(stream));
+}
+int ctrl_op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, void* stream) {
+    return op_pack_conv_w_direct(w, dtype, out, Cout, Cin, S(stream));
+}
+int ctrl_op_pack_linear_w(const void* w, int dtype, void* out, int N, int K, int geglu, void* stream) {
+    return op_pack_linear_w(w, dtype, H(out), N, K, geglu, S(stream));
+}
+int ctrl_op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, void* stream) {
+    return op_pack_vec(v, dtype, out, N, geglu, S(stream));
+}
+int ctrl_router_weights(const float* wg, const int* mask_host, float* weights_out, int R, int E, int equal_weights, void* stream) {
+    return op_router_softmax(wg, mask_host, weights_out, R, E, equal_weights, S(stream));
+}
+int ctrl_router_merge(const void* const* experts_host, const float* weights_row, const int* widx_host, int K,
+                      void* out, int dtype, size_t n, void* stream) {
+    return op_weighted_merge(experts_host, weights_row, widx_host, K, out, dtype, n, S(stream));
+}
+}

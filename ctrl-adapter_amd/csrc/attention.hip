@@ -1,0 +1,353 @@
+// Flash attention for gfx950 (v_mfma_f32_32x32x16_f16), fp32 online softmax.
+//
+// Replaces F.scaled_dot_product_attention inside diffusers' Attention/AttnProcessor2_0 as reached from
+//   * the adapter's spatial BasicTransformerBlock (model/adapter_spatial_temporal.py:108-116, called :271):
+//     heads = C/64, head_dim 64, L = H*W up to 16384 (SDXL 128x128), cross-attention Lk = 77
+//   * the ControlNet's Transformer2DModel blocks (controlnet/controlnet.py:371-391,410-424):
+//     8 heads of 40/80/160, L = 4096/1024/256/64, cross-attention Lk = 77.
+//
+// Structure (one workgroup = 128 queries of one (batch, head); 4 wavefronts x 32 queries):
+//   S^T = K.Q^T   -- "swapped" product: the MFMA result column is the query, so every lane owns ONE
+//                    query and 32 of the 64 keys of the tile; row max / row sum need a single exchange
+//                    with lane^32 and the rescale factor is a per-lane scalar.
+//   O^T += V^T.P^T -- the P^T B-operand is exactly the lane's own exponentiated scores (no cross-lane
+//                    movement) because K rows are fetched from LDS through a bit-2<->bit-3 swapped row
+//                    index; V is supplied transposed ([C][tokens], written that way by the QKV GEMM
+//                    epilogue) so its A-operand is one ds_read_b128 of 8 consecutive keys.
+//   K / V^T tiles (64 keys) are staged global -> VGPR -> LDS, double-buffered; LDS rows are padded to an
+//   odd number of 16-byte slots (bank-conflict-free b128 fragment reads).
+#include "ops.h"
+
+namespace {
+
+__device__ __forceinline__ int krow_perm(int i) {   // swap bits 2 and 3 (identity on bits 0,1,4)
+    return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
+    constexpr int DK = (D + 15) / 16 * 16;      // QK^T reduction extent (zero padded)
+    constexpr int KS = DK / 16;                 // k-steps of the 32x32x16 MFMA
+    constexpr int DB = (D + 31) / 32;           // 32-row output blocks of O^T
+    constexpr int KLD = DK + 8;                 // K tile row stride (halfs)
+    constexpr int VLD = 64 + 8;                 // V^T tile row stride (halfs)
+    constexpr int KCHUNKS = 64 * (DK / 8);      // 16-B chunks in a K tile
+    constexpr int VCHUNKS = D * 8;              // 16-B chunks in a V^T tile (only rows < D are staged)
+    constexpr int KCH = (KCHUNKS + 255) / 256, VCH = (VCHUNKS + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    half_t* Ks = (half_t*)smem_raw;                 // [2][64][KLD]
+    half_t* Vs = Ks + 2 * 64 * KLD;                 // [2][DB*32][VLD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, lq = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int Lq = a.Lq, Lk = a.Lk;
+    const float c = a.scale * 1.4426950408889634f;   // softmax in the exp2 domain
+
+    const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- Q fragments (B operand: col = query, k = hi*8+j) kept in registers ----
+    h8 qf[KS];
+    {
+        int q = q0 + lq;
+        if (q > Lq - 1) q = Lq - 1;               // clamp (rows beyond Lq are computed but never stored)
+        const half_t* qp = (const half_t*)a.Q + ((size_t)b * Lq + q) * a.ldq + (size_t)h * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + hi * 8;
+            qf[ks] = (d0 < D) ? *(const h8*)(qp + d0) : hzero;
+        }
+    }
+
+    const half_t* Kbase = (const half_t*)a.K + (size_t)b * Lk * a.ldk + (size_t)h * D;
+    const half_t* Vbase = (const half_t*)a.Vt + ((size_t)b * a.heads + h) * D * (size_t)a.Lkpad;
+
+    h8 kreg[KCH], vreg[VCH];
+    auto gload = [&](int t) {
+        const int kt0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (DK / 8), ch = idx - row * (DK / 8);
+            const int key = kt0 + row;
+            const bool ok = (idx < KCHUNKS) && (key < Lk) && (ch * 8 < D);
+            kreg[i] = ok ? *(const h8*)(Kbase + (size_t)key * a.ldk + ch * 8) : hzero;
+        }
+        const bool tail = (kt0 + 64 > Lk);
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx >> 3, ch = idx & 7;
+            const bool ok = (idx < VCHUNKS) && (kt0 + ch * 8 < Lk);
+            h8 v = ok ? *(const h8*)(Vbase + (size_t)row * a.Lkpad + kt0 + ch * 8) : hzero;
+            if (tail && ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (kt0 + ch * 8 + j >= Lk) v[j] = (half_t)0.f;
+            }
+            vreg[i] = v;
+        }
+    };
+    auto lds_store = [&](int buf) {
+        half_t* Kb = Ks + buf * 64 * KLD;
+        half_t* Vb = Vs + buf * DB * 32 * VLD;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < KCHUNKS) {
+                const int row = idx / (DK / 8), ch = idx - row * (DK / 8);
+                *(h8*)(Kb + row * KLD + ch * 8) = kreg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < VCHUNKS) {
+                const int row = idx >> 3, ch = idx & 7;
+                *(h8*)(Vb + row * VLD + ch * 8) = vreg[i];
+            }
+        }
+    };
+
+    f16v o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles = (Lk + 63) / 64;
+    gload(0);
+    lds_store(0);
+    __syncthreads();
+
+    const int krow = krow_perm(lq);
+    int cur = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) gload(t + 1);
+        const half_t* Kb = Ks + cur * 64 * KLD;
+        const half_t* Vb = Vs + cur * DB * 32 * VLD;
+
+        // ---- S^T = K . Q^T  (two 32-key blocks) ----
+        f16v sacc[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[mb][r] = 0.f;
+            const half_t* kp = Kb + (mb * 32 + krow) * KLD + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const h8 kf = *(const h8*)(kp + ks * 16);
+                sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[mb], 0, 0, 0);
+            }
+        }
+        // register r of block mb holds key  kt0 + 32*mb + 16*(r>>3) + 8*hi + (r&7)  (see krow_perm)
+        const int kt0 = t * 64;
+        if (kt0 + 64 > Lk) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt0 + mb * 32 + ((r >> 3) << 4) + hi * 8 + (r & 7);
+                    if (key >= Lk) sacc[mb][r] = -1e30f;
+                }
+        }
+        // ---- online softmax (exp2 domain) ----
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * c);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        h8 pf[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sacc[mb][r] * c - m_new);
+                psum += p;
+                pf[mb][r >> 3][r & 7] = (half_t)p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const half_t* vp = Vb + lq * VLD + mb * 32 + s2 * 16 + hi * 8;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const h8 vf = *(const h8*)(vp + db * 32 * VLD);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[mb][s2], o[db], 0, 0, 0);
+                }
+            }
+
+        if (t + 1 < ntiles) lds_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- finalize: O[q][d] = O^T[d][q] / l ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + lq;
+    if (q < Lq) {
+        half_t* op = (half_t*)a.O + ((size_t)b * Lq + q) * a.ldo + (size_t)h * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // rows (r&3) + 8*(r>>2) + 4*hi of the 32x32 C/D fragment: r = 4g..4g+3 -> 4 consecutive d
+                const int d0 = db * 32 + 8 * g + 4 * hi;
+                if (d0 < D) {
+                    h4 v = {(half_t)(o[db][4 * g] * inv), (half_t)(o[db][4 * g + 1] * inv),
+                            (half_t)(o[db][4 * g + 2] * inv), (half_t)(o[db][4 * g + 3] * inv)};
+                    *(h4*)(op + d0) = v;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch_attn(const AttnArgs& a, hipStream_t s) {
+    constexpr int DK = (D + 15) / 16 * 16, DB = (D + 31) / 32;
+    constexpr size_t smem = (size_t)2 * (64 * (DK + 8) + DB * 32 * (64 + 8)) * sizeof(half_t);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    dim3 grid((a.Lq + 127) / 128, a.heads, a.B);
+    LAUNCH("flash_attn", (flash_attn_kernel<D>), grid, dim3(256), smem, s, a);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Temporal attention: sequence = frames (F <= 32), batch = clips x pixels, head_dim 64.
+// Replaces the Attention inside diffusers' TemporalBasicTransformerBlock (constructed
+// model/adapter_spatial_temporal.py:120-130, called :280) after its [bF,L,C] -> [b*L,F,C] reshape.
+// The F x F score matrix is tiny, so this kernel is HBM-bound: one wavefront per (clip, pixel, head)
+// reads q/k/v rows once (128-B contiguous head slices), keeps everything in registers and writes the
+// result back in the original frame-major layout (no materialised permute).
+//   lane l: frame f = l % F_PAD handles query f; the 64-dim dot products are done by the F lanes
+//   cooperatively via LDS-free shuffles is wasteful for F=16, so instead each lane owns (query f, 16-dim
+//   slice s): lanes = F_PAD(16) x 4 slices.
+// ---------------------------------------------------------------------------------------------
+template <int FP>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs a) {
+    // work item = (clip b, pixel p, head h), one wavefront each.  Lane = (16-dim slice sl, query frame fl);
+    // FP = padded frame count (16 or 32): every loop over key frames is fully unrolled so the score
+    // vector stays in VGPRs (runtime-indexed arrays would spill to scratch).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long item = (long)blockIdx.x * 4 + wave;
+    const long nitems = (long)a.Bc * a.HW * a.heads;
+    if (item >= nitems) return;
+    const int h = (int)(item % a.heads);
+    const long bp = item / a.heads;
+    const int p = (int)(bp % a.HW);
+    const int b = (int)(bp / a.HW);
+    const int C = a.heads * 64;
+    const int F = a.F;
+    const int sl = lane >> 4;          // 16-dim slice of the head
+    const int fl = lane & 15;          // query frame handled by this lane (within a pass)
+    const float c = a.scale * 1.4426950408889634f;
+    const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t col = (size_t)h * 64 + sl * 16;
+
+#pragma unroll
+    for (int f0 = 0; f0 < FP; f0 += 16) {
+        if (f0 >= F) break;
+        const int fq = f0 + fl;
+        const bool qok = fq < F;
+        h8 q0 = hzero, q1 = hzero;
+        if (qok) {
+            const half_t* qp = (const half_t*)a.QKV + ((size_t)(b * F + fq) * a.HW + p) * a.ld + col;
+            q0 = *(const h8*)qp;
+            q1 = *(const h8*)(qp + 8);
+        }
+        float sc[FP];
+        float mx = -1e30f;
+#pragma unroll
+        for (int kf = 0; kf < FP; ++kf) {
+            sc[kf] = -1e30f;
+            if (kf < F) {
+                const half_t* kp = (const half_t*)a.QKV + ((size_t)(b * F + kf) * a.HW + p) * a.ld + C + col;
+                const h8 k0 = *(const h8*)kp, k1 = *(const h8*)(kp + 8);
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += (float)q0[j] * (float)k0[j] + (float)q1[j] * (float)k1[j];
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+                sc[kf] = d * c;
+                mx = fmaxf(mx, sc[kf]);
+            }
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < FP; ++kf) {
+            sc[kf] = (kf < F) ? __builtin_amdgcn_exp2f(sc[kf] - mx) : 0.f;
+            l += sc[kf];
+        }
+        const float inv = 1.f / l;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < FP; ++kf) {
+            if (kf < F) {
+                const half_t* vp = (const half_t*)a.QKV + ((size_t)(b * F + kf) * a.HW + p) * a.ld + 2 * C + col;
+                const h8 v0 = *(const h8*)vp, v1 = *(const h8*)(vp + 8);
+                const float w = sc[kf] * inv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc[j] += w * (float)v0[j]; acc[8 + j] += w * (float)v1[j]; }
+            }
+        }
+        if (qok) {
+            half_t* op = (half_t*)a.O + ((size_t)(b * F + fq) * a.HW + p) * a.ldo + col;
+            h8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (half_t)acc[j]; o1[j] = (half_t)acc[8 + j]; }
+            *(h8*)op = o0;
+            *(h8*)(op + 8) = o1;
+        }
+    }
+}
+
+}  // namespace
+
+int op_flash_attn(const AttnArgs& a, hipStream_t s) {
+    CTRL_CHECK(a.B > 0 && a.heads > 0 && a.Lq > 0 && a.Lk > 0, "flash_attn: empty problem");
+    CTRL_CHECK(a.Lkpad % 64 == 0 && a.Lkpad >= a.Lk, "flash_attn: Lkpad must be a multiple of 64 and >= Lk");
+    CTRL_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "flash_attn: leading dims must be multiples of 8");
+    CTRL_CHECK((((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.Vt) & 15) == 0 && ((uintptr_t)a.O & 7) == 0,
+               "flash_attn: pointers must be 16-byte aligned");
+    switch (a.D) {
+        case 64: return launch_attn<64>(a, s);
+        case 40: return launch_attn<40>(a, s);
+        case 80: return launch_attn<80>(a, s);
+        case 160: return launch_attn<160>(a, s);
+        default: CTRL_FAIL("flash_attn: unsupported head_dim " + std::to_string(a.D) + " (supported: 40, 64, 80, 160)");
+    }
+}
+
+int op_temporal_attn(const TAttnArgs& a, hipStream_t s) {
+    CTRL_CHECK(a.F > 0 && a.F <= 32, "temporal_attn: F must be in 1..32");
+    CTRL_CHECK(a.ld % 8 == 0 && a.ldo % 8 == 0, "temporal_attn: leading dims must be multiples of 8");
+    const long nitems = (long)a.Bc * a.HW * a.heads;
+    CTRL_CHECK(nitems > 0, "temporal_attn: empty problem");
+    dim3 grid((unsigned)((nitems + 3) / 4));
+    if (a.F <= 16) LAUNCH("temporal_attn", temporal_attn_kernel<16>, grid, dim3(256), 0, s, a);
+    else LAUNCH("temporal_attn", temporal_attn_kernel<32>, grid, dim3(256), 0, s, a);
+    return 0;
+}

@@ -1,0 +1,78 @@
+// Common device/host helpers for libctrlhip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+// dtype codes of the C ABI (include/ctrl_hip.h)
+enum { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2 };
+
+// ---- error plumbing (no C++ exceptions cross the ABI) ----
+void ctrl_set_error(const std::string& s);
+#define CTRL_FAIL(msg)                                                            \
+    do {                                                                          \
+        ctrl_set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + (msg)); \
+        return 1;                                                                 \
+    } while (0)
+#define CTRL_CHECK(cond, msg) do { if (!(cond)) CTRL_FAIL(msg); } while (0)
+#define HIP_TRY(expr)                                                             \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) CTRL_FAIL(std::string(#expr) + " -> " + hipGetErrorString(e_)); \
+    } while (0)
+#define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+// ---- per-kernel-class event profiler (used by bench.py's roofline leg) ----
+void prof_before(const char* tag, hipStream_t s);
+void prof_after(hipStream_t s);
+extern bool g_prof_on;
+
+#define LAUNCH(tag, kern, grid, block, shmem, stream, ...)                        \
+    do {                                                                          \
+        if (g_prof_on) prof_before(tag, stream);                                  \
+        hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);        \
+        if (g_prof_on) prof_after(stream);                                        \
+        hipError_t le_ = hipGetLastError();                                       \
+        if (le_ != hipSuccess) CTRL_FAIL(std::string("launch ") + tag + ": " + hipGetErrorString(le_)); \
+    } while (0)
+
+#ifdef __HIPCC__
+// ---- device helpers ----
+__device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ u16 f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    unsigned r = u + 0x7FFFu + ((u >> 16) & 1u);   // RNE (NaN not expected on this path)
+    return (u16)(r >> 16);
+}
+__device__ __forceinline__ float load_as_f32(const void* p, size_t i, int dt) {
+    if (dt == DT_F32) return ((const float*)p)[i];
+    if (dt == DT_F16) return (float)((const half_t*)p)[i];
+    return bf16_to_f32(((const u16*)p)[i]);
+}
+__device__ __forceinline__ void store_from_f32(void* p, size_t i, int dt, float v) {
+    if (dt == DT_F32) ((float*)p)[i] = v;
+    else if (dt == DT_F16) ((half_t*)p)[i] = (half_t)v;
+    else ((u16*)p)[i] = f32_to_bf16(v);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif

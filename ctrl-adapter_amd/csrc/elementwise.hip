@@ -1,0 +1,328 @@
+// Layout conversion, pooling, embeddings, small-M linears, blends, router softmax / merge and the
+// load-time weight packers (gfx950).  All HBM- or latency-bound helper kernels of the hot path.
+#include "ops.h"
+
+namespace {
+
+// ---- [N][C][HW] any dtype -> [N][HW][C] fp16 through a 32(c) x 64(hw) LDS tile ----
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const void* __restrict__ x, int dt, half_t* __restrict__ y,
+                                                           int C, int HW) {
+    __shared__ float tile[32][65];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+    {
+        const int pl = t & 63;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cl = (t >> 6) + 4 * i;
+            const int c = c0 + cl, p = p0 + pl;
+            tile[cl][pl] = (c < C && p < HW) ? load_as_f32(x, ((size_t)n * C + c) * HW + p, dt) : 0.f;
+        }
+    }
+    __syncthreads();
+    {
+        const int cl = t & 31;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pl = (t >> 5) + 8 * i;
+            const int c = c0 + cl, p = p0 + pl;
+            if (c < C && p < HW) y[((size_t)n * HW + p) * C + c] = (half_t)tile[cl][pl];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const half_t* __restrict__ x, void* __restrict__ y, int dt,
+                                                           int C, int HW, float scale) {
+    __shared__ float tile[32][65];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+    {
+        const int cl = t & 31;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pl = (t >> 5) + 8 * i;
+            const int c = c0 + cl, p = p0 + pl;
+            tile[cl][pl] = (c < C && p < HW) ? (float)x[((size_t)n * HW + p) * C + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    {
+        const int pl = t & 63;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cl = (t >> 6) + 4 * i;
+            const int c = c0 + cl, p = p0 + pl;
+            if (c < C && p < HW) store_from_f32(y, ((size_t)n * C + c) * HW + p, dt, tile[cl][pl] * scale);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_kernel(const void* __restrict__ x, void* __restrict__ y, int dt,
+                                                      int Hin, int Win, int Hout, int Wout, size_t total) {
+    const int ky = Hin / Hout, kx = Win / Wout;
+    const float inv = 1.0f / (float)(ky * kx);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wout);
+        const size_t r = i / Wout;
+        const int oy = (int)(r % Hout);
+        const size_t nc = r / Hout;
+        float s = 0.f;
+        for (int a = 0; a < ky; ++a)
+            for (int b = 0; b < kx; ++b) s += load_as_f32(x, (nc * Hin + oy * ky + a) * Win + ox * kx + b, dt);
+        store_from_f32(y, i, dt, s * inv);
+    }
+}
+
+// diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin],
+// freq_k = exp(-ln(10000) * k / half)
+__global__ void sincos_kernel(const float* __restrict__ t, int t_count, int Fmod, float* __restrict__ out, int N, int dim) {
+    const int half_dim = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * half_dim) return;
+    const int n = i / half_dim, k = i - n * half_dim;
+    const float tv = t ? t[t_count == 1 ? 0 : n] : (float)(n % Fmod);
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half_dim);
+    const float arg = tv * freq;
+    out[(size_t)n * dim + k] = cosf(arg);
+    out[(size_t)n * dim + half_dim + k] = sinf(arg);
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, long ldx, const half_t* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ out, long ldo,
+                                                           int M, int N, int K, int in_silu, int out_silu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * MT;
+    float acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = 0.f;
+    const half_t* wp = w + (size_t)n * K;
+    for (int k = lane * 8; k < K; k += 512) {
+        const h8 wv = *(const h8*)(wp + k);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (m0 + i < M) {
+                const float* xp = x + (size_t)(m0 + i) * ldx + k;
+                const f4 a0 = *(const f4*)xp, a1 = *(const f4*)(xp + 4);
+                float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xx = in_silu ? silu_f(xv[j]) : xv[j];
+                    acc[i] += xx * (float)wv[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const float r = wave_sum(acc[i]);
+        if (lane == 0 && m0 + i < M) {
+            float v = r + (b ? b[n] : 0.f);
+            if (out_silu) v = silu_f(v);
+            out[(size_t)(m0 + i) * ldo + n] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void blend_kernel(const half_t* __restrict__ xs, const half_t* __restrict__ xt,
+                                                    const float* __restrict__ mix, half_t* __restrict__ y, size_t nchunks) {
+    const float alpha = 1.0f / (1.0f + __expf(-mix[0]));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+        const h8 a = ((const h8*)xs)[i], b = ((const h8*)xt)[i];
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(alpha * (float)a[j] + (1.0f - alpha) * (float)b[j]);
+        ((h8*)y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const half_t* __restrict__ x, const float* __restrict__ v, long ldv,
+                                                         half_t* __restrict__ y, size_t nchunks, int C, int rows_per_img, int vmod) {
+    const int lpr = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / lpr;
+        const int c0 = (int)(i - row * lpr) * 8;
+        const size_t img = (row / rows_per_img) % vmod;
+        const h8 a = ((const h8*)x)[i];
+        const float* vp = v + img * ldv + c0;
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] + vp[j]);
+        ((h8*)y)[i] = o;
+    }
+}
+
+struct MergeArgs {
+    const void* x[8];
+    int widx[8];
+    int K;
+};
+__global__ __launch_bounds__(256) void merge_kernel(MergeArgs m, const float* __restrict__ w, void* __restrict__ out,
+                                                    int dt, size_t n) {
+    float wk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wk[k] = (k < m.K) ? w[m.widx[k]] : 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < m.K) s += wk[k] * load_as_f32(m.x[k], i, dt);
+        store_from_f32(out, i, dt, s);
+    }
+}
+
+struct RouterMask { int m[16]; };
+// reference: model/ctrl_router.py:85-112 (logits = wg.weight[:,0] or zeros; -1e6 on masked experts; softmax)
+__global__ void router_softmax_kernel(const float* __restrict__ wg, RouterMask mask, float* __restrict__ out,
+                                      int R, int E, int equal_weights) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float lg[16];
+    float mx = -3.0e38f;
+    for (int e = 0; e < E; ++e) {
+        float v = equal_weights ? 0.f : wg[(size_t)r * E + e];
+        if (mask.m[e] == 0) v -= 1e6f;
+        lg[e] = v;
+        mx = fmaxf(mx, v);
+    }
+    float s = 0.f;
+    for (int e = 0; e < E; ++e) { lg[e] = expf(lg[e] - mx); s += lg[e]; }
+    for (int e = 0; e < E; ++e) out[(size_t)r * E + e] = lg[e] / s;
+}
+
+// ---------------- weight packers (run once at plan build) ----------------
+__global__ void pack_conv_w_kernel(const void* __restrict__ w, int dt, half_t* __restrict__ out, int Cout, int Cin, int taps) {
+    const size_t total = (size_t)Cout * taps * Cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        const size_t r = i / Cin;
+        const int tp = (int)(r % taps);
+        const size_t co = r / taps;
+        out[i] = (half_t)load_as_f32(w, (co * Cin + ci) * taps + tp, dt);
+    }
+}
+__global__ void pack_conv_w_direct_kernel(const void* __restrict__ w, int dt, float* __restrict__ out, int Cout, int Cin) {
+    const size_t total = (size_t)9 * Cin * Cout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i % Cout);
+        const size_t r = i / Cout;
+        const int ci = (int)(r % Cin);
+        const int tp = (int)(r / Cin);
+        out[i] = load_as_f32(w, ((size_t)co * Cin + ci) * 9 + tp, dt);
+    }
+}
+// GEGLU interleave: packed row p -> source row:  blk = p/32, within = p%32;
+//   within < 16 : hidden row  blk*16 + within ;  else : gate row  N/2 + blk*16 + within-16
+__device__ __forceinline__ int geglu_src_row(int p, int N) {
+    const int blk = p >> 5, wi = p & 31;
+    return wi < 16 ? blk * 16 + wi : N / 2 + blk * 16 + (wi - 16);
+}
+__global__ void pack_linear_w_kernel(const void* __restrict__ w, int dt, half_t* __restrict__ out, int N, int K, int geglu) {
+    const size_t total = (size_t)N * K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % K);
+        const int p = (int)(i / K);
+        const int srow = geglu ? geglu_src_row(p, N) : p;
+        out[i] = (half_t)load_as_f32(w, (size_t)srow * K + k, dt);
+    }
+}
+__global__ void pack_vec_kernel(const void* __restrict__ v, int dt, float* __restrict__ out, int N, int geglu) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    out[i] = load_as_f32(v, geglu ? geglu_src_row(i, N) : i, dt);
+}
+
+unsigned grid_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+int op_nchw_to_nhwc(const void* x, int dtype, half_t* y, int N, int C, int HW, hipStream_t s) {
+    dim3 grid((HW + 63) / 64, (C + 31) / 32, N);
+    LAUNCH("nchw_to_nhwc", nchw_to_nhwc_kernel, grid, dim3(256), 0, s, x, dtype, y, C, HW);
+    return 0;
+}
+int op_nhwc_to_nchw(const half_t* x, void* y, int dtype, int N, int C, int HW, float scale, hipStream_t s) {
+    dim3 grid((HW + 63) / 64, (C + 31) / 32, N);
+    LAUNCH("nhwc_to_nchw", nhwc_to_nchw_kernel, grid, dim3(256), 0, s, x, y, dtype, C, HW, scale);
+    return 0;
+}
+int op_avgpool_nchw(const void* x, void* y, int dtype, int NC, int Hin, int Win, int Hout, int Wout, hipStream_t s) {
+    CTRL_CHECK(Hin % Hout == 0 && Win % Wout == 0, "avgpool: only integer pooling ratios are supported");
+    const size_t total = (size_t)NC * Hout * Wout;
+    LAUNCH("avgpool", avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, y, dtype, Hin, Win, Hout, Wout, total);
+    return 0;
+}
+int op_timestep_sincos(const float* t, int t_count, float* out, int N, int dim, hipStream_t s) {
+    CTRL_CHECK(dim % 2 == 0, "timestep embedding: dim must be even");
+    CTRL_CHECK(t_count == 1 || t_count == N, "timestep embedding: need 1 or N timesteps");
+    const int total = N * (dim / 2);
+    LAUNCH("sincos", sincos_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t, t_count, 1, out, N, dim);
+    return 0;
+}
+int op_frameidx_sincos(float* out, int N, int F, int dim, hipStream_t s) {
+    const int total = N * (dim / 2);
+    LAUNCH("sincos", sincos_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)nullptr, 0, F, out, N, dim);
+    return 0;
+}
+int op_linear_small(const float* x, long ldx, const half_t* w, const float* b, float* out, long ldo,
+                    int M, int N, int K, int in_silu, int out_silu, hipStream_t s) {
+    CTRL_CHECK(K % 8 == 0 && ldx % 4 == 0, "linear_small: K must be a multiple of 8 and ldx of 4");
+    CTRL_CHECK(M >= 1 && M <= 4096, "linear_small: M out of range");
+    dim3 grid((N + 3) / 4, (M + 7) / 8);
+    LAUNCH("linear_small", linear_small_kernel<8>, grid, dim3(256), 0, s, x, ldx, w, b, out, ldo, M, N, K, in_silu, out_silu);
+    return 0;
+}
+int op_blend(const half_t* xs, const half_t* xt, const float* mix, half_t* y, size_t n, hipStream_t s) {
+    CTRL_CHECK(n % 8 == 0, "blend: element count must be a multiple of 8");
+    LAUNCH("blend", blend_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, xs, xt, mix, y, n / 8);
+    return 0;
+}
+int op_add_rowvec(const half_t* x, const float* v, long ldv, half_t* y, size_t M, int C, int rows_per_img, int vmod, hipStream_t s) {
+    CTRL_CHECK(C % 8 == 0, "add_rowvec: C must be a multiple of 8");
+    const size_t nch = M * (size_t)(C / 8);
+    LAUNCH("add_rowvec", add_rowvec_kernel, dim3(grid_for(nch)), dim3(256), 0, s, x, v, ldv, y, nch, C, rows_per_img, vmod);
+    return 0;
+}
+int op_fill_zero(void* p, size_t bytes, hipStream_t s) {
+    HIP_TRY(hipMemsetAsync(p, 0, bytes, s));
+    return 0;
+}
+int op_weighted_merge(const void* const* xs, const float* w, const int* widx, int K, void* out, int dtype, size_t n, hipStream_t s) {
+    CTRL_CHECK(K >= 1 && K <= 8, "weighted_merge: 1..8 experts supported");
+    MergeArgs m = {};
+    for (int k = 0; k < K; ++k) { m.x[k] = xs[k]; m.widx[k] = widx[k]; }
+    m.K = K;
+    LAUNCH("merge", merge_kernel, dim3(grid_for(n)), dim3(256), 0, s, m, w, out, dtype, n);
+    return 0;
+}
+int op_router_softmax(const float* wg, const int* mask, float* out, int R, int E, int equal_weights, hipStream_t s) {
+    CTRL_CHECK(E >= 1 && E <= 16, "router: 1..16 experts supported");
+    RouterMask rm;
+    for (int e = 0; e < 16; ++e) rm.m[e] = (e < E && mask) ? mask[e] : 1;
+    LAUNCH("router", router_softmax_kernel, dim3((R + 63) / 64), dim3(64), 0, s, wg, rm, out, R, E, equal_weights);
+    return 0;
+}
+int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s) {
+    LAUNCH("pack", pack_conv_w_kernel, dim3(grid_for((size_t)Cout * Cin * taps)), dim3(256), 0, s, w, dtype, out, Cout, Cin, taps);
+    return 0;
+}
+int op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, hipStream_t s) {
+    LAUNCH("pack", pack_conv_w_direct_kernel, dim3(grid_for((size_t)Cout * Cin * 9)), dim3(256), 0, s, w, dtype, out, Cout, Cin);
+    return 0;
+}
+int op_pack_linear_w(const void* w, int dtype, half_t* out, int N, int K, int geglu, hipStream_t s) {
+    CTRL_CHECK(!geglu || N % 32 == 0, "pack_linear_w: GEGLU needs N % 32 == 0");
+    LAUNCH("pack", pack_linear_w_kernel, dim3(grid_for((size_t)N * K)), dim3(256), 0, s, w, dtype, out, N, K, geglu);
+    return 0;
+}
+int op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, hipStream_t s) {
+    LAUNCH("pack", pack_vec_kernel, dim3((N + 255) / 256), dim3(256), 0, s, v, dtype, out, N, geglu);
+    return 0;
+}

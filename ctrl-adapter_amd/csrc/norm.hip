@@ -1,0 +1,171 @@
+// GroupNorm / LayerNorm for channels-last fp16 activations, fp32 statistics (gfx950).
+//
+// Reference ops: torch.nn.GroupNorm(32, C) in ResnetBlock2D (model/resnet_block_2d.py:116,128),
+// TemporalResnetBlock, Transformer2DModel.norm and AdapterSpatioTemporal.norm
+// (model/adapter_spatial_temporal.py:61); torch.nn.LayerNorm in (Temporal)BasicTransformerBlock.
+//
+// These kernels are HBM-bound: each reads its input once with 16-byte vector loads and reduces with
+// wavefront shuffles / LDS atomics.  GroupNorm is split into a statistics pass (sum, sum of squares per
+// (image, group) via one fp32 atomic pair per workgroup) and an apply pass (normalise + affine + optional
+// SiLU) because one group of an SDXL-sized map (10 ch x 128x128) does not fit one workgroup.
+#include "ops.h"
+
+namespace {
+
+// x [imgs][rows][C]; grid (chunks, imgs); each thread owns an 8-channel chunk and strides over rows.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats,
+                                                       int rows, int C, int G, int rows_per_block) {
+    extern __shared__ float sh[];   // [2*C]: per-channel sum, sumsq
+    const int tid = threadIdx.x;
+    const int lpr = C >> 3;                 // lanes per row
+    const int rpi = 256 / lpr;              // rows per iteration
+    const int tr = tid / lpr, tc = tid - tr * lpr;
+    const int img = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    for (int i = tid; i < 2 * C; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+    if (tr < rpi) {
+        const half_t* xp = x + ((size_t)img * rows) * C + tc * 8;
+        for (int r = r0 + tr; r < r1; r += rpi) {
+            const h8 v = *(const h8*)(xp + (size_t)r * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&sh[tc * 8 + j], s[j]);
+            atomicAdd(&sh[C + tc * 8 + j], ss[j]);
+        }
+    }
+    __syncthreads();
+    const int cg = C / G;
+    if (tid < G) {
+        float a = 0.f, b = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += sh[c]; b += sh[C + c]; }
+        atomicAdd(&stats[((size_t)img * G + tid) * 2 + 0], a);
+        atomicAdd(&stats[((size_t)img * G + tid) * 2 + 1], b);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       half_t* __restrict__ y, int rows, int C, int G, float eps,
+                                                       int silu, size_t total_chunks) {
+    const int lpr = C >> 3;
+    const int cg = C / G;
+    const float inv_cnt = 1.0f / ((float)rows * (float)cg);
+    for (size_t ch = (size_t)blockIdx.x * 256 + threadIdx.x; ch < total_chunks; ch += (size_t)gridDim.x * 256) {
+        const size_t row = ch / lpr;
+        const int c0 = (int)(ch - row * lpr) * 8;
+        const int img = (int)(row / rows);
+        const h8 v = *(const h8*)(x + row * C + c0);
+        h8 o;
+        int gprev = -1;
+        float mean = 0.f, rstd = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            const int g = c / cg;
+            if (g != gprev) {
+                const float s = stats[((size_t)img * G + g) * 2], ss = stats[((size_t)img * G + g) * 2 + 1];
+                mean = s * inv_cnt;
+                const float var = fmaxf(ss * inv_cnt - mean * mean, 0.f);
+                rstd = rsqrtf(var + eps);
+                gprev = g;
+            }
+            float f = ((float)v[j] - mean) * rstd * gamma[c] + beta[c];
+            if (silu) f = silu_f(f);
+            o[j] = (half_t)f;
+        }
+        *(h8*)(y + row * C + c0) = o;
+    }
+}
+
+// one wavefront per row; C <= 64*8*NCH
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long ldx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        half_t* __restrict__ y, long ldy, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const half_t* xp = x + (size_t)row * ldx;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = (lane + i * 64) * 8;
+        if (c0 < C) {
+            const h8 t = *(const h8*)(xp + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = (lane + i * 64) * 8;
+        if (c0 < C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    half_t* yp = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = (lane + i * 64) * 8;
+        if (c0 < C) {
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)((v[i][j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j]);
+            *(h8*)(yp + c0) = o;
+        }
+    }
+}
+
+}  // namespace
+
+int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
+    CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_stats: C must be a multiple of 8 and of G, <= 2048");
+    CTRL_CHECK(G <= 256, "gn_stats: G too large");
+    // ~64 workgroups per image keep atomics few while filling the chip for batch >= 4
+    int rows_per_block = (rows_per_img + 63) / 64;
+    const int rpi = 256 / (C / 8);
+    rows_per_block = ((rows_per_block + rpi - 1) / rpi) * rpi;
+    if (rows_per_block < rpi) rows_per_block = rpi;
+    const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
+    LAUNCH("gn_stats", gn_stats_kernel, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
+           x, stats, rows_per_img, C, G, rows_per_block);
+    return 0;
+}
+
+int op_gn_apply(const half_t* x, const float* stats, const float* gamma, const float* beta, half_t* y,
+                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s) {
+    CTRL_CHECK(C % 8 == 0 && C % G == 0, "gn_apply: C must be a multiple of 8 and of G");
+    const size_t total = (size_t)imgs * rows_per_img * (C / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    LAUNCH("gn_apply", gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+           x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, total);
+    return 0;
+}
+
+int op_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
+                 int M, int C, float eps, hipStream_t s) {
+    CTRL_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C must be a multiple of 8 and <= 2048");
+    CTRL_CHECK(ldx % 8 == 0 && ldy % 8 == 0, "layernorm: leading dims must be multiples of 8");
+    const dim3 grid((M + 3) / 4), block(256);
+    if (C <= 512) LAUNCH("layernorm", layernorm_kernel<1>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);
+    else if (C <= 1024) LAUNCH("layernorm", layernorm_kernel<2>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);
+    else LAUNCH("layernorm", layernorm_kernel<4>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);
+    return 0;
+}

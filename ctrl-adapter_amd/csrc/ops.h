@@ -1,0 +1,91 @@
+// Internal op layer of libctrlhip: every function enqueues hand-written gfx950 kernels on `stream`
+// and returns 0 / non-zero (message via ctrl_last_error()).  Activations are fp16, channels-last
+// ("NHWC": a feature map [n][y][x][c] is a row-major token matrix [n*H*W][C]); accumulation,
+// normalisation statistics, softmax and all epilogue math are fp32.
+#pragma once
+#include "common.h"
+#include "../../include/ctrl_hip.h"
+
+// ------------------------------------------------------------------------------------------
+// Implicit GEMM (MFMA f16 -> f32):  out[m][n] = epilogue( sum_k Agather[m][k] * W[n][k] )
+// ------------------------------------------------------------------------------------------
+enum { IG_ROWS = 0, IG_CONV2D = 1, IG_TEMPORAL = 2 };
+enum { SEG_ROW = 0, SEG_TRANSPOSED = 1 };
+
+typedef ctrl_igemm_seg IGemmSeg;     // see include/ctrl_hip.h for field docs
+typedef ctrl_igemm_desc IGemmArgs;
+int op_igemm(const IGemmArgs& a, hipStream_t s);
+// convenience: plain linear out[M][N] (fp16 row-major) = A[M][K] * W[N][K]^T + bias
+int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, half_t* out, long ldo,
+              int M, int N, int K, const half_t* res, long ldres, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// Flash attention, one (query tile, head, batch) per workgroup, online softmax in fp32.
+//   Q [B*Lq][ldq] (head h at column h*D), K [B*Lk][ldk], Vt [B][heads*D][Lkpad] (V transposed),
+//   O [B*Lq][ldo].
+// ------------------------------------------------------------------------------------------
+typedef ctrl_attn_desc AttnArgs;
+int op_flash_attn(const AttnArgs& a, hipStream_t s);
+
+// temporal attention over the frame axis: tokens X [(b*F+f)*HW + p][...]; seq = F (<= 32)
+typedef ctrl_tattn_desc TAttnArgs;
+int op_temporal_attn(const TAttnArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// Normalisation
+// ------------------------------------------------------------------------------------------
+// GroupNorm statistics over [img][rows_per_img][C]: stats[img][G][2] += (sum, sumsq)   (fp32 atomics;
+// caller zeroes `stats` once per forward)
+int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s);
+// y = (x-mean)*rstd*gamma+beta (optionally SiLU); x,y [imgs*rows][C]
+int op_gn_apply(const half_t* x, const float* stats, const float* gamma, const float* beta, half_t* y,
+                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s);
+// LayerNorm over the last dim of x [M][C] -> y fp16
+int op_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
+                 int M, int C, float eps, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// Element-wise / layout / small kernels
+// ------------------------------------------------------------------------------------------
+// [N][C][HW] (any dtype) -> [N][HW][C] fp16
+int op_nchw_to_nhwc(const void* x, int dtype, half_t* y, int N, int C, int HW, hipStream_t s);
+// [N][HW][C] fp16 -> [N][C][HW] (any dtype), y = x*scale
+int op_nhwc_to_nchw(const half_t* x, void* y, int dtype, int N, int C, int HW, float scale, hipStream_t s);
+// exact kxk mean pooling of an NCHW tensor (adaptive_avg_pool2d with integer ratio), dtype preserved
+int op_avgpool_nchw(const void* x, void* y, int dtype, int NC, int Hin, int Win, int Hout, int Wout, hipStream_t s);
+// sinusoidal timestep embedding, flip_sin_to_cos=True, shift 0: out[n][dim] fp32 = [cos | sin]
+int op_timestep_sincos(const float* t, int t_count, float* out, int N, int dim, hipStream_t s);
+// frame-index variant: t[n] = n % F
+int op_frameidx_sincos(float* out, int N, int F, int dim, hipStream_t s);
+// small-M linear (M <= 64): out[m][n] = act(sum_k in_act(x[m][k]) * w[n][k] + b[n]); x,out fp32; w fp16
+//   in_silu: apply SiLU to x on load; out_silu: apply SiLU to the result
+int op_linear_small(const float* x, long ldx, const half_t* w, const float* b, float* out, long ldo,
+                    int M, int N, int K, int in_silu, int out_silu, hipStream_t s);
+// y[m][c] = a*x1[m][c] + b*x2[m][c]   (AlphaBlender; a=alpha, b=1-alpha read from device: alpha=sigmoid(*mix))
+int op_blend(const half_t* x_spatial, const half_t* x_temporal, const float* mix_factor, half_t* y, size_t n, hipStream_t s);
+// y[m][c] = x[m][c] + v[(m / rows_per_img) % vmod][c]   (fp32 per-image vector broadcast add)
+int op_add_rowvec(const half_t* x, const float* v, long ldv, half_t* y, size_t M, int C, int rows_per_img, int vmod, hipStream_t s);
+// fill fp16/any
+int op_fill_zero(void* p, size_t bytes, hipStream_t s);
+// K-way weighted merge of NCHW tensors: out = sum_e w[widx[e]] * x_e   (router merge; weights on device)
+int op_weighted_merge(const void* const* xs_dev, const float* w, const int* widx_dev, int K, void* out, int dtype,
+                      size_t n, hipStream_t s);
+// router: weights[r][e] = softmax_e( wg[r][e] (or 0) - 1e6*(1-mask[e]) ),  r in [0,R)
+int op_router_softmax(const float* wg, const int* mask, float* out, int R, int E, int equal_weights, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// Direct 3x3 convolution for tiny channel counts (ControlNet stem / conditioning embedder head)
+//   in : NCHW any dtype (in_nchw=1) or NHWC fp16;  w fp32 [9][Cin][Cout]; out NHWC fp16 (+bias, optional SiLU)
+// ------------------------------------------------------------------------------------------
+int op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w, const float* bias, half_t* out,
+                      int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, hipStream_t s);
+
+// weight packing (load time)
+// conv weight [Cout][Cin][kh][kw] (any dtype) -> fp16 [Cout][kh*kw][Cin]   (taps-major K)
+int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s);
+// conv weight [Cout][Cin][3][3] -> fp32 [9][Cin][Cout] for the direct kernel
+int op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, hipStream_t s);
+// linear weight [N][K] -> fp16 [N][K]; optional GEGLU interleave of rows (N = 2*inner)
+int op_pack_linear_w(const void* w, int dtype, half_t* out, int N, int K, int geglu, hipStream_t s);
+// vector -> fp32 (optional GEGLU interleave)
+int op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, hipStream_t s);

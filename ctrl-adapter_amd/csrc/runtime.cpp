@@ -1,0 +1,54 @@
+// Runtime glue of libctrlhip: thread-local error string and the per-kernel-class HIP-event profiler
+// used by bench.py's roofline leg (events are recorded on the stream the kernels are launched on).
+#include "common.h"
+#include "../../include/ctrl_hip.h"
+#include <map>
+#include <vector>
+#include <cstring>
+
+static thread_local std::string g_err;
+void ctrl_set_error(const std::string& s) { g_err = s; }
+
+bool g_prof_on = false;
+namespace {
+struct Rec { const char* tag; hipEvent_t e0, e1; };
+std::vector<Rec> g_recs;
+std::vector<std::pair<std::string, std::pair<double, int>>> g_summary;
+}
+void prof_before(const char* tag, hipStream_t s) {
+    Rec r; r.tag = tag;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+}
+void prof_after(hipStream_t s) { hipEventRecord(g_recs.back().e1, s); }
+
+extern "C" {
+int ctrl_abi_version(void) { return CTRL_ABI_VERSION; }
+const char* ctrl_last_error(void) { return g_err.c_str(); }
+int ctrl_prof_begin(void) { g_recs.clear(); g_summary.clear(); g_prof_on = true; return 0; }
+int ctrl_prof_end(void) {
+    g_prof_on = false;
+    HIP_TRY(hipDeviceSynchronize());
+    std::map<std::string, std::pair<double, int>> acc;
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        auto& a = acc[r.tag];
+        a.first += ms; a.second += 1;
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_recs.clear();
+    g_summary.assign(acc.begin(), acc.end());
+    return 0;
+}
+int ctrl_prof_count(void) { return (int)g_summary.size(); }
+int ctrl_prof_get(int i, char* name, int name_len, double* total_ms, int* launches) {
+    CTRL_CHECK(i >= 0 && i < (int)g_summary.size(), "prof_get: index out of range");
+    std::strncpy(name, g_summary[i].first.c_str(), name_len - 1);
+    name[name_len - 1] = 0;
+    *total_ms = g_summary[i].second.first;
+    *launches = g_summary[i].second.second;
+    return 0;
+}
+}

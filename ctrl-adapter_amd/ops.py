@@ -1,0 +1,241 @@
+"""Thin Python wrappers over the op-level C ABI (ctrl_op_*): allocate outputs with torch, pass raw pointers.
+
+Used by the parity tests and micro-benchmarks; the product forward path goes through the plan-level
+entry points (controlnet.py / ctrl_adapter.py) and never composes these from Python.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+IG_ROWS, IG_CONV2D, IG_TEMPORAL = 0, 1, 2
+SEG_ROW, SEG_TRANSPOSED = 0, 1
+
+
+def _f16(*shape, device="cuda"):
+    return torch.empty(*shape, dtype=torch.float16, device=device)
+
+
+def pack_conv_w(w):
+    """[Cout][Cin][kh][kw] -> fp16 [Cout][kh*kw][Cin]"""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    out = _f16(cout, taps * cin)
+    L.check(L.lib().ctrl_op_pack_conv_w(L.ptr(w.contiguous()), L.dtype_code(w.dtype), L.ptr(out), cout, cin, taps, L.cur_stream()))
+    return out
+
+
+def pack_conv_w_direct(w):
+    cout, cin = w.shape[0], w.shape[1]
+    out = torch.empty(9, cin, cout, dtype=torch.float32, device=w.device)
+    L.check(L.lib().ctrl_op_pack_conv_w_direct(L.ptr(w.contiguous()), L.dtype_code(w.dtype), L.ptr(out), cout, cin, L.cur_stream()))
+    return out
+
+
+def pack_linear_w(w, geglu=False):
+    n, k = w.shape
+    out = _f16(n, k)
+    L.check(L.lib().ctrl_op_pack_linear_w(L.ptr(w.contiguous()), L.dtype_code(w.dtype), L.ptr(out), n, k, int(geglu), L.cur_stream()))
+    return out
+
+
+def pack_vec(v, geglu=False):
+    out = torch.empty(v.numel(), dtype=torch.float32, device=v.device)
+    L.check(L.lib().ctrl_op_pack_vec(L.ptr(v.contiguous()), L.dtype_code(v.dtype), L.ptr(out), v.numel(), int(geglu), L.cur_stream()))
+    return out
+
+
+def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
+          res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0):
+    """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
+    d = L.IGemmDesc()
+    d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
+    g = geom or {}
+    d.Hin = g.get("Hin", 1); d.Win = g.get("Win", 1); d.Hout = g.get("Hout", 1); d.Wout = g.get("Wout", 1)
+    d.stride = g.get("stride", 1); d.up = g.get("up", 1)
+    d.F = F; d.HW = HW
+    d.W = W.data_ptr(); d.M = M; d.Nout = Nout; d.Ktot = taps * Cin
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.rowvec = rowvec.data_ptr() if rowvec is not None else None
+    d.rowvec_ld = rowvec.shape[-1] if rowvec is not None else 0
+    d.rows_per_img = rows_per_img
+    d.res = res.data_ptr() if res is not None else None
+    d.ldres = ldres
+    d.scale = scale; d.geglu = int(geglu)
+    d.nseg = len(segs)
+    for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):
+        d.seg[i].out = out.data_ptr(); d.seg[i].ld = ld; d.seg[i].col_begin = cb; d.seg[i].ncols = nc
+        d.seg[i].fmt = fmt; d.seg[i].dtype = L.dtype_code(out.dtype); d.seg[i].L = Ltok
+    L.check(L.lib().ctrl_op_igemm(C.byref(d), L.cur_stream()))
+
+
+def linear(x, w_packed, bias=None, res=None, geglu=False):
+    """x [M][K] fp16 -> [M][N] fp16 (N/2 for GEGLU)"""
+    M, K = x.shape
+    N = w_packed.shape[0]
+    on = N // 2 if geglu else N
+    out = _f16(M, on)
+    igemm(x, K, w_packed, M, N, K, bias=bias, res=res, ldres=on, geglu=geglu,
+          segs=[(out, on, 0, on, SEG_ROW, 1)])
+    return out
+
+
+def conv2d(x_nhwc, w_packed, Cout, taps=9, stride=1, up=1, bias=None, rowvec=None, res=None, scale=1.0,
+           out_nchw_dtype=None):
+    """x [N][H][W][Cin] fp16 -> [N][Ho][Wo][Cout] fp16 (or NCHW in out_nchw_dtype)"""
+    N, H, W, Cin = x_nhwc.shape
+    pad = 1 if taps == 9 else 0
+    Ho = (H * up + 2 * pad - (3 if taps == 9 else 1)) // stride + 1
+    Wo = (W * up + 2 * pad - (3 if taps == 9 else 1)) // stride + 1
+    M = N * Ho * Wo
+    geom = dict(Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, up=up)
+    if out_nchw_dtype is None:
+        out = _f16(N, Ho, Wo, Cout)
+        segs = [(out, Cout, 0, Cout, SEG_ROW, 1)]
+    else:
+        out = torch.empty(N, Cout, Ho, Wo, dtype=out_nchw_dtype, device=x_nhwc.device)
+        segs = [(out, Ho * Wo, 0, Cout, SEG_TRANSPOSED, Ho * Wo)]
+    igemm(x_nhwc, Cin, w_packed, M, Cout, Cin, taps=taps, mode=IG_CONV2D, geom=geom, bias=bias, rowvec=rowvec,
+          rows_per_img=Ho * Wo, res=res, ldres=Cout, scale=scale, segs=segs)
+    return out
+
+
+def flash_attn(Q, ldq, K, ldk, Vt, Lkpad, B, heads, D, Lq, Lk, scale=None):
+    out = _f16(B * Lq, heads * D)
+    d = L.AttnDesc()
+    d.Q = Q.data_ptr(); d.ldq = ldq; d.K = K.data_ptr(); d.ldk = ldk; d.Vt = Vt.data_ptr(); d.Lkpad = Lkpad
+    d.O = out.data_ptr(); d.ldo = heads * D
+    d.B = B; d.heads = heads; d.D = D; d.Lq = Lq; d.Lk = Lk
+    d.scale = scale if scale is not None else D ** -0.5
+    L.check(L.lib().ctrl_op_flash_attn(C.byref(d), L.cur_stream()))
+    return out
+
+
+def temporal_attn(qkv, Bc, F, HW, heads):
+    Cc = heads * 64
+    out = _f16(qkv.shape[0], Cc)
+    d = L.TAttnDesc()
+    d.QKV = qkv.data_ptr(); d.ld = 3 * Cc; d.O = out.data_ptr(); d.ldo = Cc
+    d.Bc = Bc; d.F = F; d.HW = HW; d.heads = heads; d.scale = 64 ** -0.5
+    L.check(L.lib().ctrl_op_temporal_attn(C.byref(d), L.cur_stream()))
+    return out
+
+
+def groupnorm(x, gamma, beta, imgs, rows_per_img, G=32, eps=1e-5, silu=False):
+    Cc = x.shape[-1]
+    stats = torch.zeros(imgs, G, 2, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    lib = L.lib()
+    L.check(lib.ctrl_op_gn_stats(L.ptr(x), L.ptr(stats), imgs, rows_per_img, Cc, G, L.cur_stream()))
+    L.check(lib.ctrl_op_gn_apply(L.ptr(x), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(y), imgs, rows_per_img, Cc, G,
+                                 C.c_float(eps), int(silu), L.cur_stream()))
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    L.check(L.lib().ctrl_op_layernorm(L.ptr(x), C.c_int64(Cc), L.ptr(gamma), L.ptr(beta), L.ptr(y), C.c_int64(Cc), M, Cc,
+                                      C.c_float(eps), L.cur_stream()))
+    return y
+
+
+def nchw_to_nhwc(x):
+    N, Cc, H, W = x.shape
+    y = _f16(N, H, W, Cc)
+    L.check(L.lib().ctrl_op_nchw_to_nhwc(L.ptr(x.contiguous()), L.dtype_code(x.dtype), L.ptr(y), N, Cc, H * W, L.cur_stream()))
+    return y
+
+
+def nhwc_to_nchw(x, dtype=torch.float32, scale=1.0):
+    N, H, W, Cc = x.shape
+    y = torch.empty(N, Cc, H, W, dtype=dtype, device=x.device)
+    L.check(L.lib().ctrl_op_nhwc_to_nchw(L.ptr(x), L.ptr(y), L.dtype_code(dtype), N, Cc, H * W, C.c_float(scale), L.cur_stream()))
+    return y
+
+
+def avgpool_nchw(x, Hout, Wout):
+    """exact integer-ratio F.adaptive_avg_pool2d; dtype preserved"""
+    N, Cc, H, W = x.shape
+    y = torch.empty(N, Cc, Hout, Wout, dtype=x.dtype, device=x.device)
+    L.check(L.lib().ctrl_avgpool_nchw(L.ptr(x.contiguous()), L.ptr(y), L.dtype_code(x.dtype), N * Cc, H, W, Hout, Wout, L.cur_stream()))
+    return y
+
+
+def timestep_sincos(t, N, dim):
+    out = torch.empty(N, dim, dtype=torch.float32, device=t.device)
+    L.check(L.lib().ctrl_op_timestep_sincos(L.ptr(t), t.numel(), L.ptr(out), N, dim, L.cur_stream()))
+    return out
+
+
+def linear_small(x, w_packed, bias=None, in_silu=False, out_silu=False):
+    M, K = x.shape
+    N = w_packed.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    L.check(L.lib().ctrl_op_linear_small(L.ptr(x), C.c_int64(K), L.ptr(w_packed), L.ptr(bias), L.ptr(out), C.c_int64(N), M, N, K,
+                                         int(in_silu), int(out_silu), L.cur_stream()))
+    return out
+
+
+def blend(xs, xt, mix):
+    y = torch.empty_like(xs)
+    L.check(L.lib().ctrl_op_blend(L.ptr(xs), L.ptr(xt), L.ptr(mix), L.ptr(y), C.c_size_t(xs.numel()), L.cur_stream()))
+    return y
+
+
+def add_rowvec(x, v, rows_per_img, vmod):
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    L.check(L.lib().ctrl_op_add_rowvec(L.ptr(x), L.ptr(v), C.c_int64(v.shape[-1]), L.ptr(y), C.c_size_t(M), Cc, rows_per_img, vmod, L.cur_stream()))
+    return y
+
+
+def conv3x3_direct(x, w_direct, bias, Cout, stride=1, silu=False, nchw=False):
+    if nchw:
+        N, Cin, H, W = x.shape
+    else:
+        N, H, W, Cin = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = _f16(N, Ho, Wo, Cout)
+    L.check(L.lib().ctrl_op_conv3x3_direct(L.ptr(x), L.dtype_code(x.dtype), int(nchw), L.ptr(w_direct), L.ptr(bias), L.ptr(out),
+                                           N, Cin, Cout, H, W, stride, int(silu), L.cur_stream()))
+    return out
+
+
+def router_weights(wg, mask, equal_weights=False):
+    R, E = wg.shape
+    out = torch.empty(R, E, dtype=torch.float32, device=wg.device)
+    m = (C.c_int * E)(*[int(v) for v in mask]) if mask is not None else None
+    L.check(L.lib().ctrl_router_weights(L.ptr(wg), m, L.ptr(out), R, E, int(equal_weights), L.cur_stream()))
+    return out
+
+
+def router_merge(experts, weights_row, widx):
+    K = len(experts)
+    out = torch.empty_like(experts[0])
+    ptrs = (C.c_void_p * K)(*[e.data_ptr() for e in experts])
+    idx = (C.c_int * K)(*widx)
+    L.check(L.lib().ctrl_router_merge(ptrs, L.ptr(weights_row), idx, K, L.ptr(out), L.dtype_code(out.dtype),
+                                      C.c_size_t(out.numel()), L.cur_stream()))
+    return out
+
+
+class Profiler:
+    """HIP-event profiler over kernel classes (see ctrl_prof_* in include/ctrl_hip.h)."""
+
+    def __enter__(self):
+        L.check(L.lib().ctrl_prof_begin())
+        return self
+
+    def __exit__(self, *exc):
+        lib = L.lib()
+        L.check(lib.ctrl_prof_end())
+        self.rows = {}
+        name = C.create_string_buffer(64)
+        ms = C.c_double()
+        n = C.c_int()
+        for i in range(lib.ctrl_prof_count()):
+            L.check(lib.ctrl_prof_get(i, name, 64, C.byref(ms), C.byref(n)))
+            self.rows[name.value.decode()] = (ms.value, n.value)
+        return False

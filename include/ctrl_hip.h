@@ -1,0 +1,205 @@
+/* libctrlhip -- C ABI of the MI355X-native (gfx950) Ctrl-Adapter denoising hot path.
+ *
+ * Drop-in boundary for the per-timestep ControlNet forward + Ctrl-Adapter forward (+ router / merge) of
+ * HL-hanlin/Ctrl-Adapter.  Every entry point takes plain device pointers and sizes (no torch types),
+ * enqueues hand-written HIP kernels on the caller's stream (`stream` is a hipStream_t passed as void*;
+ * NULL = default stream), never synchronises, and returns 0 on success / non-zero on error with the
+ * message available from ctrl_last_error().  No C++ exception crosses this boundary.
+ *
+ * Plan-level entry points (what a reference-side binding calls):
+ *   ctrl_controlnet_forward   replaces ControlNetModel.forward            controlnet/controlnet.py:662-881
+ *   ctrl_adapter_forward      replaces ControlNetAdapter.forward          model/ctrl_adapter.py:171-224
+ *                             (and AdapterSpatioTemporal.forward          model/adapter_spatial_temporal.py:175-292,
+ *                              ResnetBlock2D.forward                      model/resnet_block_2d.py:164-221)
+ *   ctrl_router_weights       replaces ControlNetRouter.forward           model/ctrl_router.py:85-112
+ *   ctrl_router_merge         replaces the caller-side expert merge       i2vgen_xl/pipelines/
+ *                             i2vgen_xl_controlnet_adapter_pipeline.py:1000-1022 (and train.py:1262-1276)
+ *   ctrl_avgpool_nchw         replaces F.adaptive_avg_pool2d(latents,(64,64))  sdxl/pipelines/
+ *                             sdxl_controlnet_adapter_pipeline.py:1306-1309
+ * Op-level entry points (ctrl_op_*) expose the individual kernels for parity tests and micro-benchmarks.
+ */
+#ifndef CTRL_HIP_H
+#define CTRL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTRL_ABI_VERSION 1
+
+/* element types of boundary tensors */
+enum { CTRL_F32 = 0, CTRL_F16 = 1, CTRL_BF16 = 2 };
+
+/* ---------------------------------------------------------------- runtime */
+int ctrl_abi_version(void);
+const char* ctrl_last_error(void);           /* thread-local, valid until the next failing call */
+/* per-kernel-class HIP-event profiler: begin -> run forwards -> end(sync) -> query */
+int ctrl_prof_begin(void);
+int ctrl_prof_end(void);
+int ctrl_prof_count(void);
+int ctrl_prof_get(int i, char* name, int name_len, double* total_ms, int* launches);
+
+/* ---------------------------------------------------------------- op level */
+typedef struct ctrl_igemm_seg {
+    void* out;          /* destination */
+    int64_t ld;         /* ROW: row stride (elements); TRANSPOSED: padded token stride */
+    int32_t col_begin;  /* first output column of the segment (multiple of 16) */
+    int32_t ncols;      /* segment width */
+    int32_t fmt;        /* 0 ROW: out[m*ld + c];  1 TRANSPOSED: out[((m/L)*ncols + c)*ld + m%L] */
+    int32_t dtype;      /* CTRL_F32 / CTRL_F16 / CTRL_BF16 */
+    int32_t L;          /* tokens per image (TRANSPOSED) */
+    int32_t pad_;
+} ctrl_igemm_seg;
+
+typedef struct ctrl_igemm_desc {
+    const void* A;      /* fp16 activations, channels-last */
+    int64_t lda;        /* elements between consecutive pixels/rows */
+    int32_t mode;       /* 0 rows (linear / 1x1), 1 conv2d, 2 temporal (3 frame taps) */
+    int32_t Cin;        /* K per tap */
+    int32_t taps;       /* 1 | 9 | 3 */
+    int32_t Hin, Win, Hout, Wout, stride, up;   /* conv2d geometry; up = nearest up-sampling folded into the gather */
+    int32_t F, HW;      /* temporal: frames per clip, rows per frame */
+    int32_t pad0_;
+    const void* W;      /* fp16 [Nout][taps*Cin] */
+    int32_t M, Nout, Ktot;
+    int32_t pad1_;
+    const float* bias;  /* [Nout] or NULL */
+    const float* rowvec; int32_t rowvec_ld; int32_t rows_per_img;   /* + rowvec[(m/rows_per_img)*ld + n] */
+    const void* res; int64_t ldres;                                 /* + res[m*ldres + n] (fp16) */
+    float scale;
+    int32_t geglu;      /* weights packed in interleaved (hidden,gate) 16-column blocks; out width Nout/2 */
+    int32_t nseg;
+    int32_t pad2_;
+    ctrl_igemm_seg seg[3];
+} ctrl_igemm_desc;
+int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
+
+typedef struct ctrl_attn_desc {
+    const void* Q; int64_t ldq;      /* [B*Lq][ldq] fp16, head h at column h*D */
+    const void* K; int64_t ldk;      /* [B*Lk][ldk] */
+    const void* Vt; int32_t Lkpad; int32_t pad0_;   /* [B][heads*D][Lkpad], Lkpad % 64 == 0 */
+    void* O; int64_t ldo;            /* [B*Lq][ldo] */
+    int32_t B, heads, D, Lq, Lk;
+    float scale;
+} ctrl_attn_desc;
+int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream);
+
+typedef struct ctrl_tattn_desc {
+    const void* QKV; int64_t ld;     /* [(b*F+f)*HW + p][3*C]  q | k | v */
+    void* O; int64_t ldo;            /* [rows][C] */
+    int32_t Bc, F, HW, heads;        /* head_dim 64 */
+    float scale;
+    int32_t pad0_;
+} ctrl_tattn_desc;
+int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream);
+
+int ctrl_op_gn_stats(const void* x, float* stats, int imgs, int rows_per_img, int C, int G, void* stream);
+int ctrl_op_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
+                     int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
+int ctrl_op_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                      int M, int C, float eps, void* stream);
+int ctrl_op_nchw_to_nhwc(const void* x, int dtype, void* y, int N, int C, int HW, void* stream);
+int ctrl_op_nhwc_to_nchw(const void* x, void* y, int dtype, int N, int C, int HW, float scale, void* stream);
+int ctrl_avgpool_nchw(const void* x, void* y, int dtype, int NC, int Hin, int Win, int Hout, int Wout, void* stream);
+int ctrl_op_timestep_sincos(const float* t, int t_count, float* out, int N, int dim, void* stream);
+int ctrl_op_linear_small(const float* x, int64_t ldx, const void* w, const float* b, float* out, int64_t ldo,
+                         int M, int N, int K, int in_silu, int out_silu, void* stream);
+int ctrl_op_blend(const void* x_spatial, const void* x_temporal, const float* mix_factor, void* y, size_t n, void* stream);
+int ctrl_op_add_rowvec(const void* x, const float* v, int64_t ldv, void* y, size_t M, int C, int rows_per_img, int vmod, void* stream);
+int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w, const float* bias, void* out,
+                           int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, void* stream);
+/* load-time packers */
+int ctrl_op_pack_conv_w(const void* w, int dtype, void* out, int Cout, int Cin, int taps, void* stream);
+int ctrl_op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, void* stream);
+int ctrl_op_pack_linear_w(const void* w, int dtype, void* out, int N, int K, int geglu, void* stream);
+int ctrl_op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, void* stream);
+
+/* ---------------------------------------------------------------- plan level */
+/* A named view of one state-dict tensor (reference layout, device memory). */
+typedef struct ctrl_tensor_ref {
+    const char* name;
+    const void* data;
+    int32_t dtype;
+    int32_t ndim;
+    int64_t shape[4];
+} ctrl_tensor_ref;
+
+/* ---- ControlNet (SD-1.5 architecture family; controlnet/controlnet.py:179-438) ---- */
+typedef struct ctrl_controlnet_config {
+    int32_t in_channels;               /* 4 */
+    int32_t conditioning_channels;     /* 3 */
+    int32_t block_out_channels[4];     /* 320,640,1280,1280 */
+    int32_t down_block_has_attn[4];    /* 1,1,1,0  (CrossAttnDownBlock2D x3, DownBlock2D) */
+    int32_t layers_per_block;          /* 2 */
+    int32_t num_attention_heads;       /* 8 (the reference's `attention_head_dim` naming quirk, :221-227) */
+    int32_t cross_attention_dim;       /* 768 */
+    int32_t cond_embed_channels[4];    /* 16,32,96,256 */
+    float norm_eps;                    /* 1e-5 */
+} ctrl_controlnet_config;
+
+typedef struct ctrl_controlnet ctrl_controlnet;   /* opaque */
+
+/* parameter inventory: names/shapes are the reference's state-dict keys (single source of truth for the
+ * Python mirror).  Returns the number of parameters; fills name/shape for index i. */
+int ctrl_controlnet_param_count(const ctrl_controlnet_config* cfg);
+int ctrl_controlnet_param_spec(const ctrl_controlnet_config* cfg, int i, char* name, int name_len,
+                               int64_t shape[4], int* ndim);
+/* builds a plan: packs the weights (fp16, MFMA-friendly layouts) into memory owned by the plan */
+int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_ref* tensors, int n_tensors,
+                           void* stream, ctrl_controlnet** out);
+void ctrl_controlnet_destroy(ctrl_controlnet* h);
+
+enum { CTRL_SKIP_CONV_IN = 1, CTRL_SKIP_TIME_EMB = 2, CTRL_GUESS_MODE = 4 };
+/* sample [N][4][Hs][Ws], timesteps fp32 device [t_count] (1 or N), encoder_hidden_states [N][Lk][cross],
+ * controlnet_cond [N][3][8*Hs][8*Ws]; outs[0..11] = down_block_res_samples, outs[12] = mid_block_res_sample,
+ * all NCHW in out_dtype, already multiplied by conditioning_scale. */
+int ctrl_controlnet_forward(ctrl_controlnet* h,
+                            const void* sample, int sample_dtype, int N, int Hs, int Ws,
+                            const float* timesteps, int t_count,
+                            const void* encoder_hidden_states, int ehs_dtype, int Lk,
+                            const void* controlnet_cond, int cond_dtype,
+                            float conditioning_scale, int flags,
+                            void* const* outs, int out_dtype, void* stream);
+
+/* ---- Ctrl-Adapter (model/ctrl_adapter.py:17-116) ---- */
+typedef struct ctrl_adapter_config {
+    int32_t backbone_sdxl;             /* 1: up-sampling scale 2 (ctrl_adapter.py:61-66) */
+    int32_t num_blocks;                /* layers per adapter block (configs use 1) */
+    int32_t num_adapters_per_location; /* 1|2|3 */
+    int32_t cross_attention_dim;       /* 2048 (sdxl) | 1024 (i2vgen-xl, svd) */
+    int32_t add_spatial_resnet, add_temporal_resnet, add_spatial_transformer, add_temporal_transformer;
+    int32_t loc_A, loc_B, loc_C, loc_D, loc_M;
+} ctrl_adapter_config;
+
+typedef struct ctrl_adapter ctrl_adapter;
+int ctrl_adapter_param_count(const ctrl_adapter_config* cfg);
+int ctrl_adapter_param_spec(const ctrl_adapter_config* cfg, int i, char* name, int name_len,
+                            int64_t shape[4], int* ndim);
+int ctrl_adapter_create(const ctrl_adapter_config* cfg, const ctrl_tensor_ref* tensors, int n_tensors,
+                        void* stream, ctrl_adapter** out);
+void ctrl_adapter_destroy(ctrl_adapter* h);
+/* ins[0..11] down_block_res_samples, ins[12] mid (may be NULL) : NCHW [N][C_i][H_i][W_i] in in_dtype, with
+ * (H_0,W_0) = (H0,W0) and the SD-1.5 pyramid below it.  outs[i] NCHW in out_dtype at the adapted
+ * resolution (x2 for sdxl); slots without an adapter are zero-filled (zeros_like, ctrl_adapter.py:193).
+ * outs[12] may be NULL.  encoder_hidden_states [ehs_batch][Lk][cross], ehs_batch = 1 (broadcast) or N. */
+int ctrl_adapter_forward(ctrl_adapter* h,
+                         const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                         const float* timesteps, int t_count,
+                         const void* encoder_hidden_states, int ehs_dtype, int ehs_batch, int Lk,
+                         void* const* outs, int out_dtype, void* stream);
+
+/* ---- Router (model/ctrl_router.py) ---- */
+/* weights_out fp32 device [num_routers + (has_mid?1:0)][E]; wg fp32 device same shape (Linear(1,E).weight[:,0]
+ * per router; ignored for equal_weights); mask host int[E] (NULL = all ones). */
+int ctrl_router_weights(const float* wg, const int* mask_host, float* weights_out, int R, int E,
+                        int equal_weights, void* stream);
+/* out = sum_k weights[row*E + widx[k]] * experts[k]  over K active experts, element-wise on n elements */
+int ctrl_router_merge(const void* const* experts_host, const float* weights_row, const int* widx_host, int K,
+                      void* out, int dtype, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTRL_HIP_H */

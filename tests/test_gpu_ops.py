@@ -1,0 +1,269 @@
+"""Op-level parity: every hand-written HIP kernel (through the ctrl_op_* C ABI) against a plain PyTorch
+fp32 reference of the same op on the CPU.  Inputs are rounded to fp16 first so both sides see identical
+values; the tolerance (stated per test) covers fp16 output rounding (2^-11) plus fp32 accumulation order.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_inf
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-3   # rel-inf; one fp16 rounding of the result is 4.9e-4 relative
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().float()
+
+
+@pytest.fixture(scope="module")
+def ops(gpu):
+    import ctrl_adapter_amd  # noqa: F401
+    from ctrl_adapter_amd import ops as o
+    return o
+
+
+def report(name, err, tol=TOL):
+    print("PARITY %-40s rel_inf=%.3e (tol %.1e)" % (name, err, tol))
+    assert err <= tol, "%s: rel_inf %.3e > %.1e" % (name, err, tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 320, 512), (4096, 1280, 1280), (1000, 960, 512), (77 * 2, 2560, 2048), (130, 512, 320)])
+def test_linear(ops, gpu, M, N, K):
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = x @ w.t() + b + r
+    wp = ops.pack_linear_w(w.to(gpu))
+    out = ops.linear(x.half().to(gpu), wp, bias=b.to(gpu), res=r.half().to(gpu))
+    report("linear %dx%dx%d" % (M, N, K), rel_inf(out, ref))
+
+
+def test_linear_geglu(ops, gpu):
+    M, K, inner = 260, 512, 2048
+    x, w, b = rnd(M, K, seed=1), rnd(2 * inner, K, seed=2, scale=0.05), rnd(2 * inner, seed=3)
+    y = x @ w.t() + b
+    ref = y[:, :inner] * F.gelu(y[:, inner:])
+    wp = ops.pack_linear_w(w.to(gpu), geglu=True)
+    bp = ops.pack_vec(b.to(gpu), geglu=True)
+    out = ops.linear(x.half().to(gpu), wp, bias=bp, geglu=True)
+    report("linear_geglu", rel_inf(out, ref))
+
+
+@pytest.mark.parametrize("cin,cout,h,stride,up", [(320, 320, 16, 1, 1), (320, 640, 16, 2, 1), (320, 320, 8, 1, 2),
+                                                  (96, 96, 32, 1, 1), (96, 256, 32, 2, 1), (640, 640, 32, 1, 1)])
+def test_conv3x3(ops, gpu, cin, cout, h, stride, up):
+    n = 2
+    x = rnd(n, cin, h, h, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=0.02)
+    b = rnd(cout, seed=3)
+    temb = rnd(n, cout, seed=4)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up == 2 else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1) + temb[:, :, None, None]
+    wp = ops.pack_conv_w(w.to(gpu))
+    xh = x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    out = ops.conv2d(xh, wp, cout, taps=9, stride=stride, up=up, bias=b.to(gpu), rowvec=temb.to(gpu))
+    report("conv3x3 %d->%d s%d up%d" % (cin, cout, stride, up), rel_inf(out.permute(0, 3, 1, 2), ref))
+
+
+def test_conv1x1_nchw_out_scaled(ops, gpu):
+    n, cin, cout, h = 2, 320, 320, 16
+    x, w, b = rnd(n, cin, h, h, seed=1), rnd(cout, cin, 1, 1, seed=2, scale=0.05), rnd(cout, seed=3)
+    ref = F.conv2d(x, w, b) * 0.7
+    wp = ops.pack_conv_w(w.to(gpu))
+    xh = x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        out = ops.conv2d(xh, wp, cout, taps=1, bias=b.to(gpu), scale=0.7, out_nchw_dtype=dt)
+        report("conv1x1 nchw %s" % dt, rel_inf(out, ref), 1e-2 if dt == torch.bfloat16 else TOL)
+
+
+def test_conv1x1_upsampled_shortcut(ops, gpu):
+    n, c, h = 2, 320, 8
+    x, w, b = rnd(n, c, h, h, seed=1), rnd(c, c, 1, 1, seed=2, scale=0.05), rnd(c, seed=3)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b)
+    wp = ops.pack_conv_w(w.to(gpu))
+    xh = x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    out = ops.conv2d(xh, wp, c, taps=1, up=2, bias=b.to(gpu))
+    report("conv1x1 up2", rel_inf(out.permute(0, 3, 1, 2), ref))
+
+
+def test_qkv_segments(ops, gpu):
+    B, Ltok, K, Cc = 2, 192, 512, 320
+    x = rnd(B * Ltok, K, seed=1)
+    w = rnd(3 * Cc, K, seed=2, scale=0.05)
+    ref = x @ w.t()
+    wp = ops.pack_linear_w(w.to(gpu))
+    qk = torch.zeros(B * Ltok, 2 * Cc, dtype=torch.float16, device=gpu)
+    Lpad = 256
+    vt = torch.zeros(B, Cc, Lpad, dtype=torch.float16, device=gpu)
+    ops.igemm(x.half().to(gpu), K, wp, B * Ltok, 3 * Cc, K,
+              segs=[(qk, 2 * Cc, 0, 2 * Cc, ops.SEG_ROW, 1), (vt, Lpad, 2 * Cc, Cc, ops.SEG_TRANSPOSED, Ltok)])
+    report("qkv seg q|k", rel_inf(qk, ref[:, :2 * Cc]))
+    vref = ref[:, 2 * Cc:].reshape(B, Ltok, Cc).permute(0, 2, 1)
+    report("qkv seg v^T", rel_inf(vt[:, :, :Ltok], vref))
+    assert vt[:, :, Ltok:].abs().max().item() == 0.0
+    # odd token count (77) exercises the scalar transposed store
+    B2, L2 = 3, 77
+    x2 = rnd(B2 * L2, K, seed=5)
+    ref2 = x2 @ w.t()
+    qk2 = torch.zeros(B2 * L2, 2 * Cc, dtype=torch.float16, device=gpu)
+    vt2 = torch.zeros(B2, Cc, 128, dtype=torch.float16, device=gpu)
+    ops.igemm(x2.half().to(gpu), K, wp, B2 * L2, 3 * Cc, K,
+              segs=[(qk2, 2 * Cc, 0, 2 * Cc, ops.SEG_ROW, 1), (vt2, 128, 2 * Cc, Cc, ops.SEG_TRANSPOSED, L2)])
+    report("qkv seg (L=77) q|k", rel_inf(qk2, ref2[:, :2 * Cc]))
+    report("qkv seg (L=77) v^T", rel_inf(vt2[:, :, :L2], ref2[:, 2 * Cc:].reshape(B2, L2, Cc).permute(0, 2, 1)))
+
+
+def test_temporal_conv(ops, gpu):
+    b, Fr, HW, Cc = 2, 5, 48, 64
+    x = rnd(b, Cc, Fr, HW, 1, seed=1)            # b c f h w
+    w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=0.05)
+    bias = rnd(Cc, seed=3)
+    ref = F.conv3d(x, w, bias, padding=(1, 0, 0))  # b c f hw 1
+    xr = x[..., 0].permute(0, 2, 3, 1).contiguous().reshape(b * Fr * HW, Cc)   # [(b f hw)][c]
+    wp = ops.pack_conv_w(w.reshape(Cc, Cc, 3, 1).to(gpu))
+    out = torch.empty(b * Fr * HW, Cc, dtype=torch.float16, device=gpu)
+    ops.igemm(xr.half().to(gpu), Cc, wp, b * Fr * HW, Cc, Cc, taps=3, mode=ops.IG_TEMPORAL, bias=bias.to(gpu),
+              segs=[(out, Cc, 0, Cc, ops.SEG_ROW, 1)], F=Fr, HW=HW)
+    refr = ref[..., 0].permute(0, 2, 3, 1).reshape(b * Fr * HW, Cc)
+    report("temporal conv3", rel_inf(out, refr))
+
+
+def _attn_ref(q, k, v, heads):
+    B, Lq, Cc = q.shape
+    D = Cc // heads
+    qh = q.reshape(B, Lq, heads, D).transpose(1, 2)
+    kh = k.reshape(B, -1, heads, D).transpose(1, 2)
+    vh = v.reshape(B, -1, heads, D).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(D)
+    o = torch.softmax(s, dim=-1) @ vh
+    return o.transpose(1, 2).reshape(B, Lq, Cc)
+
+
+@pytest.mark.parametrize("D,heads,Lq,Lk", [(64, 5, 256, 256), (64, 5, 200, 77), (64, 10, 1024, 1024), (40, 8, 256, 256),
+                                           (80, 8, 256, 77), (160, 8, 64, 64), (160, 8, 256, 77), (40, 8, 4096, 4096)])
+def test_flash_attn(ops, gpu, D, heads, Lq, Lk):
+    B = 2
+    Cc = heads * D
+    q, k, v = rnd(B, Lq, Cc, seed=1), rnd(B, Lk, Cc, seed=2), rnd(B, Lk, Cc, seed=3)
+    # spike one key against one query so the running max jumps mid-sequence (exercises the rescale path)
+    if Lk > 128:
+        k[0, Lk - 70] = q[0, 5] * 4.0
+    ref = _attn_ref(q, k, v, heads)
+    Lkpad = (Lk + 63) // 64 * 64
+    vt = torch.full((B, Cc, Lkpad), float("nan"), dtype=torch.float16)   # pad columns must be ignored
+    vt[:, :, :Lk] = v.half().permute(0, 2, 1)
+    out = ops.flash_attn(q.half().reshape(B * Lq, Cc).to(gpu), Cc, k.half().reshape(B * Lk, Cc).to(gpu), Cc,
+                         vt.to(gpu), Lkpad, B, heads, D, Lq, Lk)
+    report("flash_attn D%d h%d Lq%d Lk%d" % (D, heads, Lq, Lk), rel_inf(out.reshape(B, Lq, Cc), ref))
+
+
+def test_temporal_attn(ops, gpu):
+    for Fr in (16, 14, 24):
+        Bc, HW, heads = 2, 12, 5
+        Cc = heads * 64
+        qkv = rnd(Bc * Fr * HW, 3 * Cc, seed=Fr)
+        q, k, v = qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+
+        def to_seq(t):  # [(b f p)][c] -> [(b p)][f][c]
+            return t.reshape(Bc, Fr, HW, Cc).permute(0, 2, 1, 3).reshape(Bc * HW, Fr, Cc)
+        ref = _attn_ref(to_seq(q), to_seq(k), to_seq(v), heads)
+        ref = ref.reshape(Bc, HW, Fr, Cc).permute(0, 2, 1, 3).reshape(Bc * Fr * HW, Cc)
+        out = ops.temporal_attn(qkv.half().to(gpu), Bc, Fr, HW, heads)
+        report("temporal_attn F%d" % Fr, rel_inf(out, ref))
+
+
+@pytest.mark.parametrize("Cc,hw,silu", [(320, 32 * 32, True), (640, 16 * 16, False), (1280, 64, True), (320, 128 * 128, True)])
+def test_groupnorm(ops, gpu, Cc, hw, silu):
+    n = 2
+    x = rnd(n, hw, Cc, seed=1) + 0.5
+    g, b = rnd(Cc, seed=2) + 1.0, rnd(Cc, seed=3)
+    ref = F.group_norm(x.permute(0, 2, 1), 32, g, b, eps=1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out = ops.groupnorm(x.half().to(gpu), g.to(gpu), b.to(gpu), n, hw, eps=1e-5, silu=silu)
+    report("groupnorm C%d hw%d" % (Cc, hw), rel_inf(out, ref))
+
+
+@pytest.mark.parametrize("Cc", [512, 320, 640, 1280])
+def test_layernorm(ops, gpu, Cc):
+    x = rnd(1030, Cc, seed=1) * 2 + 0.3
+    g, b = rnd(Cc, seed=2) + 1.0, rnd(Cc, seed=3)
+    ref = F.layer_norm(x, (Cc,), g, b, eps=1e-5)
+    out = ops.layernorm(x.half().to(gpu), g.to(gpu), b.to(gpu))
+    report("layernorm C%d" % Cc, rel_inf(out, ref))
+
+
+def test_layout_and_pool(ops, gpu):
+    x = rnd(3, 70, 9, 11, seed=1)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        y = ops.nchw_to_nhwc(x.to(dt).to(gpu))
+        report("nchw_to_nhwc %s" % dt, rel_inf(y.permute(0, 3, 1, 2), x.to(dt).float()), 1e-3)
+        z = ops.nhwc_to_nchw(x.permute(0, 2, 3, 1).contiguous().half().to(gpu), dtype=dt, scale=0.5)
+        report("nhwc_to_nchw %s" % dt, rel_inf(z, x * 0.5), 5e-3)
+    lat = rnd(4, 4, 128, 128, seed=2)
+    report("avgpool 128->64", rel_inf(ops.avgpool_nchw(lat.to(gpu), 64, 64), F.adaptive_avg_pool2d(lat, (64, 64))), 1e-6)
+    img = rnd(2, 3, 1024, 1024, seed=3)
+    report("avgpool 1024->512", rel_inf(ops.avgpool_nchw(img.half().to(gpu), 512, 512), F.adaptive_avg_pool2d(img, (512, 512))), 1e-3)
+
+
+def test_timestep_and_small_linear(ops, gpu):
+    t = torch.tensor([999.0, 749.0, 1.0, 250.5])
+    for dim in (320, 640, 1280):
+        half = dim // 2
+        freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        arg = t[:, None] * freq[None]
+        ref = torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+        out = ops.timestep_sincos(t.to(gpu), 4, dim)
+        err = (out.cpu() - ref).abs().max().item()
+        print("PARITY sincos dim%d max_abs=%.3e" % (dim, err))
+        assert err < 2e-4      # fp32 sin/cos of arguments up to 1e3
+    x = rnd(16, 1280, seed=1)
+    w, b = rnd(333, 1280, seed=2, scale=0.05), rnd(333, seed=3)
+    wp = ops.pack_linear_w(w.to(gpu))
+    out = ops.linear_small(x.to(gpu), wp, b.to(gpu), in_silu=True, out_silu=True)
+    report("linear_small silu", rel_inf(out, F.silu(F.silu(x) @ w.t() + b)), 1e-5)
+    out = ops.linear_small(x[:3].contiguous().to(gpu), wp, None)
+    report("linear_small plain", rel_inf(out, x[:3] @ w.t()), 1e-5)
+
+
+def test_blend_addvec(ops, gpu):
+    a, b = rnd(100, 320, seed=1), rnd(100, 320, seed=2)
+    mix = torch.tensor([0.3])
+    al = torch.sigmoid(mix)
+    report("blend", rel_inf(ops.blend(a.half().to(gpu), b.half().to(gpu), mix.to(gpu)), al * a + (1 - al) * b))
+    v = rnd(4, 320, seed=3)
+    ref = a.reshape(4, 25, 320) + v[:, None]
+    report("add_rowvec", rel_inf(ops.add_rowvec(a.half().to(gpu), v.to(gpu), 25, 4), ref.reshape(100, 320)))
+
+
+@pytest.mark.parametrize("cin,cout,stride,nchw,h", [(3, 16, 1, True, 64), (4, 320, 1, True, 32), (16, 16, 1, False, 48),
+                                                    (16, 32, 2, False, 48), (32, 32, 1, False, 32)])
+def test_conv3x3_direct(ops, gpu, cin, cout, stride, nchw, h):
+    n = 2
+    x, w, b = rnd(n, cin, h, h, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.1), rnd(cout, seed=3)
+    ref = F.silu(F.conv2d(x, w, b, stride=stride, padding=1))
+    wd = ops.pack_conv_w_direct(w.to(gpu))
+    xin = x.to(gpu) if nchw else x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    out = ops.conv3x3_direct(xin, wd, b.to(gpu), cout, stride=stride, silu=True, nchw=nchw)
+    report("conv3x3_direct %d->%d s%d" % (cin, cout, stride), rel_inf(out.permute(0, 3, 1, 2), ref))
+
+
+def test_router(ops, gpu):
+    wg = torch.randn(13, 3, generator=torch.Generator().manual_seed(1))
+    for mask in ([1, 1, 1], [1, 0, 1]):
+        lg = wg.clone()
+        for e, m in enumerate(mask):
+            if m == 0:
+                lg[:, e] -= 1e6
+        ref = torch.softmax(lg, dim=-1)
+        out = ops.router_weights(wg.to(gpu), mask)
+        report("router softmax mask=%s" % mask, rel_inf(out, ref), 1e-6)
+    xs = [rnd(2, 320, 8, 8, seed=i) for i in range(3)]
+    w = torch.softmax(wg, -1)
+    ref = sum(w[4, e] * xs[e] for e in range(3))
+    for dt in (torch.float32, torch.float16):
+        out = ops.router_merge([x.to(dt).to(gpu) for x in xs], w[4].contiguous().to(gpu), [0, 1, 2])
+        report("router merge %s" % dt, rel_inf(out, ref), 1e-6 if dt == torch.float32 else TOL)
