@@ -1,0 +1,93 @@
+"""Generates tests/golden/*.pt by running the REFERENCE'S OWN hot-path files from /root/reference
+(controlnet/controlnet.py, model/ctrl_adapter.py, model/adapter_spatial_temporal.py, model/resnet_block_2d.py,
+model/ctrl_router.py) unmodified, on top of oracle/_shim (a minimal `diffusers` whose blocks are oracle/blocks.py).
+
+Run in the build container only (the GPU box has no /root/reference):   python tests/golden/make_golden.py
+Stored per output tensor: shape, float64 sum and abs-sum, and <=4096 evenly strided fp32 samples -- enough to pin
+the values while keeping fixtures small.  Inputs and weights are regenerated from seeds (tests/golden/cases.py,
+oracle/init.py), keyed by parameter NAME so a state-dict key mismatch would surface as a value mismatch.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(ROOT, "oracle", "_shim"), REF, ROOT, os.path.join(ROOT, "tests", "golden")]
+
+torch.Tensor.cuda = lambda self, *a, **k: self        # model/ctrl_router.py:21,38 hard-code .cuda()
+
+from oracle.init import seeded_init  # noqa: E402
+import cases  # noqa: E402
+
+
+def digest(t):
+    t = t.detach().float().contiguous()
+    flat = t.reshape(-1)
+    step = max(1, flat.numel() // 4096)
+    return dict(shape=list(t.shape), sum=float(flat.double().sum()), abssum=float(flat.double().abs().sum()),
+                step=step, samples=flat[::step][:4096].clone())
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+
+    from controlnet.controlnet import ControlNetModel
+    from model.ctrl_adapter import ControlNetAdapter
+    from model.ctrl_router import ControlNetRouter
+
+    # ---- G1: ControlNet (SD-1.5 architecture), tiny latent grid ----
+    net = seeded_init(ControlNetModel(**cases.CONTROLNET_KW).eval(), seed=11)
+    nparams = sum(p.numel() for p in net.parameters())
+    keys = sorted(net.state_dict().keys())
+    g1 = {"n_params": nparams, "keys": keys, "runs": {}}
+    inp = cases.controlnet_inputs()
+    for tag, kw in {"plain": {}, "scale0.5": dict(conditioning_scale=0.5), "skip_conv_in": dict(skip_conv_in=True),
+                    "skip_time_emb": dict(skip_time_emb=True), "guess": dict(guess_mode=True)}.items():
+        down, mid = net(inp["sample"], inp["timestep"], encoder_hidden_states=inp["encoder_hidden_states"],
+                        controlnet_cond=inp["controlnet_cond"], return_dict=False, **kw)
+        g1["runs"][tag] = [digest(d) for d in down] + [digest(mid)]
+    torch.save(g1, os.path.join(out_dir, "controlnet_sd15.pt"))
+    print("controlnet: %d params (%.1f M), %d keys" % (nparams, nparams / 1e6, len(keys)))
+    del net
+
+    # ---- G2: SDXL adapter (spatial, up-sampling x2) ----
+    ad = seeded_init(ControlNetAdapter(**cases.ADAPTER_SDXL).eval(), seed=22)
+    downs, _ = cases.pyramid_inputs(N=2, h0=8, seed=200, with_mid=False)
+    ehs = cases.seeded_tensor((2, 77, 2048), 290)
+    out, mid = ad(downs, sparsity_masking=None, num_frames=1, timestep=torch.tensor(749.0), encoder_hidden_states=ehs)
+    assert mid is None
+    torch.save({"n_params": sum(p.numel() for p in ad.parameters()), "keys": sorted(ad.state_dict().keys()),
+                "out": [digest(o) for o in out]}, os.path.join(out_dir, "adapter_sdxl.pt"))
+    print("adapter sdxl: %.1f M params" % (sum(p.numel() for p in ad.parameters()) / 1e6))
+    del ad
+
+    # ---- G3: video adapter (all four sub-modules, A-D + M), 2 clips x 4 frames ----
+    ad = seeded_init(ControlNetAdapter(**cases.ADAPTER_VIDEO).eval(), seed=33)
+    downs, midin = cases.pyramid_inputs(N=8, h0=8, seed=300, with_mid=True)
+    ehs = cases.seeded_tensor((1, 1, 1024), 390)
+    out, mid = ad(downs, mid_block_res_sample=midin, sparsity_masking=None, num_frames=4,
+                  timestep=torch.tensor(961.0), encoder_hidden_states=ehs)
+    torch.save({"n_params": sum(p.numel() for p in ad.parameters()), "keys": sorted(ad.state_dict().keys()),
+                "out": [digest(o) for o in out] + [digest(mid)]}, os.path.join(out_dir, "adapter_video.pt"))
+    print("adapter video: %.1f M params" % (sum(p.numel() for p in ad.parameters()) / 1e6))
+    del ad
+
+    # ---- G4: router ----
+    r = seeded_init(ControlNetRouter(num_experts=3, router_type="simple_weights", num_routers=12).eval(), seed=44)
+    g4 = {"keys": sorted(r.state_dict().keys()), "runs": {}}
+    for tag, mask in {"all": [1, 1, 1], "m101": [1, 0, 1], "none": None}.items():
+        dw, mw = r(sparse_mask=mask)
+        g4["runs"][tag] = dict(down=dw.clone(), mid=mw.clone())
+    r2 = ControlNetRouter(num_experts=2, router_type="equal_weights", num_routers=12).eval()
+    dw, mw = r2(sparse_mask=[1, 1])
+    g4["equal"] = dict(down=dw.clone(), mid=mw.clone())
+    torch.save(g4, os.path.join(out_dir, "router.pt"))
+    print("router ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""The standalone oracle restatements (oracle/*.py) against the golden vectors produced by the reference's OWN
+files run over the diffusers shim (tests/golden/make_golden.py).  CPU only."""
+import pytest
+import torch
+
+from helpers import load_golden, check_digest
+import cases
+from oracle.init import seeded_init, seeded_tensor
+from oracle.controlnet import ControlNetOracle
+from oracle.adapter import ControlNetAdapterOracle
+from oracle.router import RouterOracle, merge_inference, merge_training
+
+TOL = 2e-5   # fp32 vs fp32, different op grouping only
+
+
+@pytest.fixture(scope="module")
+def controlnet():
+    torch.set_grad_enabled(False)
+    return seeded_init(ControlNetOracle(**cases.CONTROLNET_KW).eval(), seed=11)
+
+
+def test_controlnet_structure(controlnet):
+    g = load_golden("controlnet_sd15.pt")
+    assert sum(p.numel() for p in controlnet.parameters()) == g["n_params"] == 361279120
+    assert sorted(controlnet.state_dict().keys()) == g["keys"]
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", {}), ("scale0.5", dict(conditioning_scale=0.5)),
+                                    ("skip_conv_in", dict(skip_conv_in=True)), ("skip_time_emb", dict(skip_time_emb=True)),
+                                    ("guess", dict(guess_mode=True))])
+def test_controlnet_golden(controlnet, tag, kw):
+    g = load_golden("controlnet_sd15.pt")["runs"][tag]
+    inp = cases.controlnet_inputs()
+    down, mid = controlnet(inp["sample"], inp["timestep"], inp["encoder_hidden_states"], inp["controlnet_cond"], **kw)
+    for i, (t, d) in enumerate(zip(list(down) + [mid], g)):
+        check_digest(t, d, TOL, "controlnet[%s] out %d" % (tag, i))
+
+
+def test_adapter_sdxl_golden():
+    torch.set_grad_enabled(False)
+    g = load_golden("adapter_sdxl.pt")
+    ad = seeded_init(ControlNetAdapterOracle(**cases.ADAPTER_SDXL).eval(), seed=22)
+    assert sorted(ad.state_dict().keys()) == g["keys"]
+    assert sum(p.numel() for p in ad.parameters()) == g["n_params"]
+    downs, _ = cases.pyramid_inputs(N=2, h0=8, seed=200, with_mid=False)
+    out, mid = ad(downs, num_frames=1, timestep=torch.tensor(749.0), encoder_hidden_states=seeded_tensor((2, 77, 2048), 290))
+    assert mid is None
+    for i, (t, d) in enumerate(zip(out, g["out"])):
+        check_digest(t, d, TOL, "adapter_sdxl out %d" % i)
+    for i in (9, 10, 11):
+        assert out[i].abs().max().item() == 0.0      # zeros_like for slots without an adapter
+
+
+def test_adapter_video_golden():
+    torch.set_grad_enabled(False)
+    g = load_golden("adapter_video.pt")
+    ad = seeded_init(ControlNetAdapterOracle(**cases.ADAPTER_VIDEO).eval(), seed=33)
+    assert sorted(ad.state_dict().keys()) == g["keys"]
+    assert sum(p.numel() for p in ad.parameters()) == g["n_params"]
+    downs, midin = cases.pyramid_inputs(N=8, h0=8, seed=300, with_mid=True)
+    out, mid = ad(downs, mid_block_res_sample=midin, num_frames=4, timestep=torch.tensor(961.0),
+                  encoder_hidden_states=seeded_tensor((1, 1, 1024), 390))
+    for i, (t, d) in enumerate(zip(list(out) + [mid], g["out"])):
+        check_digest(t, d, TOL, "adapter_video out %d" % i)
+
+
+def test_router_golden():
+    torch.set_grad_enabled(False)
+    g = load_golden("router.pt")
+    r = seeded_init(RouterOracle(num_experts=3, router_type="simple_weights", num_routers=12).eval(), seed=44)
+    assert sorted(r.state_dict().keys()) == g["keys"]
+    for tag, mask in {"all": [1, 1, 1], "m101": [1, 0, 1], "none": None}.items():
+        dw, mw = r(sparse_mask=mask)
+        assert torch.allclose(dw, g["runs"][tag]["down"], atol=1e-7)
+        assert torch.allclose(mw, g["runs"][tag]["mid"], atol=1e-7)
+    dw, mw = RouterOracle(num_experts=2, router_type="equal_weights")(sparse_mask=[1, 1])
+    assert torch.allclose(dw, g["equal"]["down"]) and torch.allclose(mw, g["equal"]["mid"])
+
+
+def test_merge_semantics():
+    """quirk N6: the inference merge weights every active expert by w[k][0]."""
+    E, F = 3, 4
+    downs = [[seeded_tensor((2, 8, 2, 2), 10 * e + r) for r in range(12)] for e in range(E)]
+    mids = [seeded_tensor((2, 8, 1, 1), 500 + e) for e in range(E)]
+    dw = torch.softmax(seeded_tensor((12, E), 1, fp16_round=False), -1)
+    mw = torch.softmax(seeded_tensor((E,), 2, fp16_round=False), -1)
+    md, mm = merge_inference(downs, mids, dw, mw, [1, 1, 1], F)
+    for r in range(12):
+        assert torch.allclose(md[r], dw[r][0] * sum(downs[e][r] for e in range(E)), atol=1e-6)
+    assert torch.allclose(mm, mw[0] * sum(mids), atol=1e-6)
+    td, tm = merge_training(downs, mids, dw, mw, [1, 1, 1])
+    assert torch.allclose(td[3], sum(dw[3][e] * downs[e][3] for e in range(E)), atol=1e-6)
