@@ -25,12 +25,12 @@ class IGemmDesc(C.Structure):
                 ("W", C.c_void_p), ("M", C.c_int32), ("Nout", C.c_int32), ("Ktot", C.c_int32), ("pad1_", C.c_int32),
                 ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_ld", C.c_int32), ("rows_per_img", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int64), ("scale", C.c_float), ("geglu", C.c_int32),
-                ("nseg", C.c_int32), ("pad2_", C.c_int32), ("seg", IGemmSeg * 3)]
+                ("nseg", C.c_int32), ("act", C.c_int32), ("seg", IGemmSeg * 3)]
 
 
 class AttnDesc(C.Structure):
     _fields_ = [("Q", C.c_void_p), ("ldq", C.c_int64), ("K", C.c_void_p), ("ldk", C.c_int64),
-                ("Vt", C.c_void_p), ("Lkpad", C.c_int32), ("pad0_", C.c_int32),
+                ("Vt", C.c_void_p), ("Lkpad", C.c_int32), ("kvB", C.c_int32),
                 ("O", C.c_void_p), ("ldo", C.c_int64),
                 ("B", C.c_int32), ("heads", C.c_int32), ("D", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
                 ("scale", C.c_float)]
@@ -44,7 +44,7 @@ class TAttnDesc(C.Structure):
 
 class TensorRef(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
-                ("shape", C.c_int64 * 4)]
+                ("shape", C.c_int64 * 6)]
 
 
 class ControlNetConfig(C.Structure):

@@ -1,0 +1,144 @@
+"""ControlNetModel -- drop-in mirror of the reference's controlnet/controlnet.py:ControlNetModel whose forward runs
+entirely in libctrlhip (hand-written gfx950 kernels).  Same forward signature (:662-678), same return
+(ControlNetOutput or the (down_block_res_samples, mid_block_res_sample) tuple, :876-881), same state-dict keys."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._plan import ParamTreeModule, Config, c_spec, timesteps_to_device_f32
+
+
+class ControlNetOutput(tuple):
+    """(down_block_res_samples, mid_block_res_sample) with attribute access (diffusers ControlNetOutput)."""
+
+    def __new__(cls, down_block_res_samples, mid_block_res_sample):
+        return super().__new__(cls, (down_block_res_samples, mid_block_res_sample))
+
+    down_block_res_samples = property(lambda self: self[0])
+    mid_block_res_sample = property(lambda self: self[1])
+
+
+class ControlNetModel(ParamTreeModule):
+    def __init__(self, in_channels=4, conditioning_channels=3, flip_sin_to_cos=True, freq_shift=0,
+                 down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+                 mid_block_type="UNetMidBlock2DCrossAttn", only_cross_attention=False,
+                 block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1,
+                 mid_block_scale_factor=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=1280,
+                 transformer_layers_per_block=1, encoder_hid_dim=None, encoder_hid_dim_type=None, attention_head_dim=8,
+                 num_attention_heads=None, use_linear_projection=False, class_embed_type=None, addition_embed_type=None,
+                 addition_time_embed_dim=None, num_class_embeds=None, upcast_attention=False,
+                 resnet_time_scale_shift="default", projection_class_embeddings_input_dim=None,
+                 controlnet_conditioning_channel_order="rgb", conditioning_embedding_out_channels=(16, 32, 96, 256),
+                 global_pool_conditions=False, addition_embed_type_num_heads=64):
+        super().__init__()
+        self.config = Config({k: v for k, v in locals().items() if k not in ("self", "__class__")})
+        # the hot path only reaches this configuration family (SD-1.5 ControlNets); anything else fails loudly
+        unsupported = []
+        if not flip_sin_to_cos or freq_shift != 0: unsupported.append("time_proj variant")
+        if len(block_out_channels) != 4 or len(down_block_types) != 4: unsupported.append("block count != 4")
+        if mid_block_type != "UNetMidBlock2DCrossAttn": unsupported.append("mid_block_type")
+        if only_cross_attention or use_linear_projection or upcast_attention: unsupported.append("attention variant")
+        if act_fn not in ("silu", "swish") or norm_num_groups != 32 or resnet_time_scale_shift != "default":
+            unsupported.append("resnet variant")
+        if transformer_layers_per_block != 1: unsupported.append("transformer_layers_per_block")
+        if any(v is not None for v in (encoder_hid_dim, encoder_hid_dim_type, class_embed_type, addition_embed_type,
+                                        num_class_embeds)):
+            unsupported.append("class/addition embeddings")
+        if controlnet_conditioning_channel_order != "rgb" or global_pool_conditions: unsupported.append("channel order / global pool")
+        if downsample_padding != 1 or mid_block_scale_factor != 1: unsupported.append("padding/scale")
+        if unsupported:
+            raise ValueError("ControlNetModel (libctrlhip): unsupported configuration: " + ", ".join(unsupported))
+        heads = num_attention_heads or attention_head_dim      # the reference's naming quirk (:221-227)
+        if not isinstance(heads, int):
+            raise ValueError("per-block head counts are not supported")
+        cfg = L.ControlNetConfig()
+        cfg.in_channels = in_channels
+        cfg.conditioning_channels = conditioning_channels
+        for i in range(4):
+            cfg.block_out_channels[i] = block_out_channels[i]
+            cfg.down_block_has_attn[i] = int(down_block_types[i] == "CrossAttnDownBlock2D")
+            cfg.cond_embed_channels[i] = conditioning_embedding_out_channels[i]
+        cfg.layers_per_block = layers_per_block
+        cfg.num_attention_heads = heads
+        cfg.cross_attention_dim = cross_attention_dim
+        cfg.norm_eps = norm_eps
+        self._cfg = cfg
+        lib = L.lib()
+        self._register_spec(c_spec(lib.ctrl_controlnet_param_count, lib.ctrl_controlnet_param_spec, cfg))
+        co = list(block_out_channels)
+        self._slot_channels = [co[0]] + sum(([co[i]] * (layers_per_block + (1 if i != 3 else 0)) for i in range(4)), [])
+        self._slot_factor = [1] + sum(([2 ** i] * layers_per_block + ([2 ** (i + 1)] if i != 3 else []) for i in range(4)), [])
+
+    def config_dict(self):
+        return {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()}
+
+    def _destroy(self, plan):
+        L.lib().ctrl_controlnet_destroy(plan)
+
+    def _ensure_plan(self):
+        if self._plan is None:
+            refs, n, keep = self._tensor_refs()
+            h = C.c_void_p()
+            L.check(L.lib().ctrl_controlnet_create(C.byref(self._cfg), refs, n, L.cur_stream(), C.byref(h)))
+            self._plan = h
+        return self._plan
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0,
+                class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
+                cross_attention_kwargs=None, guess_mode=False, return_dict=True, skip_conv_in=False, skip_time_emb=False):
+        if class_labels is not None or timestep_cond is not None or attention_mask is not None:
+            raise ValueError("class_labels / timestep_cond / attention_mask are not supported by the HIP hot path")
+        if not sample.is_cuda:
+            raise RuntimeError("ControlNetModel (libctrlhip) runs on the GPU only; there is no CPU fallback")
+        N, _, Hs, Ws = sample.shape
+        if controlnet_cond.shape[0] != N or controlnet_cond.shape[2] != 8 * Hs or controlnet_cond.shape[3] != 8 * Ws:
+            raise ValueError("controlnet_cond must be [N, C, 8*H, 8*W] for a latent sample [N, 4, H, W]")
+        ehs = encoder_hidden_states
+        if ehs.dim() != 3 or ehs.shape[0] != N or ehs.shape[2] != self.config.cross_attention_dim:
+            raise ValueError("encoder_hidden_states must be [N, L, %d]" % self.config.cross_attention_dim)
+        plan = self._ensure_plan()
+        t = timesteps_to_device_f32(timestep, N, sample.device)
+        out_dtype = sample.dtype if sample.dtype in (torch.float16, torch.bfloat16, torch.float32) else self.dtype
+        outs = [torch.empty(N, c, max(Hs // f, 1), max(Ws // f, 1), dtype=out_dtype, device=sample.device)
+                for c, f in zip(self._slot_channels, self._slot_factor)]
+        outs.append(torch.empty(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device))
+        sample_c, ehs_c, cond_c = sample.contiguous(), ehs.contiguous(), controlnet_cond.contiguous()
+        ptrs = (C.c_void_p * 13)(*[o.data_ptr() for o in outs])
+        flags = (1 if skip_conv_in else 0) | (2 if skip_time_emb else 0) | (4 if guess_mode else 0)
+        L.check(L.lib().ctrl_controlnet_forward(
+            plan, L.ptr(sample_c), L.dtype_code(sample_c.dtype), N, Hs, Ws, L.ptr(t), t.numel(),
+            L.ptr(ehs_c), L.dtype_code(ehs_c.dtype), ehs_c.shape[1], L.ptr(cond_c), L.dtype_code(cond_c.dtype),
+            C.c_float(float(conditioning_scale)), flags, ptrs, L.dtype_code(out_dtype), L.cur_stream()))
+        down, mid = outs[:12], outs[12]
+        if not return_dict:
+            return (down, mid)
+        return ControlNetOutput(down, mid)
+
+
+class MultiControlNetModel(torch.nn.Module):
+    """controlnet/multicontrolnet.py:45-99: runs K nets on the same latents and returns per-net LISTS."""
+
+    def __init__(self, controlnets):
+        super().__init__()
+        self.nets = torch.nn.ModuleList(controlnets)
+
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, class_labels=None,
+                timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
+                guess_mode=False, return_dict=True, skip_conv_in=False, skip_time_emb=False):
+        downs, mids = [], []
+        for image, scale, net in zip(controlnet_cond, conditioning_scale, self.nets):   # positional zip (quirk N6)
+            d, m = net(sample, timestep, encoder_hidden_states, image, scale, guess_mode=guess_mode, return_dict=False,
+                       skip_conv_in=skip_conv_in, skip_time_emb=skip_time_emb)
+            downs.append(d)
+            mids.append(m)
+        return downs, mids
+
+
+def pool_latents(latents, size=(64, 64)):
+    """F.adaptive_avg_pool2d(latents, (64, 64)) of the callers (sdxl pipeline :1306-1309) as a HIP kernel."""
+    from . import ops
+    if tuple(latents.shape[-2:]) == tuple(size):
+        return latents
+    return ops.avgpool_nchw(latents, size[0], size[1])

@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
         }
     }
 
-    const half_t* Kbase = (const half_t*)a.K + (size_t)b * Lk * a.ldk + (size_t)h * D;
-    const half_t* Vbase = (const half_t*)a.Vt + ((size_t)b * a.heads + h) * D * (size_t)a.Lkpad;
+    const int kb = (a.kvB == 1) ? 0 : b;     // K/V shared by every batch (broadcast encoder states)
+    const half_t* Kbase = (const half_t*)a.K + (size_t)kb * Lk * a.ldk + (size_t)h * D;
+    const half_t* Vbase = (const half_t*)a.Vt + ((size_t)kb * a.heads + h) * D * (size_t)a.Lkpad;
 
     h8 kreg[KCH], vreg[VCH];
     auto gload = [&](int t) {
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs a) {
 
 int op_flash_attn(const AttnArgs& a, hipStream_t s) {
     CTRL_CHECK(a.B > 0 && a.heads > 0 && a.Lq > 0 && a.Lk > 0, "flash_attn: empty problem");
+    CTRL_CHECK(a.kvB == 1 || a.kvB == a.B, "flash_attn: kvB must be 1 or B");
     CTRL_CHECK(a.Lkpad % 64 == 0 && a.Lkpad >= a.Lk, "flash_attn: Lkpad must be a multiple of 64 and >= Lk");
     CTRL_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "flash_attn: leading dims must be multiples of 8");
     CTRL_CHECK((((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.Vt) & 15) == 0 && ((uintptr_t)a.O & 7) == 0,

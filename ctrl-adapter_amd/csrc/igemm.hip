@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a, int ntm, int nt
                     const float g = acc[mi][ni + (NI > 1 ? 1 : 0)][i] + bg;
                     x = x * gelu_erf_f(g);
                 }
+                if (a.act == 1) x = silu_f(x);
                 if (Rptr && row < a.M) x += (float)Rptr[(size_t)row * a.ldres + ocol];
                 v[i] = x * a.scale;
             }

@@ -1,0 +1,427 @@
+// Ctrl-Adapter forward orchestrator (C++ host code, enqueues the gfx950 kernels of libctrlhip).
+//
+// Restates the control flow of the reference:
+//   ControlNetAdapter        model/ctrl_adapter.py:17-116 (which slots get a block :119-168), forward :171-224
+//   AdapterSpatioTemporal    model/adapter_spatial_temporal.py:11-171 (module tree), forward :175-292:
+//     timestep normalisation :190-198 -> resnet time embedding :206-209 -> spatial ResNet (+ x2 nearest
+//     up-sampling of both branches, model/resnet_block_2d.py:174-184) :213-219 -> temporal ResNet + AlphaBlender
+//     :223-231 -> GroupNorm / proj_in :252-257 -> frame-index embedding :259-266 -> spatial transformer :270-273 ->
+//     temporal transformer + AlphaBlender :278-282 -> proj_out + residual :286-289
+// Frames of a clip are kept frame-major ([(b f) h w][C], the reference's own (bf) c h w order), so the temporal
+// ops address the frame axis with a stride instead of materialising the b c f h w permutes.
+#include "plan_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace {
+
+struct TResnetW {             // diffusers TemporalResnetBlock
+    Norm norm1, norm2;
+    ConvW conv1, conv2;
+    Lin temb;                 // time_emb_proj
+};
+
+struct AdapterLayerW {
+    ResnetW sres; Lin sres_temb;
+    TResnetW tres;
+    float* res_mix = nullptr;
+    BasicTBW stb;
+    TemporalTBW ttb;
+    float* tr_mix = nullptr;
+};
+
+struct AdapterBlockW {
+    int C = 0, up = 1, heads = 0;
+    Lin rte1, rte2;           // resnet_time_embedding
+    Norm norm;
+    Lin proj_in, proj_out;
+    Lin tte1, tte2;           // transformer_time_embedding
+    std::vector<AdapterLayerW> layers;
+};
+
+struct AdapterW {
+    ctrl_adapter_config cfg;
+    std::vector<int> slot_ids;          // which of the 12 ControlNet outputs get a block (ctrl_adapter.py:119-139)
+    std::vector<AdapterBlockW> blocks;  // in slot order
+    bool has_mid = false;
+    AdapterBlockW mid;
+};
+
+const int INNER = 512;   // num_attention_heads(8) * attention_head_dim(64): adapter_spatial_temporal.py:62
+
+int build_block(ParamSink& ps, const std::string& pre, int C, const ctrl_adapter_config& c, int up, AdapterBlockW* b) {
+    b->C = C; b->up = up; b->heads = C / 64;      // :42 -- head count = C / attention_head_dim
+    const bool sr = c.add_spatial_resnet, tr = c.add_temporal_resnet, st = c.add_spatial_transformer, tt = c.add_temporal_transformer;
+    if (sr || tr) {
+        TRY(ps.linear(pre + ".resnet_time_embedding.linear_1", C, C, true, false, &b->rte1));
+        TRY(ps.linear(pre + ".resnet_time_embedding.linear_2", C, C, true, false, &b->rte2));
+    }
+    if (st || tt) {
+        TRY(ps.norm(pre + ".norm", C, &b->norm));
+        if (tt) {
+            TRY(ps.linear(pre + ".transformer_time_embedding.linear_1", INNER, C, true, false, &b->tte1));
+            TRY(ps.linear(pre + ".transformer_time_embedding.linear_2", INNER, INNER, true, false, &b->tte2));
+        }
+        TRY(ps.linear(pre + ".proj_in", INNER, C, true, false, &b->proj_in));
+        TRY(ps.linear(pre + ".proj_out", C, INNER, true, false, &b->proj_out));
+    }
+    b->layers.resize(c.num_blocks);
+    for (int i = 0; i < c.num_blocks; ++i) {
+        AdapterLayerW& L = b->layers[i];
+        const std::string si = std::to_string(i);
+        if (sr) {
+            TRY(build_resnet(ps, pre + ".spatial_resnets." + si, C, C, true, &L.sres));
+            TRY(ps.linear(pre + ".spatial_resnets." + si + ".time_emb_proj", C, C, true, false, &L.sres_temb));
+        }
+        if (tr) {
+            const std::string p = pre + ".temporal_resnets." + si;
+            TRY(ps.norm(p + ".norm1", C, &L.tres.norm1));
+            TRY(ps.conv(p + ".conv1", C, C, 3, true, &L.tres.conv1));
+            TRY(ps.linear(p + ".time_emb_proj", C, C, true, false, &L.tres.temb));
+            TRY(ps.norm(p + ".norm2", C, &L.tres.norm2));
+            TRY(ps.conv(p + ".conv2", C, C, 3, true, &L.tres.conv2));
+        }
+        if (st) TRY(build_basic_tb(ps, pre + ".spatial_attentions." + si, INNER, b->heads, 64, c.cross_attention_dim, &L.stb));
+        if (tt) TRY(build_temporal_tb(ps, pre + ".temporal_attentions." + si, INNER, b->heads, 64, c.cross_attention_dim, &L.ttb));
+        if (sr && tr) TRY(ps.scalar(pre + ".resnets_time_mixer." + si + ".mix_factor", &L.res_mix));
+        if (st && tt) TRY(ps.scalar(pre + ".transformers_time_mixer." + si + ".mix_factor", &L.tr_mix));
+    }
+    return 0;
+}
+
+int build_adapter(ParamSink& ps, const ctrl_adapter_config& c, AdapterW* w) {
+    w->cfg = c;
+    const int n = c.num_adapters_per_location;
+    CTRL_CHECK(n >= 1 && n <= 3, "adapter: num_adapters_per_location must be 1..3");
+    CTRL_CHECK(c.num_blocks >= 1 && c.num_blocks <= 8, "adapter: num_blocks out of range");
+    CTRL_CHECK(c.cross_attention_dim % 64 == 0, "adapter: cross_attention_dim must be a multiple of 64");
+    // model/ctrl_adapter.py:119-168
+    static const int sel[4][4][3] = {{{0}, {2}, {0, 2}, {0, 1, 2}}, {{0}, {5}, {3, 5}, {3, 4, 5}},
+                                     {{0}, {8}, {6, 8}, {6, 7, 8}}, {{0}, {11}, {9, 11}, {9, 10, 11}}};
+    static const int chn[4][4][3] = {{{0}, {320}, {320, 320}, {320, 320, 320}}, {{0}, {640}, {320, 640}, {320, 640, 640}},
+                                     {{0}, {1280}, {640, 1280}, {640, 1280, 1280}}, {{0}, {1280}, {1280, 1280}, {1280, 1280, 1280}}};
+    const int on[4] = {c.loc_A, c.loc_B, c.loc_C, c.loc_D};
+    std::vector<int> chans;
+    for (int l = 0; l < 4; ++l)
+        if (on[l])
+            for (int k = 0; k < n; ++k) { w->slot_ids.push_back(sel[l][n][k]); chans.push_back(chn[l][n][k]); }
+    const int up = c.backbone_sdxl ? 2 : 1;
+    w->blocks.resize(chans.size());
+    for (size_t i = 0; i < chans.size(); ++i)
+        TRY(build_block(ps, "down_blocks_adapter." + std::to_string(i), chans[i], c, up, &w->blocks[i]));
+    w->has_mid = c.loc_M != 0;
+    if (w->has_mid) TRY(build_block(ps, "mid_block_adapter", 1280, c, up, &w->mid));
+    return 0;
+}
+
+struct AFwd {
+    int N, F, B;                 // frames total, frames per clip, clips
+    const float* t; int t_count;
+    EhsCtx e;                    // spatial cross-attention context
+    EhsCtx e_first;              // temporal cross-attention context (first frame of each clip), Lk == 1 only
+    int in_dt, out_dt;
+};
+
+// temporal ResNet on frame-major rows [(b f) hw][C]
+int run_temporal_resnet(Ctx& cx, const TResnetW& w, const half_t* x, half_t* out, const AFwd& a, int HW, int C,
+                        const float* temb /*[N][C]*/) {
+    const size_t mk = cx.mark();
+    const int N = a.N, M = N * HW;
+    float* tp = cx.f((size_t)N * C);
+    RUN(cx, op_linear_small(temb, C, w.temb.w, w.temb.b, tp, C, N, C, C, 1, 0, cx.s));
+    half_t* n1 = cx.h((size_t)M * C);
+    TRY(run_groupnorm(cx, w.norm1, x, n1, a.B, a.F * HW, 1e-6f, true));     // statistics span the clip's frames
+    half_t* h1 = cx.h((size_t)M * C);
+    IGemmArgs g = {};
+    g.A = n1; g.lda = C; g.mode = IG_TEMPORAL; g.Cin = C; g.taps = 3; g.F = a.F; g.HW = HW;
+    g.W = w.conv1.w; g.M = M; g.Nout = C; g.Ktot = 3 * C; g.bias = w.conv1.b;
+    g.rowvec = tp; g.rowvec_ld = C; g.rows_per_img = HW; g.scale = 1.f;
+    g.nseg = 1; g.seg[0] = IGemmSeg{h1, C, 0, C, SEG_ROW, DT_F16, 1, 0};
+    RUN(cx, op_igemm(g, cx.s));
+    half_t* n2 = n1;
+    TRY(run_groupnorm(cx, w.norm2, h1, n2, a.B, a.F * HW, 1e-6f, true));
+    IGemmArgs g2 = g;
+    g2.A = n2; g2.W = w.conv2.w; g2.bias = w.conv2.b; g2.rowvec = nullptr; g2.res = x; g2.ldres = C;
+    g2.seg[0] = IGemmSeg{out, C, 0, C, SEG_ROW, DT_F16, 1, 0};
+    RUN(cx, op_igemm(g2, cx.s));
+    cx.release(mk);
+    return 0;
+}
+
+// TemporalBasicTransformerBlock on frame-major tokens X [(b f) L][512]; every op but the attention is per token
+int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const half_t* X, half_t* out, const AFwd& a, int L) {
+    const size_t mk = cx.mark();
+    const int M = a.N * L, dim = w.dim, Ci = w.attn1.inner;
+    // x = ff_in(norm_in(x)) + x
+    half_t* xn = cx.h((size_t)M * dim);
+    RUN(cx, op_layernorm(X, dim, w.norm_in.g, w.norm_in.b, xn, dim, M, dim, 1e-5f, cx.s));
+    half_t* mid = cx.h((size_t)M * 4 * dim);
+    TRY(run_linear(cx, w.ffin1, xn, dim, mid, 4 * dim, M, nullptr, 0));
+    half_t* x0 = cx.h((size_t)M * dim);
+    TRY(run_linear(cx, w.ffin2, mid, 4 * dim, x0, dim, M, X, dim));
+    // x = attn1(norm1(x)) + x  (sequence = frames)
+    RUN(cx, op_layernorm(x0, dim, w.norm1.g, w.norm1.b, xn, dim, M, dim, 1e-5f, cx.s));
+    half_t* qkv = cx.h((size_t)M * 3 * Ci);
+    TRY(run_linear(cx, w.attn1.qkv, xn, dim, qkv, 3 * Ci, M, nullptr, 0));
+    half_t* o = cx.h((size_t)M * Ci);
+    TAttnArgs ta = {};
+    ta.QKV = qkv; ta.ld = 3 * Ci; ta.O = o; ta.ldo = Ci; ta.Bc = a.B; ta.F = a.F; ta.HW = L; ta.heads = w.attn1.heads;
+    ta.scale = 0.125f;
+    RUN(cx, op_temporal_attn(ta, cx.s));
+    half_t* x1 = cx.h((size_t)M * dim);
+    TRY(run_linear(cx, w.attn1.out, o, Ci, x1, dim, M, x0, dim));
+    // x = attn2(norm2(x), first-frame context) + x : one key => query independent (note N5)
+    {
+        const EhsCtx& e = a.e_first;
+        float* v = cx.f((size_t)e.batch * Ci);
+        RUN(cx, op_linear_small(e.f32, e.cross, w.attn2.v.w, nullptr, v, Ci, e.batch, Ci, e.cross, 0, 0, cx.s));
+        float* ov = cx.f((size_t)e.batch * dim);
+        RUN(cx, op_linear_small(v, Ci, w.attn2.out.w, w.attn2.out.b, ov, dim, e.batch, dim, Ci, 0, 0, cx.s));
+        // rows are (b f p); context index = clip b  -> (row / (F*L)) % batch
+        RUN(cx, op_add_rowvec(x1, ov, dim, x0, (size_t)M, dim, a.F * L, e.batch, cx.s));
+    }
+    // x = ff(norm3(x)) + x
+    RUN(cx, op_layernorm(x0, dim, w.norm3.g, w.norm3.b, xn, dim, M, dim, 1e-5f, cx.s));
+    half_t* mid2 = cx.h((size_t)M * 4 * dim);
+    TRY(run_linear(cx, w.ff1, xn, dim, mid2, 4 * dim, M, nullptr, 0));
+    TRY(run_linear(cx, w.ff2, mid2, 4 * dim, out, dim, M, x0, dim));
+    cx.release(mk);
+    return 0;
+}
+
+// one AdapterSpatioTemporal block: in NCHW [N][C][h][w] (in_dt) -> out NCHW [N][C][h*up][w*up] (out_dt)
+int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, const AFwd& a, const void* in, void* out,
+              int h, int w) {
+    const size_t mk = cx.mark();
+    const int N = a.N, C = b.C;
+    const bool sr = c.add_spatial_resnet, tr = c.add_temporal_resnet, st = c.add_spatial_transformer, tt = c.add_temporal_transformer;
+    half_t* x = cx.h((size_t)N * h * w * C);
+    RUN(cx, op_nchw_to_nhwc(in, a.in_dt, x, N, C, h * w, cx.s));
+    int H = h, W = w;
+    // resnet time embedding (:206-209): Timesteps(C) -> Linear -> SiLU -> Linear ; identical for every layer
+    float* temb = nullptr;
+    if (sr || tr) {
+        float* ts = cx.f((size_t)N * C);
+        RUN(cx, op_timestep_sincos(a.t, a.t_count, ts, N, C, cx.s));
+        float* t1 = cx.f((size_t)N * C);
+        RUN(cx, op_linear_small(ts, C, b.rte1.w, b.rte1.b, t1, C, N, C, C, 0, 1, cx.s));
+        temb = cx.f((size_t)N * C);
+        RUN(cx, op_linear_small(t1, C, b.rte2.w, b.rte2.b, temb, C, N, C, C, 0, 0, cx.s));
+    }
+    float* femb = nullptr;     // frame-index embedding [F][512] (:259-266)
+    if (tt) {
+        float* fs = cx.f((size_t)a.F * C);
+        RUN(cx, op_frameidx_sincos(fs, a.F, a.F, C, cx.s));
+        float* f1 = cx.f((size_t)a.F * INNER);
+        RUN(cx, op_linear_small(fs, C, b.tte1.w, b.tte1.b, f1, INNER, a.F, INNER, C, 0, 1, cx.s));
+        femb = cx.f((size_t)a.F * INNER);
+        RUN(cx, op_linear_small(f1, INNER, b.tte2.w, b.tte2.b, femb, INNER, a.F, INNER, INNER, 0, 0, cx.s));
+    }
+    const size_t nl = b.layers.size();
+    for (size_t i = 0; i < nl; ++i) {
+        const AdapterLayerW& Lw = b.layers[i];
+        const int up = (i == 0) ? b.up : 1;
+        const bool last = (i + 1 == nl);
+        if (sr) {
+            float* tp = cx.f((size_t)N * C);
+            RUN(cx, op_linear_small(temb, C, Lw.sres_temb.w, Lw.sres_temb.b, tp, C, N, C, C, 1, 0, cx.s));
+            half_t* y = cx.h((size_t)N * H * up * W * up * C);
+            TRY(run_resnet(cx, Lw.sres, x, y, N, H, W, up, tp, C, 1e-6f));
+            x = y; H *= up; W *= up;
+        } else if (up > 1) {
+            CTRL_FAIL("adapter: up-sampling without a spatial resnet (F.interpolate path, :235-237) is not implemented");
+        }
+        if (tr) {
+            half_t* yt = cx.h((size_t)N * H * W * C);
+            TRY(run_temporal_resnet(cx, Lw.tres, x, yt, a, H * W, C, temb));
+            if (sr) {
+                half_t* yb = cx.h((size_t)N * H * W * C);
+                RUN(cx, op_blend(x, yt, Lw.res_mix, yb, (size_t)N * H * W * C, cx.s));
+                x = yb;
+            } else {
+                x = yt;
+            }
+        }
+        if (st || tt) {
+            const int Lt = H * W, M = N * Lt;
+            half_t* n = cx.h((size_t)M * C);
+            TRY(run_groupnorm(cx, b.norm, x, n, N, Lt, 1e-6f, false));
+            half_t* tok = cx.h((size_t)M * INNER);
+            TRY(run_linear(cx, b.proj_in, n, C, tok, INNER, M, nullptr, 0));
+            half_t* smix = nullptr;
+            if (st) {
+                half_t* t2 = cx.h((size_t)M * INNER);
+                TRY(run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e));
+                tok = t2; smix = t2;
+            }
+            if (tt) {
+                half_t* t3 = cx.h((size_t)M * INNER);
+                RUN(cx, op_add_rowvec(tok, femb, INNER, t3, (size_t)M, INNER, Lt, a.F, cx.s));
+                half_t* t4 = cx.h((size_t)M * INNER);
+                TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt));
+                if (st) {
+                    RUN(cx, op_blend(smix, t4, Lw.tr_mix, t3, (size_t)M * INNER, cx.s));
+                    tok = t3;
+                } else {
+                    tok = t4;
+                }
+            }
+            // proj_out + residual (:286-289); the last layer writes the NCHW result directly
+            IGemmArgs g = {};
+            g.A = tok; g.lda = INNER; g.mode = IG_ROWS; g.Cin = INNER; g.taps = 1;
+            g.W = b.proj_out.w; g.M = M; g.Nout = C; g.Ktot = INNER; g.bias = b.proj_out.b;
+            g.res = x; g.ldres = C; g.scale = 1.f; g.nseg = 1;
+            if (last) {
+                g.seg[0] = IGemmSeg{out, Lt, 0, C, SEG_TRANSPOSED, a.out_dt, Lt, 0};
+                RUN(cx, op_igemm(g, cx.s));
+            } else {
+                half_t* y = cx.h((size_t)M * C);
+                g.seg[0] = IGemmSeg{y, C, 0, C, SEG_ROW, DT_F16, 1, 0};
+                RUN(cx, op_igemm(g, cx.s));
+                x = y;
+            }
+        } else if (last) {
+            RUN(cx, op_nhwc_to_nchw(x, out, a.out_dt, N, C, H * W, 1.f, cx.s));
+        }
+    }
+    cx.release(mk);
+    return 0;
+}
+
+}  // namespace
+
+struct ctrl_adapter {
+    AdapterW w;
+    std::unique_ptr<Packer> packer;
+    Arena arena;
+    ~ctrl_adapter() { if (packer) packer->release_all(); }
+};
+
+namespace {
+
+struct AdapterCall {
+    const void* const* ins; int in_dt; int N, H0, W0, F;
+    const float* t; int t_count;
+    const void* ehs; int ehs_dt; int ehs_batch; int Lk;
+    void* const* outs; int out_dt;
+};
+
+size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
+    TRY(begin_forward(cx));
+    const ctrl_adapter_config& c = w.cfg;
+    AFwd a;
+    a.N = k.N; a.F = k.F; a.B = k.N / k.F; a.t = k.t; a.t_count = k.t_count; a.in_dt = k.in_dt; a.out_dt = k.out_dt;
+    const int cross = c.cross_attention_dim;
+    // encoder hidden states: fp16 copy for the K/V projection GEMM, fp32 copy for the single-key path
+    a.e.batch = k.ehs_batch; a.e.Lk = k.Lk; a.e.cross = cross;
+    const size_t ne = (size_t)k.ehs_batch * k.Lk * cross;
+    if (c.add_spatial_transformer || c.add_temporal_transformer) {
+        half_t* e16 = cx.h(ne);
+        RUN(cx, op_nchw_to_nhwc(k.ehs, k.ehs_dt, e16, 1, 1, (int)ne, cx.s));
+        a.e.h16 = e16;
+        if (k.Lk == 1) {
+            float* e32 = cx.f(ne);
+            RUN(cx, op_nhwc_to_nchw(e16, e32, DT_F32, 1, 1, (int)ne, 1.f, cx.s));
+            a.e.f32 = e32;
+        }
+    }
+    if (c.add_temporal_transformer) {
+        // time_context = first frame of each clip (:246-249).  With broadcast encoder states (batch 1, what the
+        // pipelines pass) every clip shares it; per-sample states are supported for a single clip only, because the
+        // reference pairs (pixel, clip) rows in a different order for >1 clip (see DESIGN.md "known quirks").
+        CTRL_CHECK(k.Lk == 1, "adapter: the temporal transformer path requires single-token encoder_hidden_states");
+        CTRL_CHECK(k.ehs_batch == 1 || a.B == 1, "adapter: per-sample encoder_hidden_states with >1 clip is not supported");
+        a.e_first = a.e;
+        a.e_first.batch = 1;       // row 0 = first frame of the (only) clip, or the broadcast vector
+    }
+    // SD-1.5 pyramid below (H0, W0)
+    static const int slot_c[12] = {320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280};
+    static const int slot_f[12] = {1, 1, 1, 2, 2, 2, 4, 4, 4, 8, 8, 8};
+    const int up = c.backbone_sdxl ? 2 : 1;
+    size_t bi = 0;
+    for (int i = 0; i < 12; ++i) {
+        const int h = std::max(k.H0 / slot_f[i], 1), wd = std::max(k.W0 / slot_f[i], 1);
+        const bool has = bi < w.slot_ids.size() && w.slot_ids[bi] == i;
+        if (has) {
+            TRY(run_block(cx, w.blocks[bi], c, a, k.ins[i], k.outs[i], h, wd));
+            ++bi;
+        } else {
+            // torch.zeros_like(down_block_res_samples[i])  (ctrl_adapter.py:193): input-sized, not up-sampled
+            RUN(cx, op_fill_zero(k.outs[i], (size_t)k.N * slot_c[i] * h * wd * dt_size(k.out_dt), cx.s));
+        }
+    }
+    if (w.has_mid && k.ins[12] && k.outs[12]) {
+        const int h = std::max(k.H0 / 8, 1), wd = std::max(k.W0 / 8, 1);
+        TRY(run_block(cx, w.mid, c, a, k.ins[12], k.outs[12], h, wd));
+    }
+    (void)up;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctrl_adapter_param_count(const ctrl_adapter_config* cfg) {
+    if (!cfg) return -1;
+    SpecCollector sc; AdapterW w;
+    if (build_adapter(sc, *cfg, &w)) return -1;
+    return (int)sc.entries.size();
+}
+
+int ctrl_adapter_param_spec(const ctrl_adapter_config* cfg, int i, char* name, int name_len, int64_t shape[6], int* ndim) {
+    CTRL_CHECK(cfg && name && shape && ndim, "param_spec: null argument");
+    SpecCollector sc; AdapterW w;
+    TRY(build_adapter(sc, *cfg, &w));
+    CTRL_CHECK(i >= 0 && i < (int)sc.entries.size(), "param_spec: index out of range");
+    std::strncpy(name, sc.entries[i].name.c_str(), name_len - 1);
+    name[name_len - 1] = 0;
+    *ndim = (int)sc.entries[i].shape.size();
+    for (int k = 0; k < 6; ++k) shape[k] = k < *ndim ? sc.entries[i].shape[k] : 1;
+    return 0;
+}
+
+int ctrl_adapter_create(const ctrl_adapter_config* cfg, const ctrl_tensor_ref* tensors, int n_tensors, void* stream,
+                        ctrl_adapter** out) {
+    CTRL_CHECK(cfg && tensors && out, "adapter_create: null argument");
+    std::unique_ptr<ctrl_adapter> h(new ctrl_adapter());
+    h->packer.reset(new Packer(tensors, n_tensors, (hipStream_t)stream));
+    int rc = build_adapter(*h->packer, *cfg, &h->w);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *out = h.release();
+    return 0;
+}
+
+void ctrl_adapter_destroy(ctrl_adapter* h) { delete h; }
+
+int ctrl_adapter_forward(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                         const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
+                         int ehs_batch, int Lk, void* const* outs, int out_dtype, void* stream) {
+    CTRL_CHECK(h && ins && outs && timesteps, "adapter_forward: null argument");
+    CTRL_CHECK(N >= 1 && H0 >= 1 && W0 >= 1 && num_frames >= 1 && N % num_frames == 0,
+               "adapter_forward: batch must be a multiple of num_frames");
+    CTRL_CHECK(t_count == 1 || t_count == N, "adapter_forward: need 1 or N timesteps");
+    CTRL_CHECK(num_frames <= 32, "adapter_forward: at most 32 frames per clip");
+    const bool needs_ehs = h->w.cfg.add_spatial_transformer || h->w.cfg.add_temporal_transformer;
+    CTRL_CHECK(!needs_ehs || (encoder_hidden_states && Lk >= 1 && (ehs_batch == 1 || ehs_batch == N)),
+               "adapter_forward: encoder_hidden_states batch must be 1 or N");
+    for (int i = 0; i < 12; ++i) CTRL_CHECK(ins[i] && outs[i], "adapter_forward: null slot pointer");
+    AdapterCall k = {ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states, ehs_dtype,
+                     ehs_batch, Lk, outs, out_dtype};
+    hipStream_t s = (hipStream_t)stream;
+    h->arena.off = 0; h->arena.peak = 0;
+    Ctx dry{&h->arena, s, true};
+    TRY(adapter_run(dry, h->w, k));
+    TRY(h->arena.ensure(workspace_bytes(dry), s));
+    h->arena.off = 0;
+    Ctx cx{&h->arena, s, false};
+    cx.stats_total = dry.stats_total;
+    return adapter_run(cx, h->w, k);
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// Block builders (module tree -> parameter names, shared by the spec and the packer) and block runners
+// (sequence of HIP kernel launches) used by both orchestrators.  Names of leaf modules follow
+// diffusers v0.27.x (SURVEY.md section 8b "Weights / persistence").
+#include "plan_common.h"
+
+// ------------------------------------------------------------------------------------------ builders
+int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w) {
+    w->Cin = Cin; w->Cout = Cout;
+    TRY(ps.norm(pre + ".norm1", Cin, &w->norm1));
+    TRY(ps.conv(pre + ".conv1", Cout, Cin, 3, false, &w->conv1));
+    // time_emb_proj is registered by the caller (batched across blocks) to keep state-dict order irrelevant
+    TRY(ps.norm(pre + ".norm2", Cout, &w->norm2));
+    TRY(ps.conv(pre + ".conv2", Cout, Cout, 3, false, &w->conv2));
+    w->has_shortcut = force_shortcut || (Cin != Cout);
+    if (w->has_shortcut) TRY(ps.conv(pre + ".conv_shortcut", Cout, Cin, 1, false, &w->shortcut));
+    return 0;
+}
+
+int build_attn_self(ParamSink& ps, const std::string& pre, int dim, int heads, int D, AttnW* w) {
+    w->heads = heads; w->D = D; w->inner = heads * D;
+    TRY(ps.linear_cat({pre + ".to_q", pre + ".to_k", pre + ".to_v"}, {w->inner, w->inner, w->inner}, dim, false, &w->qkv));
+    TRY(ps.linear(pre + ".to_out.0", dim, w->inner, true, false, &w->out));
+    return 0;
+}
+
+int build_attn_cross(ParamSink& ps, const std::string& pre, int dim, int cross, int heads, int D, AttnW* w) {
+    w->heads = heads; w->D = D; w->inner = heads * D;
+    TRY(ps.linear(pre + ".to_q", w->inner, dim, false, false, &w->q));
+    TRY(ps.linear_cat({pre + ".to_k", pre + ".to_v"}, {w->inner, w->inner}, cross, false, &w->kv));
+    // the V rows of `kv` double as the stand-alone to_v operand of the single-key (Lk == 1) path
+    w->v.w = w->kv.w ? w->kv.w + (size_t)w->inner * cross : nullptr;
+    w->v.b = nullptr; w->v.N = w->inner; w->v.K = cross;
+    TRY(ps.linear(pre + ".to_out.0", dim, w->inner, true, false, &w->out));
+    return 0;
+}
+
+int build_basic_tb(ParamSink& ps, const std::string& pre, int dim, int heads, int D, int cross, BasicTBW* w) {
+    w->dim = dim; w->cross = cross;
+    TRY(ps.norm(pre + ".norm1", dim, &w->norm1));
+    TRY(build_attn_self(ps, pre + ".attn1", dim, heads, D, &w->attn1));
+    TRY(ps.norm(pre + ".norm2", dim, &w->norm2));
+    TRY(build_attn_cross(ps, pre + ".attn2", dim, cross, heads, D, &w->attn2));
+    TRY(ps.norm(pre + ".norm3", dim, &w->norm3));
+    TRY(ps.linear(pre + ".ff.net.0.proj", 8 * dim, dim, true, true, &w->ff1));
+    TRY(ps.linear(pre + ".ff.net.2", dim, 4 * dim, true, false, &w->ff2));
+    return 0;
+}
+
+int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads, int D, int cross, TemporalTBW* w) {
+    w->dim = dim; w->cross = cross;
+    TRY(ps.norm(pre + ".norm_in", dim, &w->norm_in));
+    TRY(ps.linear(pre + ".ff_in.net.0.proj", 8 * dim, dim, true, true, &w->ffin1));
+    TRY(ps.linear(pre + ".ff_in.net.2", dim, 4 * dim, true, false, &w->ffin2));
+    TRY(ps.norm(pre + ".norm1", dim, &w->norm1));
+    TRY(build_attn_self(ps, pre + ".attn1", dim, heads, D, &w->attn1));
+    TRY(ps.norm(pre + ".norm2", dim, &w->norm2));
+    TRY(build_attn_cross(ps, pre + ".attn2", dim, cross, heads, D, &w->attn2));
+    TRY(ps.norm(pre + ".norm3", dim, &w->norm3));
+    TRY(ps.linear(pre + ".ff.net.0.proj", 8 * dim, dim, true, true, &w->ff1));
+    TRY(ps.linear(pre + ".ff.net.2", dim, 4 * dim, true, false, &w->ff2));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ runners
+int run_groupnorm(Ctx& cx, const Norm& n, const half_t* x, half_t* y, int imgs, int rows, float eps, bool silu) {
+    float* st = cx.stats((size_t)imgs * 32 * 2);
+    RUN(cx, op_gn_stats(x, st, imgs, rows, n.C, 32, cx.s));
+    RUN(cx, op_gn_apply(x, st, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s));
+    return 0;
+}
+
+int run_conv(Ctx& cx, const ConvW& c, const half_t* x, half_t* y, int N, int Hin, int Win, const ConvOpts& o) {
+    const int k = c.taps == 9 ? 3 : 1, pad = c.taps == 9 ? 1 : 0;
+    const int Hout = (Hin * o.up + 2 * pad - k) / o.stride + 1, Wout = (Win * o.up + 2 * pad - k) / o.stride + 1;
+    IGemmArgs g = {};
+    g.A = x; g.lda = c.Cin; g.mode = IG_CONV2D; g.Cin = c.Cin; g.taps = c.taps;
+    g.Hin = Hin; g.Win = Win; g.Hout = Hout; g.Wout = Wout; g.stride = o.stride; g.up = o.up;
+    g.W = c.w; g.M = N * Hout * Wout; g.Nout = c.Cout; g.Ktot = c.taps * c.Cin;
+    g.bias = c.b; g.rowvec = o.rowvec; g.rowvec_ld = o.rowvec_ld; g.rows_per_img = Hout * Wout;
+    g.res = o.res; g.ldres = c.Cout; g.scale = 1.f; g.act = o.act;
+    g.nseg = 1;
+    g.seg[0] = IGemmSeg{y, c.Cout, 0, c.Cout, SEG_ROW, DT_F16, 1, 0};
+    RUN(cx, op_igemm(g, cx.s));
+    return 0;
+}
+
+int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, half_t* y, long ldy, int M, const half_t* res, long ldres) {
+    IGemmArgs g = {};
+    g.A = x; g.lda = ldx; g.mode = IG_ROWS; g.Cin = l.K; g.taps = 1;
+    g.W = l.w; g.M = M; g.Nout = l.N; g.Ktot = l.K;
+    g.bias = l.b; g.res = res; g.ldres = ldres; g.scale = 1.f; g.geglu = l.geglu ? 1 : 0;
+    const int on = l.geglu ? l.N / 2 : l.N;
+    g.nseg = 1;
+    g.seg[0] = IGemmSeg{y, ldy, 0, on, SEG_ROW, DT_F16, 1, 0};
+    RUN(cx, op_igemm(g, cx.s));
+    return 0;
+}
+
+int run_resnet(Ctx& cx, const ResnetW& w, const half_t* x, half_t* out, int N, int H, int W, int up,
+               const float* temb_proj, int temb_ld, float eps) {
+    const int Ho = H * up, Wo = W * up;
+    const size_t m = cx.mark();
+    half_t* a = cx.h((size_t)N * H * W * w.Cin);
+    TRY(run_groupnorm(cx, w.norm1, x, a, N, H * W, eps, true));
+    half_t* h1 = cx.h((size_t)N * Ho * Wo * w.Cout);
+    ConvOpts o1; o1.up = up; o1.rowvec = temb_proj; o1.rowvec_ld = temb_ld;
+    TRY(run_conv(cx, w.conv1, a, h1, N, H, W, o1));
+    half_t* b = cx.h((size_t)N * Ho * Wo * w.Cout);
+    TRY(run_groupnorm(cx, w.norm2, h1, b, N, Ho * Wo, eps, true));
+    const half_t* sc = x;
+    if (w.has_shortcut) {
+        half_t* s2 = cx.h((size_t)N * Ho * Wo * w.Cout);
+        ConvOpts os; os.up = up;
+        TRY(run_conv(cx, w.shortcut, x, s2, N, H, W, os));
+        sc = s2;
+    }
+    ConvOpts o2; o2.res = sc;
+    TRY(run_conv(cx, w.conv2, b, out, N, Ho, Wo, o2));
+    cx.release(m);
+    return 0;
+}
+
+static int run_attention(Ctx& cx, const half_t* Q, long ldq, const half_t* K, long ldk, const half_t* Vt, int Lkpad,
+                         half_t* O, long ldo, int B, int kvB, int heads, int D, int Lq, int Lk) {
+    AttnArgs a = {};
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.Vt = Vt; a.Lkpad = Lkpad; a.kvB = kvB;
+    a.O = O; a.ldo = ldo; a.B = B; a.heads = heads; a.D = D; a.Lq = Lq; a.Lk = Lk;
+    a.scale = 1.0f / sqrtf((float)D);
+    RUN(cx, op_flash_attn(a, cx.s));
+    return 0;
+}
+
+// self attention on LN'd tokens; returns attn_out_proj(attn) + bias + resid in `out`
+static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, const half_t* resid, half_t* out, int B, int L) {
+    const size_t mk = cx.mark();
+    const int M = B * L, Ci = w.inner;
+    const int Lpad = (L + 63) / 64 * 64;
+    half_t* qk = cx.h((size_t)M * 2 * Ci);
+    half_t* vt = cx.h((size_t)B * Ci * Lpad);
+    IGemmArgs g = {};
+    g.A = xn; g.lda = dim; g.mode = IG_ROWS; g.Cin = dim; g.taps = 1;
+    g.W = w.qkv.w; g.M = M; g.Nout = 3 * Ci; g.Ktot = dim; g.scale = 1.f;
+    g.nseg = 2;
+    g.seg[0] = IGemmSeg{qk, 2 * Ci, 0, 2 * Ci, SEG_ROW, DT_F16, 1, 0};
+    g.seg[1] = IGemmSeg{vt, Lpad, 2 * Ci, Ci, SEG_TRANSPOSED, DT_F16, L, 0};
+    RUN(cx, op_igemm(g, cx.s));
+    half_t* o = cx.h((size_t)M * Ci);
+    TRY(run_attention(cx, qk, 2 * Ci, qk + Ci, 2 * Ci, vt, Lpad, o, Ci, B, B, w.heads, w.D, L, L));
+    TRY(run_linear(cx, w.out, o, Ci, out, dim, M, resid, dim));
+    cx.release(mk);
+    return 0;
+}
+
+// cross attention; Lk == 1 is the degenerate query-independent case (SURVEY.md note N5)
+static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const half_t* x, int dim, half_t* out, int B, int L,
+                          const EhsCtx& e) {
+    const size_t mk = cx.mark();
+    const int M = B * L, Ci = w.inner;
+    if (e.Lk == 1) {
+        // softmax over one key == 1  =>  out = to_out(to_v(ctx)) for every query of the image
+        float* v = cx.f((size_t)e.batch * Ci);
+        RUN(cx, op_linear_small(e.f32, e.cross, w.v.w, nullptr, v, Ci, e.batch, Ci, e.cross, 0, 0, cx.s));
+        float* o = cx.f((size_t)e.batch * dim);
+        RUN(cx, op_linear_small(v, Ci, w.out.w, w.out.b, o, dim, e.batch, dim, Ci, 0, 0, cx.s));
+        RUN(cx, op_add_rowvec(x, o, dim, out, (size_t)M, dim, L, e.batch, cx.s));
+        cx.release(mk);
+        return 0;
+    }
+    half_t* xn = cx.h((size_t)M * dim);
+    RUN(cx, op_layernorm(x, dim, ln.g, ln.b, xn, dim, M, dim, 1e-5f, cx.s));
+    half_t* q = cx.h((size_t)M * Ci);
+    TRY(run_linear(cx, w.q, xn, dim, q, Ci, M, nullptr, 0));
+    const int Lkpad = (e.Lk + 63) / 64 * 64;
+    const int Mk = e.batch * e.Lk;
+    half_t* k = cx.h((size_t)Mk * Ci);
+    half_t* vt = cx.h((size_t)e.batch * Ci * Lkpad);
+    IGemmArgs g = {};
+    g.A = e.h16; g.lda = e.cross; g.mode = IG_ROWS; g.Cin = e.cross; g.taps = 1;
+    g.W = w.kv.w; g.M = Mk; g.Nout = 2 * Ci; g.Ktot = e.cross; g.scale = 1.f;
+    g.nseg = 2;
+    g.seg[0] = IGemmSeg{k, Ci, 0, Ci, SEG_ROW, DT_F16, 1, 0};
+    g.seg[1] = IGemmSeg{vt, Lkpad, Ci, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
+    RUN(cx, op_igemm(g, cx.s));
+    half_t* o = cx.h((size_t)M * Ci);
+    TRY(run_attention(cx, q, Ci, k, Ci, vt, Lkpad, o, Ci, B, e.batch == 1 ? 1 : B, w.heads, w.D, L, e.Lk));
+    TRY(run_linear(cx, w.out, o, Ci, out, dim, M, x, dim));
+    cx.release(mk);
+    return 0;
+}
+
+static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const half_t* x, int dim, half_t* out, int M,
+                  bool residual) {
+    const size_t mk = cx.mark();
+    half_t* xn = cx.h((size_t)M * dim);
+    RUN(cx, op_layernorm(x, dim, ln.g, ln.b, xn, dim, M, dim, 1e-5f, cx.s));
+    const int inner = ff1.N / 2;
+    half_t* hmid = cx.h((size_t)M * inner);
+    TRY(run_linear(cx, ff1, xn, dim, hmid, inner, M, nullptr, 0));
+    TRY(run_linear(cx, ff2, hmid, inner, out, ff2.N, M, residual ? x : nullptr, dim));
+    cx.release(mk);
+    return 0;
+}
+
+int run_basic_tb(Ctx& cx, const BasicTBW& w, const half_t* X, half_t* out, int B, int L, const EhsCtx& e) {
+    CTRL_CHECK(e.batch == 1 || e.batch == B, "encoder_hidden_states batch must be 1 or equal to the sample batch");
+    const size_t mk = cx.mark();
+    const int M = B * L, dim = w.dim;
+    half_t* xn = cx.h((size_t)M * dim);
+    RUN(cx, op_layernorm(X, dim, w.norm1.g, w.norm1.b, xn, dim, M, dim, 1e-5f, cx.s));
+    half_t* x1 = cx.h((size_t)M * dim);
+    TRY(run_self_attn(cx, w.attn1, xn, dim, X, x1, B, L));
+    half_t* x2 = xn;     // xn is dead after the QKV projection: reuse it
+    TRY(run_cross_attn(cx, w.attn2, w.norm2, x1, dim, x2, B, L, e));
+    TRY(run_ff(cx, w.norm3, w.ff1, w.ff2, x2, dim, out, M, true));
+    cx.release(mk);
+    return 0;
+}

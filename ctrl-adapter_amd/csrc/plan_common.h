@@ -1,0 +1,281 @@
+// Host-side plan infrastructure shared by the ControlNet and Ctrl-Adapter orchestrators (C++, no torch):
+//   * ParamSink: one description of the module tree drives both the parameter inventory
+//     (ctrl_*_param_spec: names/shapes = the reference's state-dict keys) and the weight packer
+//   * Arena: stack-discipline device workspace owned by the plan (sized by a dry pass, so the steady-state
+//     forward performs no hipMalloc and is graph-capturable)
+//   * block runners (GroupNorm+SiLU, ResnetBlock2D, BasicTransformerBlock, ...) that enqueue the HIP kernels
+#pragma once
+#include "ops.h"
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------ packed params
+struct Lin { half_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; bool geglu = false; };
+struct ConvW { half_t* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, taps = 0; };
+struct ConvD { float* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0; };
+struct Norm { float* g = nullptr; float* b = nullptr; int C = 0; };
+
+struct SpecEntry { std::string name; std::vector<int64_t> shape; };
+
+struct ParamSink {
+    virtual ~ParamSink() {}
+    // nn.Linear(K, N): <name>.weight [N][K] (+ <name>.bias [N])
+    virtual int linear(const std::string& name, int N, int K, bool bias, bool geglu, Lin* out) = 0;
+    // several bias-free / biased linears with the same K concatenated along N (QKV, batched time projections)
+    virtual int linear_cat(const std::vector<std::string>& names, const std::vector<int>& Ns, int K, bool bias, Lin* out) = 0;
+    // nn.Conv2d(Cin, Cout, k) for the implicit GEMM: k = 1 | 3 ; nn.Conv3d (3,1,1) when temporal
+    virtual int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW* out) = 0;
+    // nn.Conv2d(Cin, Cout, 3) for the direct small-channel kernel
+    virtual int conv_direct(const std::string& name, int Cout, int Cin, ConvD* out) = 0;
+    virtual int norm(const std::string& name, int C, Norm* out) = 0;
+    virtual int scalar(const std::string& name, float** out) = 0;
+    // raw fp32 copy of a small tensor (router weights ...)
+    virtual int raw_f32(const std::string& name, const std::vector<int64_t>& shape, float** out) = 0;
+};
+
+struct SpecCollector : ParamSink {
+    std::vector<SpecEntry> entries;
+    int linear(const std::string& name, int N, int K, bool bias, bool, Lin*) override {
+        entries.push_back({name + ".weight", {N, K}});
+        if (bias) entries.push_back({name + ".bias", {N}});
+        return 0;
+    }
+    int linear_cat(const std::vector<std::string>& names, const std::vector<int>& Ns, int K, bool bias, Lin*) override {
+        for (size_t i = 0; i < names.size(); ++i) linear(names[i], Ns[i], K, bias, false, nullptr);
+        return 0;
+    }
+    int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW*) override {
+        if (temporal) entries.push_back({name + ".weight", {Cout, Cin, 3, 1, 1}});
+        else entries.push_back({name + ".weight", {Cout, Cin, k, k}});
+        entries.push_back({name + ".bias", {Cout}});
+        return 0;
+    }
+    int conv_direct(const std::string& name, int Cout, int Cin, ConvD*) override {
+        entries.push_back({name + ".weight", {Cout, Cin, 3, 3}});
+        entries.push_back({name + ".bias", {Cout}});
+        return 0;
+    }
+    int norm(const std::string& name, int C, Norm*) override {
+        entries.push_back({name + ".weight", {C}});
+        entries.push_back({name + ".bias", {C}});
+        return 0;
+    }
+    int scalar(const std::string& name, float**) override { entries.push_back({name, {1}}); return 0; }
+    int raw_f32(const std::string& name, const std::vector<int64_t>& shape, float**) override {
+        entries.push_back({name, shape});
+        return 0;
+    }
+};
+
+// Packs reference-layout tensors into plan-owned device memory (fp16 GEMM operands, fp32 vectors).
+struct Packer : ParamSink {
+    std::unordered_map<std::string, const ctrl_tensor_ref*> map;
+    std::vector<void*> allocs;
+    size_t bytes = 0;
+    hipStream_t s;
+    Packer(const ctrl_tensor_ref* t, int n, hipStream_t stream) : s(stream) {
+        for (int i = 0; i < n; ++i) map[t[i].name] = &t[i];
+    }
+    void release_all() { for (void* p : allocs) hipFree(p); allocs.clear(); }
+    int dalloc(size_t nbytes, void** out) {
+        HIP_TRY(hipMalloc(out, nbytes ? nbytes : 16));
+        allocs.push_back(*out);
+        bytes += nbytes;
+        return 0;
+    }
+    int get(const std::string& name, const std::vector<int64_t>& shape, const ctrl_tensor_ref** out) {
+        auto it = map.find(name);
+        CTRL_CHECK(it != map.end(), "missing parameter '" + name + "'");
+        const ctrl_tensor_ref* t = it->second;
+        int64_t want = 1, have = 1;
+        for (auto v : shape) want *= v;
+        for (int i = 0; i < t->ndim; ++i) have *= t->shape[i];
+        bool same = ((int)shape.size() == t->ndim);
+        for (int i = 0; same && i < t->ndim; ++i) same = (shape[i] == t->shape[i]);
+        CTRL_CHECK(same && want == have, "parameter '" + name + "' has the wrong shape");
+        CTRL_CHECK(t->data != nullptr, "parameter '" + name + "' has no data");
+        *out = t;
+        return 0;
+    }
+    int vec(const std::string& name, int N, bool geglu, float* dst) {
+        const ctrl_tensor_ref* t;
+        TRY(get(name, {N}, &t));
+        return op_pack_vec(t->data, t->dtype, dst, N, geglu ? 1 : 0, s);
+    }
+    int linear(const std::string& name, int N, int K, bool bias, bool geglu, Lin* out) override {
+        const ctrl_tensor_ref* t;
+        TRY(get(name + ".weight", {N, K}, &t));
+        TRY(dalloc((size_t)N * K * sizeof(half_t), (void**)&out->w));
+        TRY(op_pack_linear_w(t->data, t->dtype, out->w, N, K, geglu ? 1 : 0, s));
+        out->b = nullptr;
+        if (bias) {
+            TRY(dalloc((size_t)N * sizeof(float), (void**)&out->b));
+            TRY(vec(name + ".bias", N, geglu, out->b));
+        }
+        out->N = N; out->K = K; out->geglu = geglu;
+        return 0;
+    }
+    int linear_cat(const std::vector<std::string>& names, const std::vector<int>& Ns, int K, bool bias, Lin* out) override {
+        int Ntot = 0;
+        for (int n : Ns) Ntot += n;
+        TRY(dalloc((size_t)Ntot * K * sizeof(half_t), (void**)&out->w));
+        out->b = nullptr;
+        if (bias) TRY(dalloc((size_t)Ntot * sizeof(float), (void**)&out->b));
+        int off = 0;
+        for (size_t i = 0; i < names.size(); ++i) {
+            const ctrl_tensor_ref* t;
+            TRY(get(names[i] + ".weight", {Ns[i], K}, &t));
+            TRY(op_pack_linear_w(t->data, t->dtype, out->w + (size_t)off * K, Ns[i], K, 0, s));
+            if (bias) TRY(vec(names[i] + ".bias", Ns[i], false, out->b + off));
+            off += Ns[i];
+        }
+        out->N = Ntot; out->K = K; out->geglu = false;
+        return 0;
+    }
+    int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW* out) override {
+        const ctrl_tensor_ref* t;
+        const int taps = temporal ? 3 : k * k;
+        if (temporal) TRY(get(name + ".weight", {Cout, Cin, 3, 1, 1}, &t));
+        else TRY(get(name + ".weight", {Cout, Cin, k, k}, &t));
+        TRY(dalloc((size_t)Cout * Cin * taps * sizeof(half_t), (void**)&out->w));
+        TRY(op_pack_conv_w(t->data, t->dtype, out->w, Cout, Cin, taps, s));
+        TRY(dalloc((size_t)Cout * sizeof(float), (void**)&out->b));
+        TRY(vec(name + ".bias", Cout, false, out->b));
+        out->Cout = Cout; out->Cin = Cin; out->taps = taps;
+        return 0;
+    }
+    int conv_direct(const std::string& name, int Cout, int Cin, ConvD* out) override {
+        const ctrl_tensor_ref* t;
+        TRY(get(name + ".weight", {Cout, Cin, 3, 3}, &t));
+        TRY(dalloc((size_t)9 * Cin * Cout * sizeof(float), (void**)&out->w));
+        TRY(op_pack_conv_w_direct(t->data, t->dtype, out->w, Cout, Cin, s));
+        TRY(dalloc((size_t)Cout * sizeof(float), (void**)&out->b));
+        TRY(vec(name + ".bias", Cout, false, out->b));
+        out->Cout = Cout; out->Cin = Cin;
+        return 0;
+    }
+    int norm(const std::string& name, int C, Norm* out) override {
+        TRY(dalloc((size_t)C * sizeof(float), (void**)&out->g));
+        TRY(dalloc((size_t)C * sizeof(float), (void**)&out->b));
+        TRY(vec(name + ".weight", C, false, out->g));
+        TRY(vec(name + ".bias", C, false, out->b));
+        out->C = C;
+        return 0;
+    }
+    int scalar(const std::string& name, float** out) override {
+        TRY(dalloc(sizeof(float), (void**)out));
+        return vec(name, 1, false, *out);
+    }
+    int raw_f32(const std::string& name, const std::vector<int64_t>& shape, float** out) override {
+        const ctrl_tensor_ref* t;
+        TRY(get(name, shape, &t));
+        int64_t n = 1;
+        for (auto v : shape) n *= v;
+        TRY(dalloc((size_t)n * sizeof(float), (void**)out));
+        return op_pack_vec(t->data, t->dtype, *out, (int)n, 0, s);
+    }
+};
+
+// ------------------------------------------------------------------------------------------ workspace
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    ~Arena() { if (base) hipFree(base); }
+    int ensure(size_t need, hipStream_t s) {
+        if (need <= cap) return 0;
+        HIP_TRY(hipStreamSynchronize(s));     // the old buffer may still be in use by queued work
+        if (base) HIP_TRY(hipFree(base));
+        base = nullptr; cap = 0;
+        HIP_TRY(hipMalloc((void**)&base, need));
+        cap = need;
+        return 0;
+    }
+};
+
+// Execution context: `dry` = sizing pass (allocations only advance the offset, nothing is launched).
+struct Ctx {
+    Arena* ar;
+    hipStream_t s;
+    bool dry;
+    // pooled GroupNorm statistics (zeroed once per forward with a single memset)
+    float* stats_base = nullptr;
+    size_t stats_off = 0, stats_total = 0;
+
+    void* alloc(size_t bytes) {
+        const size_t a = (ar->off + 255) & ~(size_t)255;
+        ar->off = a + bytes;
+        if (ar->off > ar->peak) ar->peak = ar->off;
+        return dry ? (void*)(uintptr_t)(0x1000 + a) : (void*)(ar->base + a);   // dry: fake, never dereferenced
+    }
+    half_t* h(size_t n) { return (half_t*)alloc(n * sizeof(half_t)); }
+    float* f(size_t n) { return (float*)alloc(n * sizeof(float)); }
+    size_t mark() const { return ar->off; }
+    void release(size_t m) { ar->off = m; }
+    float* stats(size_t n) {
+        float* p = dry ? nullptr : stats_base + stats_off;
+        stats_off += n;
+        if (dry) stats_total = stats_off;
+        return p;
+    }
+};
+#define RUN(cx, expr) do { if (!(cx).dry) TRY(expr); } while (0)
+// first call of every forward body: carve (real pass) the pooled GroupNorm statistics and zero them once
+inline int begin_forward(Ctx& cx) {
+    if (!cx.dry) {
+        cx.stats_base = (float*)cx.alloc(cx.stats_total * sizeof(float));
+        if (cx.stats_total) TRY(op_fill_zero(cx.stats_base, cx.stats_total * sizeof(float), cx.s));
+    }
+    return 0;
+}
+// workspace needed by the real pass, given the finished dry pass
+inline size_t workspace_bytes(const Ctx& dry) { return dry.ar->peak + ((dry.stats_total * sizeof(float) + 255) & ~(size_t)255) + 1024; }
+
+// ------------------------------------------------------------------------------------------ block params
+struct ResnetW {            // diffusers ResnetBlock2D / the adapter's copy
+    Norm norm1, norm2;
+    ConvW conv1, conv2, shortcut;
+    bool has_shortcut = false;
+    int Cin = 0, Cout = 0;
+    int temb_off = 0;       // column offset of this block's time projection inside the batched projection
+};
+struct AttnW { Lin qkv, q, kv, v, out; int heads = 0, D = 0, inner = 0; };   // qkv (self) or q + kv (cross); v for Lk==1
+struct BasicTBW {           // BasicTransformerBlock
+    Norm norm1, norm2, norm3;
+    AttnW attn1, attn2;
+    Lin ff1, ff2;           // GEGLU proj (interleaved), out
+    int dim = 0, cross = 0;
+};
+struct TemporalTBW {        // TemporalBasicTransformerBlock
+    Norm norm_in, norm1, norm2, norm3;
+    Lin ffin1, ffin2, ff1, ff2;
+    AttnW attn1, attn2;
+    int dim = 0, cross = 0;
+};
+
+int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w);
+int build_attn_self(ParamSink& ps, const std::string& pre, int dim, int heads, int D, AttnW* w);
+int build_attn_cross(ParamSink& ps, const std::string& pre, int dim, int cross, int heads, int D, AttnW* w);
+int build_basic_tb(ParamSink& ps, const std::string& pre, int dim, int heads, int D, int cross, BasicTBW* w);
+int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads, int D, int cross, TemporalTBW* w);
+
+// ------------------------------------------------------------------------------------------ block runners
+// y = GroupNorm(x) (optional SiLU);  x,y [imgs*rows][C] fp16
+int run_groupnorm(Ctx& cx, const Norm& n, const half_t* x, half_t* y, int imgs, int rows, float eps, bool silu);
+// 3x3 / 1x1 conv through the implicit GEMM, NHWC -> NHWC (out fp16 row-major)
+struct ConvOpts {
+    int stride = 1, up = 1;
+    const float* rowvec = nullptr; int rowvec_ld = 0;
+    const half_t* res = nullptr;
+    int act = 0;
+};
+int run_conv(Ctx& cx, const ConvW& c, const half_t* x, half_t* y, int N, int Hin, int Win, const ConvOpts& o);
+int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, half_t* y, long ldy, int M, const half_t* res, long ldres);
+// out = ResnetBlock2D(x, temb); temb_proj = rowvec [N][ld] (already time_emb_proj(SiLU(emb)) incl. bias)
+int run_resnet(Ctx& cx, const ResnetW& w, const half_t* x, half_t* out, int N, int H, int W, int up,
+               const float* temb_proj, int temb_ld, float eps);
+// Encoder-hidden-state context prepared once per forward: fp16 copy [B*Lk][cross] (+ fp32 copy when Lk == 1)
+struct EhsCtx { const half_t* h16 = nullptr; const float* f32 = nullptr; int batch = 1, Lk = 0, cross = 0; };
+// X [B*L][dim] (in place semantic: returns new buffer `out`)
+int run_basic_tb(Ctx& cx, const BasicTBW& w, const half_t* X, half_t* out, int B, int L, const EhsCtx& e);

@@ -1,0 +1,354 @@
+// ControlNet forward orchestrator (C++ host code, enqueues the gfx950 kernels of libctrlhip).
+//
+// Restates the control flow of the reference's ControlNetModel (controlnet/controlnet.py): constructor
+// :179-438 fixes the module tree / parameter names, forward :662-881 fixes the order of operations:
+//   time embedding :735-758 -> conv_in / skip flags :802-811 -> + conditioning embedding :816-817 ->
+//   down blocks :820-833 -> mid block :836-846 -> 13 zero-convs :850-858 -> scaling :861-868.
+// Only the configuration the hot path reaches is supported (no class/addition embeddings, rgb order,
+// no attention mask, global_pool_conditions=False); anything else fails loudly at create().
+#include "plan_common.h"
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace {
+
+struct DownBlockW {
+    std::vector<ResnetW> resnets;
+    std::vector<Norm> tnorm;            // Transformer2DModel.norm
+    std::vector<ConvW> proj_in, proj_out;
+    std::vector<BasicTBW> tb;
+    bool has_attn = false, has_down = false;
+    ConvW down;
+    int Cin = 0, Cout = 0;
+};
+
+struct ControlNetW {
+    ctrl_controlnet_config cfg;
+    ConvD conv_in;
+    Lin te1, te2;                       // time_embedding.linear_1/2
+    Lin temb_cat;                       // every resnet's time_emb_proj, concatenated along N
+    // conditioning embedder
+    ConvD ce_direct[4]; int n_direct = 0;
+    ConvW ce_gemm[5]; int n_gemm = 0;   // remaining layers incl. conv_out (last)
+    std::vector<int> ce_chain_c, ce_chain_stride;   // per layer: Cout, stride
+    DownBlockW down[4];
+    ResnetW mid_r0, mid_r1;
+    Norm mid_tnorm; ConvW mid_pin, mid_pout; BasicTBW mid_tb;
+    std::vector<ConvW> zero_convs;      // 12 down + 1 mid
+    int temb_total = 0;
+};
+
+int build_transformer2d(ParamSink& ps, const std::string& pre, int C, int heads, int cross, Norm* n, ConvW* pin,
+                        ConvW* pout, BasicTBW* tb) {
+    TRY(ps.norm(pre + ".norm", C, n));
+    TRY(ps.conv(pre + ".proj_in", C, C, 1, false, pin));
+    TRY(build_basic_tb(ps, pre + ".transformer_blocks.0", C, heads, C / heads, cross, tb));
+    TRY(ps.conv(pre + ".proj_out", C, C, 1, false, pout));
+    return 0;
+}
+
+int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW* w) {
+    w->cfg = c;
+    const int c0 = c.block_out_channels[0], temb_dim = 4 * c0;
+    CTRL_CHECK(c.in_channels == 4 || c.in_channels == 3, "controlnet: in_channels must be 3 or 4 (direct stem kernel)");
+    CTRL_CHECK(c.conditioning_channels == 3 || c.conditioning_channels == 4, "controlnet: conditioning_channels must be 3 or 4");
+    CTRL_CHECK(c.layers_per_block >= 1 && c.layers_per_block <= 4, "controlnet: layers_per_block out of range");
+    for (int i = 0; i < 4; ++i) {
+        CTRL_CHECK(c.block_out_channels[i] % 64 == 0, "controlnet: block_out_channels must be multiples of 64");
+        const int d = c.block_out_channels[i] / c.num_attention_heads;
+        CTRL_CHECK(!c.down_block_has_attn[i] || d == 40 || d == 64 || d == 80 || d == 160,
+                   "controlnet: head_dim must be one of 40/64/80/160");
+    }
+    TRY(ps.conv_direct("conv_in", c0, c.in_channels, &w->conv_in));
+    TRY(ps.linear("time_embedding.linear_1", temb_dim, c0, true, false, &w->te1));
+    TRY(ps.linear("time_embedding.linear_2", temb_dim, temb_dim, true, false, &w->te2));
+
+    // conditioning embedder (controlnet/controlnet.py:62-104): conv_in, (same, stride-2) x3, conv_out
+    {
+        const int* cc = c.cond_embed_channels;
+        std::vector<std::string> names = {"controlnet_cond_embedding.conv_in"};
+        std::vector<int> cin = {c.conditioning_channels}, cout = {cc[0]}, stride = {1};
+        for (int i = 0; i < 3; ++i) {
+            names.push_back("controlnet_cond_embedding.blocks." + std::to_string(2 * i));
+            cin.push_back(cc[i]); cout.push_back(cc[i]); stride.push_back(1);
+            names.push_back("controlnet_cond_embedding.blocks." + std::to_string(2 * i + 1));
+            cin.push_back(cc[i]); cout.push_back(cc[i + 1]); stride.push_back(2);
+        }
+        names.push_back("controlnet_cond_embedding.conv_out");
+        cin.push_back(cc[3]); cout.push_back(c0); stride.push_back(1);
+        bool gemm_phase = false;
+        for (size_t i = 0; i < names.size(); ++i) {
+            const bool can_gemm = (cin[i] % 32 == 0) && (cout[i] >= 64);
+            if (can_gemm) gemm_phase = true;
+            if (!gemm_phase) {
+                CTRL_CHECK(w->n_direct < 4, "controlnet: too many small conditioning-embedder layers");
+                CTRL_CHECK(i == 0 || cin[i] == 16 || cin[i] == 32, "controlnet: unsupported conditioning embedder width");
+                TRY(ps.conv_direct(names[i], cout[i], cin[i], &w->ce_direct[w->n_direct++]));
+            } else {
+                CTRL_CHECK(can_gemm && w->n_gemm < 5, "controlnet: unsupported conditioning embedder layout");
+                TRY(ps.conv(names[i], cout[i], cin[i], 3, false, &w->ce_gemm[w->n_gemm++]));
+            }
+            w->ce_chain_c.push_back(cout[i]);
+            w->ce_chain_stride.push_back(stride[i]);
+        }
+    }
+
+    std::vector<std::string> temb_names;
+    std::vector<int> temb_ns;
+    auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r) -> int {
+        TRY(build_resnet(ps, pre, Cin, Cout, false, r));
+        r->temb_off = w->temb_total;
+        w->temb_total += Cout;
+        temb_names.push_back(pre + ".time_emb_proj");
+        temb_ns.push_back(Cout);
+        return 0;
+    };
+
+    int out_c = c0;
+    for (int i = 0; i < 4; ++i) {
+        DownBlockW& d = w->down[i];
+        d.Cin = out_c; d.Cout = c.block_out_channels[i]; out_c = d.Cout;
+        d.has_attn = c.down_block_has_attn[i] != 0;
+        d.has_down = (i != 3);
+        const std::string pre = "down_blocks." + std::to_string(i);
+        d.resnets.resize(c.layers_per_block);
+        if (d.has_attn) { d.tnorm.resize(c.layers_per_block); d.proj_in.resize(c.layers_per_block);
+                          d.proj_out.resize(c.layers_per_block); d.tb.resize(c.layers_per_block); }
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            TRY(add_resnet(pre + ".resnets." + std::to_string(j), j == 0 ? d.Cin : d.Cout, d.Cout, &d.resnets[j]));
+            if (d.has_attn)
+                TRY(build_transformer2d(ps, pre + ".attentions." + std::to_string(j), d.Cout, c.num_attention_heads,
+                                        c.cross_attention_dim, &d.tnorm[j], &d.proj_in[j], &d.proj_out[j], &d.tb[j]));
+        }
+        if (d.has_down) TRY(ps.conv(pre + ".downsamplers.0.conv", d.Cout, d.Cout, 3, false, &d.down));
+    }
+    TRY(add_resnet("mid_block.resnets.0", out_c, out_c, &w->mid_r0));
+    TRY(build_transformer2d(ps, "mid_block.attentions.0", out_c, c.num_attention_heads, c.cross_attention_dim,
+                            &w->mid_tnorm, &w->mid_pin, &w->mid_pout, &w->mid_tb));
+    TRY(add_resnet("mid_block.resnets.1", out_c, out_c, &w->mid_r1));
+    TRY(ps.linear_cat(temb_names, temb_ns, temb_dim, true, &w->temb_cat));
+
+    // zero convs: slot channels follow the residual list (controlnet/controlnet.py:360-408)
+    std::vector<int> slot_c = {c0};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < c.layers_per_block + (i != 3 ? 1 : 0); ++j) slot_c.push_back(c.block_out_channels[i]);
+    w->zero_convs.resize(slot_c.size() + 1);
+    for (size_t i = 0; i < slot_c.size(); ++i)
+        TRY(ps.conv("controlnet_down_blocks." + std::to_string(i), slot_c[i], slot_c[i], 1, false, &w->zero_convs[i]));
+    TRY(ps.conv("controlnet_mid_block", out_c, out_c, 1, false, &w->zero_convs[slot_c.size()]));
+    return 0;
+}
+
+}  // namespace
+
+struct ctrl_controlnet {
+    ControlNetW w;
+    std::unique_ptr<Packer> packer;
+    Arena arena;
+    ~ctrl_controlnet() { if (packer) packer->release_all(); }
+};
+
+namespace {
+
+struct FwdArgs {
+    const void* sample; int sample_dt; int N, Hs, Ws;
+    const float* t; int t_count;
+    const void* ehs; int ehs_dt; int Lk;
+    const void* cond; int cond_dt;
+    float scale; int flags;
+    void* const* outs; int out_dt;
+};
+
+int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& pout, const BasicTBW& tb, const half_t* x,
+                      half_t* out, int N, int H, int W, const EhsCtx& e) {
+    const size_t mk = cx.mark();
+    const int C = tn.C, M = N * H * W;
+    half_t* n = cx.h((size_t)M * C);
+    TRY(run_groupnorm(cx, tn, x, n, N, H * W, 1e-6f, false));
+    half_t* t0 = cx.h((size_t)M * C);
+    ConvOpts o;
+    TRY(run_conv(cx, pin, n, t0, N, H, W, o));
+    half_t* t1 = n;      // n is dead after proj_in
+    TRY(run_basic_tb(cx, tb, t0, t1, N, H * W, e));
+    ConvOpts oo; oo.res = x;
+    TRY(run_conv(cx, pout, t1, out, N, H, W, oo));
+    cx.release(mk);
+    return 0;
+}
+
+int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
+    const ctrl_controlnet_config& c = w.cfg;
+    const int N = a.N, c0 = c.block_out_channels[0], temb_dim = 4 * c0;
+    TRY(begin_forward(cx));
+    // ---- 1. time embedding (:735-758) and every resnet's projection of it, one batched small-M linear ----
+    float* tsin = cx.f((size_t)N * c0);
+    RUN(cx, op_timestep_sincos(a.t, a.t_count, tsin, N, c0, cx.s));
+    float* t1 = cx.f((size_t)N * temb_dim);
+    RUN(cx, op_linear_small(tsin, c0, w.te1.w, w.te1.b, t1, temb_dim, N, temb_dim, c0, 0, 1, cx.s));
+    float* emb = cx.f((size_t)N * temb_dim);
+    if (a.flags & CTRL_SKIP_TIME_EMB) RUN(cx, op_fill_zero(emb, (size_t)N * temb_dim * sizeof(float), cx.s));   // :809-811
+    else RUN(cx, op_linear_small(t1, temb_dim, w.te2.w, w.te2.b, emb, temb_dim, N, temb_dim, temb_dim, 0, 0, cx.s));
+    float* tproj = cx.f((size_t)N * w.temb_total);
+    RUN(cx, op_linear_small(emb, temb_dim, w.temb_cat.w, w.temb_cat.b, tproj, w.temb_total, N, w.temb_total, temb_dim, 1, 0, cx.s));
+
+    // ---- encoder hidden states -> fp16 [N*Lk][cross] ----
+    EhsCtx e;
+    e.batch = N; e.Lk = a.Lk; e.cross = c.cross_attention_dim;
+    {
+        half_t* e16 = cx.h((size_t)N * a.Lk * e.cross);
+        RUN(cx, op_nchw_to_nhwc(a.ehs, a.ehs_dt, e16, 1, 1, N * a.Lk * e.cross, cx.s));
+        e.h16 = e16;
+    }
+
+    // ---- 2. stem: conv_in(sample) (:802-807) ----
+    const int H = a.Hs, W = a.Ws;
+    half_t* x = cx.h((size_t)N * H * W * c0);          // block input (also residual slot 0)
+    half_t* stem = nullptr;
+    if (!(a.flags & CTRL_SKIP_CONV_IN)) {
+        stem = cx.h((size_t)N * H * W * c0);
+        RUN(cx, op_conv3x3_direct(a.sample, a.sample_dt, 1, w.conv_in.w, w.conv_in.b, stem, N, c.in_channels, c0, H, W, 1, 0, cx.s));
+    }
+    // ---- conditioning embedding (:94-104) + add (:816-817) ----
+    {
+        const size_t mk = cx.mark();
+        int ch = c.conditioning_channels, hh = 8 * H, ww = 8 * W;
+        const void* cur = a.cond; int cur_dt = a.cond_dt; int nchw = 1;
+        const size_t nl = w.ce_chain_c.size();
+        int gi = 0;
+        for (size_t i = 0; i < nl; ++i) {
+            const int co = w.ce_chain_c[i], st = w.ce_chain_stride[i];
+            const int ho = (hh - 1) / st + 1, wo = (ww - 1) / st + 1;
+            const bool last = (i + 1 == nl);
+            half_t* y = last ? x : cx.h((size_t)N * ho * wo * co);
+            if ((int)i < w.n_direct) {
+                RUN(cx, op_conv3x3_direct(cur, cur_dt, nchw, w.ce_direct[i].w, w.ce_direct[i].b, y, N, ch, co, hh, ww, st, 1, cx.s));
+            } else {
+                ConvOpts o; o.stride = st; o.act = last ? 0 : 1; o.res = last ? stem : nullptr;
+                TRY(run_conv(cx, w.ce_gemm[gi++], (const half_t*)cur, y, N, hh, ww, o));
+            }
+            cur = y; cur_dt = DT_F16; nchw = 0; ch = co; hh = ho; ww = wo;
+        }
+        CTRL_CHECK(hh == H && ww == W, "controlnet_cond must be 8x the latent resolution");
+        cx.release(mk);
+    }
+
+    // ---- 3. down blocks (:820-833) ----
+    std::vector<const half_t*> res; std::vector<int> res_c, res_h, res_w;
+    res.push_back(x); res_c.push_back(c0); res_h.push_back(H); res_w.push_back(W);
+    int h = H, wd = W;
+    const half_t* cur = x;
+    for (int i = 0; i < 4; ++i) {
+        const DownBlockW& d = w.down[i];
+        for (size_t j = 0; j < d.resnets.size(); ++j) {
+            half_t* r = cx.h((size_t)N * h * wd * d.Cout);
+            TRY(run_resnet(cx, d.resnets[j], cur, r, N, h, wd, 1, tproj + d.resnets[j].temb_off, w.temb_total, c.norm_eps));
+            cur = r;
+            if (d.has_attn) {
+                half_t* t = cx.h((size_t)N * h * wd * d.Cout);
+                TRY(run_transformer2d(cx, d.tnorm[j], d.proj_in[j], d.proj_out[j], d.tb[j], cur, t, N, h, wd, e));
+                cur = t;
+            }
+            res.push_back(cur); res_c.push_back(d.Cout); res_h.push_back(h); res_w.push_back(wd);
+        }
+        if (d.has_down) {
+            const int ho = (h - 1) / 2 + 1, wo = (wd - 1) / 2 + 1;
+            half_t* y = cx.h((size_t)N * ho * wo * d.Cout);
+            ConvOpts o; o.stride = 2;
+            TRY(run_conv(cx, d.down, cur, y, N, h, wd, o));
+            cur = y; h = ho; wd = wo;
+            res.push_back(cur); res_c.push_back(d.Cout); res_h.push_back(h); res_w.push_back(wd);
+        }
+    }
+    // ---- 4. mid block (:836-846) ----
+    {
+        const int C = c.block_out_channels[3];
+        half_t* m0 = cx.h((size_t)N * h * wd * C);
+        TRY(run_resnet(cx, w.mid_r0, cur, m0, N, h, wd, 1, tproj + w.mid_r0.temb_off, w.temb_total, c.norm_eps));
+        half_t* m1 = cx.h((size_t)N * h * wd * C);
+        TRY(run_transformer2d(cx, w.mid_tnorm, w.mid_pin, w.mid_pout, w.mid_tb, m0, m1, N, h, wd, e));
+        half_t* m2 = cx.h((size_t)N * h * wd * C);
+        TRY(run_resnet(cx, w.mid_r1, m1, m2, N, h, wd, 1, tproj + w.mid_r1.temb_off, w.temb_total, c.norm_eps));
+        res.push_back(m2); res_c.push_back(C); res_h.push_back(h); res_w.push_back(wd);
+    }
+    // ---- 5./6. zero convs (:850-858) with the conditioning scale fused (:861-868), NCHW outputs ----
+    const size_t nout = res.size();
+    CTRL_CHECK(nout == w.zero_convs.size(), "controlnet: residual/zero-conv count mismatch");
+    for (size_t i = 0; i < nout; ++i) {
+        float sc = a.scale;
+        if (a.flags & CTRL_GUESS_MODE) {   // torch.logspace(-1, 0, n) * conditioning_scale
+            sc *= powf(10.f, -1.f + (float)i / (float)(nout - 1));
+        }
+        const ConvW& z = w.zero_convs[i];
+        const int HW = res_h[i] * res_w[i];
+        IGemmArgs g = {};
+        g.A = res[i]; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1;
+        g.W = z.w; g.M = N * HW; g.Nout = z.Cout; g.Ktot = z.Cin; g.bias = z.b; g.scale = sc;
+        g.nseg = 1;
+        g.seg[0] = IGemmSeg{a.outs[i], HW, 0, z.Cout, SEG_TRANSPOSED, a.out_dt, HW, 0};
+        RUN(cx, op_igemm(g, cx.s));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctrl_controlnet_param_count(const ctrl_controlnet_config* cfg) {
+    if (!cfg) return -1;
+    SpecCollector sc; ControlNetW w;
+    if (build_controlnet(sc, *cfg, &w)) return -1;
+    return (int)sc.entries.size();
+}
+
+int ctrl_controlnet_param_spec(const ctrl_controlnet_config* cfg, int i, char* name, int name_len, int64_t shape[6], int* ndim) {
+    CTRL_CHECK(cfg && name && shape && ndim, "param_spec: null argument");
+    SpecCollector sc; ControlNetW w;
+    TRY(build_controlnet(sc, *cfg, &w));
+    CTRL_CHECK(i >= 0 && i < (int)sc.entries.size(), "param_spec: index out of range");
+    std::strncpy(name, sc.entries[i].name.c_str(), name_len - 1);
+    name[name_len - 1] = 0;
+    *ndim = (int)sc.entries[i].shape.size();
+    for (int k = 0; k < 6; ++k) shape[k] = k < *ndim ? sc.entries[i].shape[k] : 1;
+    return 0;
+}
+
+int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_ref* tensors, int n_tensors, void* stream,
+                           ctrl_controlnet** out) {
+    CTRL_CHECK(cfg && tensors && out, "controlnet_create: null argument");
+    std::unique_ptr<ctrl_controlnet> h(new ctrl_controlnet());
+    h->packer.reset(new Packer(tensors, n_tensors, (hipStream_t)stream));
+    int rc = build_controlnet(*h->packer, *cfg, &h->w);
+    if (rc) return rc;     // ~ctrl_controlnet frees what was packed so far
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // packed copies are complete; source tensors may be freed
+    *out = h.release();
+    return 0;
+}
+
+void ctrl_controlnet_destroy(ctrl_controlnet* h) { delete h; }
+
+int ctrl_controlnet_forward(ctrl_controlnet* h, const void* sample, int sample_dtype, int N, int Hs, int Ws,
+                            const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype, int Lk,
+                            const void* controlnet_cond, int cond_dtype, float conditioning_scale, int flags,
+                            void* const* outs, int out_dtype, void* stream) {
+    CTRL_CHECK(h && sample && timesteps && encoder_hidden_states && controlnet_cond && outs, "controlnet_forward: null argument");
+    CTRL_CHECK(N >= 1 && N <= 4096 && Hs >= 1 && Ws >= 1 && Lk >= 1, "controlnet_forward: bad sizes");
+    CTRL_CHECK(Hs % 8 == 0 && Ws % 8 == 0, "controlnet_forward: latent height/width must be multiples of 8 (3 stride-2 stages)");
+    CTRL_CHECK(t_count == 1 || t_count == N, "controlnet_forward: need 1 or N timesteps");
+    for (int i = 0; i < 13; ++i) CTRL_CHECK(outs[i] != nullptr, "controlnet_forward: null output pointer");
+    FwdArgs a = {sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
+                 controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype};
+    hipStream_t s = (hipStream_t)stream;
+    // sizing pass (no launches) -> workspace; then the real pass
+    h->arena.off = 0; h->arena.peak = 0;
+    Ctx dry{&h->arena, s, true};
+    TRY(controlnet_run(dry, h->w, a));
+    TRY(h->arena.ensure(workspace_bytes(dry), s));
+    h->arena.off = 0;
+    Ctx cx{&h->arena, s, false};
+    cx.stats_total = dry.stats_total;
+    return controlnet_run(cx, h->w, a);
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+"""ControlNetAdapter -- drop-in mirror of the reference's model/ctrl_adapter.py:ControlNetAdapter whose forward runs
+entirely in libctrlhip.  Same constructor arguments (:17-44), forward signature and return (:171-172, :224), same
+state-dict keys (down_blocks_adapter.{i}.*, mid_block_adapter.*)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._plan import ParamTreeModule, Config, c_spec, timesteps_to_device_f32
+
+_SLOT_C = [320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280]
+_SLOT_F = [1, 1, 1, 2, 2, 2, 4, 4, 4, 8, 8, 8]
+
+
+class ControlNetAdapter(ParamTreeModule):
+    def __init__(self, backbone_model_name, num_blocks=2, num_frames=8, num_adapters_per_location=3,
+                 cross_attention_dim=None, adapter_type="spatial_temporal_resnet_transformer",
+                 add_spatial_resnet=True, add_temporal_resnet=False, add_spatial_transformer=True,
+                 add_temporal_transformer=False, add_adapter_location_A=False, add_adapter_location_B=False,
+                 add_adapter_location_C=False, add_adapter_location_D=False, add_adapter_location_M=False,
+                 num_repeats=1, out_channels=None):
+        super().__init__()
+        self.config = Config({k: v for k, v in locals().items() if k not in ("self", "__class__")})
+        if num_repeats != 1:
+            raise ValueError("num_repeats > 1 (experimental zero-conv aggregation, ctrl_adapter.py:208-221) is not supported")
+        if cross_attention_dim is None and (add_spatial_transformer or add_temporal_transformer):
+            raise ValueError("cross_attention_dim is required when a transformer sub-module is enabled")
+        cfg = L.AdapterConfig()
+        cfg.backbone_sdxl = int(backbone_model_name in ["sdxl"])
+        cfg.num_blocks = num_blocks
+        cfg.num_adapters_per_location = num_adapters_per_location
+        cfg.cross_attention_dim = cross_attention_dim or 0
+        cfg.add_spatial_resnet, cfg.add_temporal_resnet = int(add_spatial_resnet), int(add_temporal_resnet)
+        cfg.add_spatial_transformer, cfg.add_temporal_transformer = int(add_spatial_transformer), int(add_temporal_transformer)
+        cfg.loc_A, cfg.loc_B, cfg.loc_C, cfg.loc_D, cfg.loc_M = (int(add_adapter_location_A), int(add_adapter_location_B),
+                                                                 int(add_adapter_location_C), int(add_adapter_location_D),
+                                                                 int(add_adapter_location_M))
+        self._cfg = cfg
+        self._up = 2 if cfg.backbone_sdxl else 1
+        lib = L.lib()
+        self._register_spec(c_spec(lib.ctrl_adapter_param_count, lib.ctrl_adapter_param_spec, cfg))
+        self.num_adapters_per_location = num_adapters_per_location
+        self.add_adapter_location_M = add_adapter_location_M
+
+    def config_dict(self):
+        return dict(self.config)
+
+    def get_down_block_ids(self):
+        sel = {"A": {3: [0, 1, 2], 2: [0, 2], 1: [2]}, "B": {3: [3, 4, 5], 2: [3, 5], 1: [5]},
+               "C": {3: [6, 7, 8], 2: [6, 8], 1: [8]}, "D": {3: [9, 10, 11], 2: [9, 11], 1: [11]}}
+        ids = []
+        for k in "ABCD":
+            if self.config["add_adapter_location_" + k]:
+                ids += sel[k].get(self.num_adapters_per_location, [])
+        return ids
+
+    def _destroy(self, plan):
+        L.lib().ctrl_adapter_destroy(plan)
+
+    def _ensure_plan(self):
+        if self._plan is None:
+            refs, n, keep = self._tensor_refs()
+            h = C.c_void_p()
+            L.check(L.lib().ctrl_adapter_create(C.byref(self._cfg), refs, n, L.cur_stream(), C.byref(h)))
+            self._plan = h
+        return self._plan
+
+    @torch.no_grad()
+    def forward(self, down_block_res_samples, mid_block_res_sample=None, sparsity_masking=None, num_frames=None,
+                timestep=None, encoder_hidden_states=None):
+        # sparsity_masking is accepted and ignored, exactly like the reference (SURVEY.md note N7)
+        if len(down_block_res_samples) != 12:
+            raise ValueError("expected the 12 ControlNet down_block_res_samples")
+        x0 = down_block_res_samples[0]
+        if not x0.is_cuda:
+            raise RuntimeError("ControlNetAdapter (libctrlhip) runs on the GPU only; there is no CPU fallback")
+        N, _, H0, W0 = x0.shape
+        dt = x0.dtype
+        for i, (t, c, f) in enumerate(zip(down_block_res_samples, _SLOT_C, _SLOT_F)):
+            if tuple(t.shape) != (N, c, max(H0 // f, 1), max(W0 // f, 1)) or t.dtype != dt:
+                raise ValueError("down_block_res_samples[%d] has shape %s, expected the SD-1.5 ControlNet pyramid" % (i, tuple(t.shape)))
+        num_frames = int(num_frames) if num_frames is not None else 1
+        plan = self._ensure_plan()
+        t32 = timesteps_to_device_f32(timestep, N, x0.device)
+        needs_ehs = self.config.add_spatial_transformer or self.config.add_temporal_transformer
+        ehs = None
+        eb, Lk = 1, 1
+        if needs_ehs:
+            ehs = encoder_hidden_states
+            if ehs.dim() == 2:                      # adapter_spatial_temporal.py:240-241
+                ehs = ehs.unsqueeze(1)
+            ehs = ehs.contiguous()
+            eb, Lk = ehs.shape[0], ehs.shape[1]
+            if ehs.shape[2] != self.config.cross_attention_dim or eb not in (1, N):
+                raise ValueError("encoder_hidden_states must be [1 or N, L, %d]" % self.config.cross_attention_dim)
+        ids = self.get_down_block_ids()
+        ins = [t.contiguous() for t in down_block_res_samples]
+        outs = []
+        for i, (c, f) in enumerate(zip(_SLOT_C, _SLOT_F)):
+            h, w = max(H0 // f, 1), max(W0 // f, 1)
+            s = self._up if i in ids else 1             # zeros_like keeps the input size (ctrl_adapter.py:193)
+            outs.append(torch.empty(N, c, h * s, w * s, dtype=dt, device=x0.device))
+        mid_in = mid_out = None
+        if mid_block_res_sample is not None and self.add_adapter_location_M:
+            mid_in = mid_block_res_sample.contiguous()
+            mid_out = torch.empty(N, 1280, mid_in.shape[2] * self._up, mid_in.shape[3] * self._up, dtype=dt, device=x0.device)
+        in_ptrs = (C.c_void_p * 13)(*([t.data_ptr() for t in ins] + [mid_in.data_ptr() if mid_in is not None else None]))
+        out_ptrs = (C.c_void_p * 13)(*([t.data_ptr() for t in outs] + [mid_out.data_ptr() if mid_out is not None else None]))
+        L.check(L.lib().ctrl_adapter_forward(
+            plan, in_ptrs, L.dtype_code(dt), N, H0, W0, num_frames, L.ptr(t32), t32.numel(),
+            L.ptr(ehs), L.dtype_code(ehs.dtype) if ehs is not None else 0, eb, Lk,
+            out_ptrs, L.dtype_code(dt), L.cur_stream()))
+        return outs, mid_out

@@ -101,12 +101,12 @@ def conv2d(x_nhwc, w_packed, Cout, taps=9, stride=1, up=1, bias=None, rowvec=Non
     return out
 
 
-def flash_attn(Q, ldq, K, ldk, Vt, Lkpad, B, heads, D, Lq, Lk, scale=None):
+def flash_attn(Q, ldq, K, ldk, Vt, Lkpad, B, heads, D, Lq, Lk, scale=None, kvB=0):
     out = _f16(B * Lq, heads * D)
     d = L.AttnDesc()
     d.Q = Q.data_ptr(); d.ldq = ldq; d.K = K.data_ptr(); d.ldk = ldk; d.Vt = Vt.data_ptr(); d.Lkpad = Lkpad
     d.O = out.data_ptr(); d.ldo = heads * D
-    d.B = B; d.heads = heads; d.D = D; d.Lq = Lq; d.Lk = Lk
+    d.B = B; d.heads = heads; d.D = D; d.Lq = Lq; d.Lk = Lk; d.kvB = kvB if kvB else B
     d.scale = scale if scale is not None else D ** -0.5
     L.check(L.lib().ctrl_op_flash_attn(C.byref(d), L.cur_stream()))
     return out

@@ -71,15 +71,15 @@ typedef struct ctrl_igemm_desc {
     float scale;
     int32_t geglu;      /* weights packed in interleaved (hidden,gate) 16-column blocks; out width Nout/2 */
     int32_t nseg;
-    int32_t pad2_;
+    int32_t act;        /* 0 none, 1 SiLU applied after bias/rowvec (before residual) */
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
 
 typedef struct ctrl_attn_desc {
     const void* Q; int64_t ldq;      /* [B*Lq][ldq] fp16, head h at column h*D */
-    const void* K; int64_t ldk;      /* [B*Lk][ldk] */
-    const void* Vt; int32_t Lkpad; int32_t pad0_;   /* [B][heads*D][Lkpad], Lkpad % 64 == 0 */
+    const void* K; int64_t ldk;      /* [kvB*Lk][ldk] */
+    const void* Vt; int32_t Lkpad; int32_t kvB;     /* [kvB][heads*D][Lkpad], Lkpad % 64 == 0; kvB = B, or 1 = K/V shared by all batches */
     void* O; int64_t ldo;            /* [B*Lq][ldo] */
     int32_t B, heads, D, Lq, Lk;
     float scale;
@@ -123,7 +123,7 @@ typedef struct ctrl_tensor_ref {
     const void* data;
     int32_t dtype;
     int32_t ndim;
-    int64_t shape[4];
+    int64_t shape[6];
 } ctrl_tensor_ref;
 
 /* ---- ControlNet (SD-1.5 architecture family; controlnet/controlnet.py:179-438) ---- */
@@ -145,7 +145,7 @@ typedef struct ctrl_controlnet ctrl_controlnet;   /* opaque */
  * Python mirror).  Returns the number of parameters; fills name/shape for index i. */
 int ctrl_controlnet_param_count(const ctrl_controlnet_config* cfg);
 int ctrl_controlnet_param_spec(const ctrl_controlnet_config* cfg, int i, char* name, int name_len,
-                               int64_t shape[4], int* ndim);
+                               int64_t shape[6], int* ndim);
 /* builds a plan: packs the weights (fp16, MFMA-friendly layouts) into memory owned by the plan */
 int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_ref* tensors, int n_tensors,
                            void* stream, ctrl_controlnet** out);
@@ -176,7 +176,7 @@ typedef struct ctrl_adapter_config {
 typedef struct ctrl_adapter ctrl_adapter;
 int ctrl_adapter_param_count(const ctrl_adapter_config* cfg);
 int ctrl_adapter_param_spec(const ctrl_adapter_config* cfg, int i, char* name, int name_len,
-                            int64_t shape[4], int* ndim);
+                            int64_t shape[6], int* ndim);
 int ctrl_adapter_create(const ctrl_adapter_config* cfg, const ctrl_tensor_ref* tensors, int n_tensors,
                         void* stream, ctrl_adapter** out);
 void ctrl_adapter_destroy(ctrl_adapter* h);

@@ -1,0 +1,143 @@
+"""End-to-end parity of the plan-level C ABI (through the nn.Module mirrors) on a real MI355X:
+  * against the committed golden vectors (reference's own files run over the diffusers shim), tiny grids
+  * against the CPU oracle at the full SDXL 1024^2 shapes for one image
+  * size-independent properties at batch 8 (batch consistency, linearity in conditioning_scale, zero slots)
+Tolerance: rel-inf = max|a-b| / max|b| per output tensor.  The HIP path stores activations
+in fp16 with fp32 accumulation / statistics / softmax; weights and inputs are fp16-representable on both sides.
+The north-star bound is 1e-3 on the adapter residuals; TOL below is the asserted bound and the achieved values are
+printed (and recorded in profiles/)."""
+import pytest
+import torch
+
+from helpers import load_golden, check_digest
+import cases
+from conftest import rel_inf
+from oracle.init import seeded_init, seeded_tensor
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def P(gpu):
+    import ctrl_adapter_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def controlnet(P, gpu):
+    return seeded_init(P.ControlNetModel(**cases.CONTROLNET_KW), seed=11).to(gpu)
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", {}), ("scale0.5", dict(conditioning_scale=0.5)),
+                                    ("skip_conv_in", dict(skip_conv_in=True)), ("skip_time_emb", dict(skip_time_emb=True)),
+                                    ("guess", dict(guess_mode=True))])
+def test_controlnet_golden(controlnet, gpu, tag, kw):
+    g = load_golden("controlnet_sd15.pt")["runs"][tag]
+    inp = cases.controlnet_inputs()
+    down, mid = controlnet(inp["sample"].half().to(gpu), inp["timestep"].to(gpu), inp["encoder_hidden_states"].half().to(gpu),
+                           inp["controlnet_cond"].half().to(gpu), return_dict=False, **kw)
+    errs = [check_digest(t, d, TOL, "controlnet[%s] out %d" % (tag, i)) for i, (t, d) in enumerate(zip(list(down) + [mid], g))]
+    print("PARITY controlnet golden %-14s max rel_inf=%.3e" % (tag, max(errs)))
+
+
+def test_controlnet_output_container_and_dtypes(controlnet, gpu):
+    inp = cases.controlnet_inputs()
+    out = controlnet(inp["sample"].to(gpu), 999, inp["encoder_hidden_states"].to(gpu), inp["controlnet_cond"].to(gpu))
+    assert len(out.down_block_res_samples) == 12 and out.mid_block_res_sample.shape == (2, 1280, 1, 1)
+    assert out[0][0].dtype == torch.float32          # fp32 boundary tensors in -> fp32 out
+    with pytest.raises(ValueError):
+        controlnet(inp["sample"].to(gpu), 999, inp["encoder_hidden_states"].to(gpu), inp["controlnet_cond"][:, :, :32].to(gpu))
+    with pytest.raises(RuntimeError):
+        controlnet(inp["sample"], 999, inp["encoder_hidden_states"], inp["controlnet_cond"])     # CPU tensors: no fallback
+
+
+def test_adapter_sdxl_golden(P, gpu):
+    g = load_golden("adapter_sdxl.pt")
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+    downs, _ = cases.pyramid_inputs(N=2, h0=8, seed=200, with_mid=False)
+    out, mid = ad([d.half().to(gpu) for d in downs], sparsity_masking=None, num_frames=1, timestep=torch.tensor(749.0),
+                  encoder_hidden_states=seeded_tensor((2, 77, 2048), 290).half().to(gpu))
+    assert mid is None
+    errs = [check_digest(t, d, TOL, "adapter_sdxl out %d" % i) for i, (t, d) in enumerate(zip(out, g["out"]))]
+    print("PARITY adapter_sdxl golden per-slot rel_inf: " + " ".join("%.2e" % e for e in errs))
+    for i in (9, 10, 11):
+        assert out[i].abs().max().item() == 0.0 and out[i].shape == downs[i].shape
+
+
+def test_adapter_video_golden(P, gpu):
+    g = load_golden("adapter_video.pt")
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_VIDEO), seed=33).to(gpu)
+    downs, midin = cases.pyramid_inputs(N=8, h0=8, seed=300, with_mid=True)
+    out, mid = ad([d.half().to(gpu) for d in downs], mid_block_res_sample=midin.half().to(gpu), num_frames=4,
+                  timestep=torch.tensor(961.0), encoder_hidden_states=seeded_tensor((1, 1, 1024), 390).half().to(gpu))
+    errs = [check_digest(t, d, TOL, "adapter_video out %d" % i) for i, (t, d) in enumerate(zip(list(out) + [mid], g["out"]))]
+    print("PARITY adapter_video golden per-slot rel_inf: " + " ".join("%.2e" % e for e in errs))
+
+
+def test_router_golden_and_merge(P, gpu):
+    g = load_golden("router.pt")
+    r = seeded_init(P.ControlNetRouter(num_experts=3, router_type="simple_weights", num_routers=12), seed=44).to(gpu)
+    assert sorted(r.state_dict().keys()) == g["keys"]
+    for tag, mask in {"all": [1, 1, 1], "m101": [1, 0, 1], "none": None}.items():
+        dw, mw = r(sparse_mask=mask)
+        assert torch.allclose(dw.cpu(), g["runs"][tag]["down"], atol=1e-6), tag
+        assert torch.allclose(mw.cpu(), g["runs"][tag]["mid"], atol=1e-6), tag
+    dw, mw = P.ControlNetRouter(num_experts=2, router_type="equal_weights")(sparse_mask=[1, 1])
+    assert torch.allclose(dw.cpu(), g["equal"]["down"]) and torch.allclose(mw.cpu(), g["equal"]["mid"])
+    # merge: both the inference quirk (N6) and the training formula, against the oracle's restatement
+    from oracle.router import merge_inference, merge_training
+    E, F = 3, 4
+    downs = [[seeded_tensor((2, 8, 2, 2), 10 * e + k) for k in range(12)] for e in range(E)]
+    mids = [seeded_tensor((2, 8, 1, 1), 500 + e) for e in range(E)]
+    dw, mw = r(sparse_mask=[1, 0, 1])
+    act = [0, 2]
+    gd = [[downs[e][k].to(gpu) for k in range(12)] for e in act]
+    gm = [mids[e].to(gpu) for e in act]
+    md, mm = r.merge(gd, gm, dw, mw, [1, 0, 1], num_frames=F, inference_quirk=True)
+    rd, rm = merge_inference([downs[e] for e in act], [mids[e] for e in act], dw.cpu(), mw.cpu(), [1, 0, 1], F)
+    assert max(rel_inf(a, b) for a, b in zip(md, rd)) < 1e-6 and rel_inf(mm, rm) < 1e-6
+    md, mm = r.merge(gd, gm, dw, mw, [1, 0, 1], inference_quirk=False)
+    rd, rm = merge_training([downs[e] for e in act], [mids[e] for e in act], dw.cpu(), mw.cpu(), [1, 0, 1])
+    assert max(rel_inf(a, b) for a, b in zip(md, rd)) < 1e-6 and rel_inf(mm, rm) < 1e-6
+
+
+def test_full_size_sdxl_vs_oracle_and_batch_properties(P, controlnet, gpu):
+    """BASELINE.json config 2 shapes (64x64 latents -> 128x128 adapter grids): one image against the CPU oracle,
+    then batch 8 through size-independent properties."""
+    from oracle.controlnet import ControlNetOracle
+    from oracle.adapter import ControlNetAdapterOracle
+    torch.set_grad_enabled(False)
+    lat = seeded_tensor((1, 4, 128, 128), 1)
+    ehs_c = seeded_tensor((1, 77, 768), 2)
+    cond = seeded_tensor((1, 3, 512, 512), 3, kind="uniform")
+    ehs_a = seeded_tensor((1, 77, 2048), 4)
+    t = torch.tensor(499.0)
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+
+    def run(n):
+        s = P.pool_latents(lat.half().to(gpu).repeat(n, 1, 1, 1), (64, 64))
+        d, m = controlnet(s, t, ehs_c.half().to(gpu).repeat(n, 1, 1), cond.half().to(gpu).repeat(n, 1, 1, 1), return_dict=False)
+        o, _ = ad(d, num_frames=1, timestep=t, encoder_hidden_states=ehs_a.half().to(gpu).repeat(n, 1, 1))
+        return d, m, o
+
+    d1, m1, o1 = run(1)
+    oc = seeded_init(ControlNetOracle(**cases.CONTROLNET_KW).eval(), seed=11)
+    oa = seeded_init(ControlNetAdapterOracle(**cases.ADAPTER_SDXL).eval(), seed=22)
+    rd, rm = oc(torch.nn.functional.adaptive_avg_pool2d(lat, (64, 64)), t, ehs_c, cond)
+    ro, _ = oa(rd, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+    e_cn = [rel_inf(a, b) for a, b in zip(list(d1) + [m1], list(rd) + [rm])]
+    e_ad = [rel_inf(a, b) for a, b in zip(o1[:9], ro[:9])]
+    print("PARITY full-size controlnet rel_inf: " + " ".join("%.2e" % e for e in e_cn))
+    print("PARITY full-size adapter    rel_inf: " + " ".join("%.2e" % e for e in e_ad))
+    assert max(e_cn) <= TOL and max(e_ad) <= TOL
+    # batch 8: every image of a replicated batch must reproduce the single-image result
+    d8, m8, o8 = run(8)
+    for a, b in zip(o8[:9], o1[:9]):
+        assert rel_inf(a[5:6], b) < 2e-3
+        assert rel_inf(a[0:1], a[7:8]) < 2e-3
+    assert o8[0].shape == (8, 320, 128, 128) and o8[8].shape == (8, 1280, 32, 32) and o8[11].shape == (8, 1280, 8, 8)
+    # linearity of the ControlNet outputs in conditioning_scale
+    s = P.pool_latents(lat.half().to(gpu), (64, 64))
+    dh, mh = controlnet(s, t, ehs_c.half().to(gpu), cond.half().to(gpu), conditioning_scale=0.25, return_dict=False)
+    assert max(rel_inf(a.float() * 4, b) for a, b in zip(dh, d1)) < 2e-3
