@@ -230,6 +230,7 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid((a.Lq + 127) / 128, a.heads, a.B);
+    PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
     LAUNCH("flash_attn", (flash_attn_kernel<D>), grid, dim3(256), smem, s, a);
     return 0;
 }
@@ -349,6 +350,7 @@ int op_temporal_attn(const TAttnArgs& a, hipStream_t s) {
     const long nitems = (long)a.Bc * a.HW * a.heads;
     CTRL_CHECK(nitems > 0, "temporal_attn: empty problem");
     dim3 grid((unsigned)((nitems + 3) / 4));
+    PROF_WORK(4.0 * nitems * a.F * a.F * 64, 2.0 * 4.0 * nitems * a.F * 64);
     if (a.F <= 16) LAUNCH("temporal_attn", temporal_attn_kernel<16>, grid, dim3(256), 0, s, a);
     else LAUNCH("temporal_attn", temporal_attn_kernel<32>, grid, dim3(256), 0, s, a);
     return 0;

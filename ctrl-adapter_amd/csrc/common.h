@@ -35,6 +35,8 @@ void ctrl_set_error(const std::string& s);
 void prof_before(const char* tag, hipStream_t s);
 void prof_after(hipStream_t s);
 extern bool g_prof_on;
+extern double g_prof_flops, g_prof_bytes;     // algorithmic work of the NEXT launch (set by the op, consumed by prof_before)
+#define PROF_WORK(flops, bytes) do { if (g_prof_on) { g_prof_flops = (double)(flops); g_prof_bytes = (double)(bytes); } } while (0)
 
 #define LAUNCH(tag, kern, grid, block, shmem, stream, ...)                        \
     do {                                                                          \

@@ -254,6 +254,7 @@ int launch_cfg(const IGemmArgs& a, hipStream_t s) {
         attr_done = true;
     }
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
+    PROF_WORK(2.0 * a.M * a.Nout * a.Ktot, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
     LAUNCH(tag, (igemm_kernel<BM, BN, BK, MODE>), dim3(ntm * ntn), dim3(256), smem, s, a, ntm, ntn);
     return 0;

@@ -143,6 +143,7 @@ int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C
     rows_per_block = ((rows_per_block + rpi - 1) / rpi) * rpi;
     if (rows_per_block < rpi) rows_per_block = rpi;
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
+    PROF_WORK(0, 2.0 * imgs * rows_per_img * C);
     LAUNCH("gn_stats", gn_stats_kernel, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
            x, stats, rows_per_img, C, G, rows_per_block);
     return 0;
@@ -154,6 +155,7 @@ int op_gn_apply(const half_t* x, const float* stats, const float* gamma, const f
     const size_t total = (size_t)imgs * rows_per_img * (C / 8);
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    PROF_WORK(0, 4.0 * imgs * rows_per_img * C);
     LAUNCH("gn_apply", gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
            x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, total);
     return 0;
@@ -164,6 +166,7 @@ int op_layernorm(const half_t* x, long ldx, const float* gamma, const float* bet
     CTRL_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C must be a multiple of 8 and <= 2048");
     CTRL_CHECK(ldx % 8 == 0 && ldy % 8 == 0, "layernorm: leading dims must be multiples of 8");
     const dim3 grid((M + 3) / 4), block(256);
+    PROF_WORK(0, 4.0 * M * C);
     if (C <= 512) LAUNCH("layernorm", layernorm_kernel<1>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);
     else if (C <= 1024) LAUNCH("layernorm", layernorm_kernel<2>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);
     else LAUNCH("layernorm", layernorm_kernel<4>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);

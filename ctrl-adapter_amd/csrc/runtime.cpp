@@ -10,13 +10,16 @@ static thread_local std::string g_err;
 void ctrl_set_error(const std::string& s) { g_err = s; }
 
 bool g_prof_on = false;
+double g_prof_flops = 0, g_prof_bytes = 0;
 namespace {
-struct Rec { const char* tag; hipEvent_t e0, e1; };
+struct Rec { const char* tag; hipEvent_t e0, e1; double flops, bytes; };
+struct Sum { double ms = 0, flops = 0, bytes = 0; int n = 0; };
 std::vector<Rec> g_recs;
-std::vector<std::pair<std::string, std::pair<double, int>>> g_summary;
+std::vector<std::pair<std::string, Sum>> g_summary;
 }
 void prof_before(const char* tag, hipStream_t s) {
-    Rec r; r.tag = tag;
+    Rec r; r.tag = tag; r.flops = g_prof_flops; r.bytes = g_prof_bytes;
+    g_prof_flops = g_prof_bytes = 0;
     hipEventCreate(&r.e0); hipEventCreate(&r.e1);
     hipEventRecord(r.e0, s);
     g_recs.push_back(r);
@@ -30,12 +33,12 @@ int ctrl_prof_begin(void) { g_recs.clear(); g_summary.clear(); g_prof_on = true;
 int ctrl_prof_end(void) {
     g_prof_on = false;
     HIP_TRY(hipDeviceSynchronize());
-    std::map<std::string, std::pair<double, int>> acc;
+    std::map<std::string, Sum> acc;
     for (auto& r : g_recs) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.e0, r.e1);
         auto& a = acc[r.tag];
-        a.first += ms; a.second += 1;
+        a.ms += ms; a.n += 1; a.flops += r.flops; a.bytes += r.bytes;
         hipEventDestroy(r.e0); hipEventDestroy(r.e1);
     }
     g_recs.clear();
@@ -43,12 +46,14 @@ int ctrl_prof_end(void) {
     return 0;
 }
 int ctrl_prof_count(void) { return (int)g_summary.size(); }
-int ctrl_prof_get(int i, char* name, int name_len, double* total_ms, int* launches) {
+int ctrl_prof_get(int i, char* name, int name_len, double* total_ms, int* launches, double* flops, double* bytes) {
     CTRL_CHECK(i >= 0 && i < (int)g_summary.size(), "prof_get: index out of range");
     std::strncpy(name, g_summary[i].first.c_str(), name_len - 1);
     name[name_len - 1] = 0;
-    *total_ms = g_summary[i].second.first;
-    *launches = g_summary[i].second.second;
+    *total_ms = g_summary[i].second.ms;
+    *launches = g_summary[i].second.n;
+    if (flops) *flops = g_summary[i].second.flops;
+    if (bytes) *bytes = g_summary[i].second.bytes;
     return 0;
 }
 }

@@ -233,9 +233,9 @@ class Profiler:
         L.check(lib.ctrl_prof_end())
         self.rows = {}
         name = C.create_string_buffer(64)
-        ms = C.c_double()
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
         n = C.c_int()
         for i in range(lib.ctrl_prof_count()):
-            L.check(lib.ctrl_prof_get(i, name, 64, C.byref(ms), C.byref(n)))
-            self.rows[name.value.decode()] = (ms.value, n.value)
+            L.check(lib.ctrl_prof_get(i, name, 64, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            self.rows[name.value.decode()] = (ms.value, n.value, fl.value, by.value)
         return False

@@ -39,7 +39,8 @@ const char* ctrl_last_error(void);           /* thread-local, valid until the ne
 int ctrl_prof_begin(void);
 int ctrl_prof_end(void);
 int ctrl_prof_count(void);
-int ctrl_prof_get(int i, char* name, int name_len, double* total_ms, int* launches);
+/* flops / bytes: ALGORITHMIC work summed over the class's launches (2*M*N*K, 4*B*h*Lq*Lk*D, one read + one write, ...) */
+int ctrl_prof_get(int i, char* name, int name_len, double* total_ms, int* launches, double* flops, double* bytes);
 
 /* ---------------------------------------------------------------- op level */
 typedef struct ctrl_igemm_seg {
