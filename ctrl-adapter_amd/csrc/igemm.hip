@@ -13,32 +13,42 @@
 // cin contiguous, so every A-tile row is one 16-byte-vectorisable run of channels of one (shifted)
 // input pixel; zero padding is a predicated load.  Weights are pre-packed [Cout][tap][Cin].
 //
-// Tiling: BM x BN x BK per 256-thread workgroup (4 wavefronts in a 2x2 grid), A/B tiles staged
-// global -> VGPR -> LDS (double-buffered, next tile's global loads in flight during the MFMAs),
-// LDS rows padded to an odd number of 16-byte slots so the ds_read_b128 fragment reads of 16 distinct
-// rows are bank-conflict free (MI355X_MICROARCH.md, LDS section).  fp32 accumulation; the epilogue
+// Tiling: BM x BN x BK per workgroup (4 or 8 wavefronts), A/B tiles staged global -> LDS with the asynchronous
+// LDS-DMA (global_load_lds_dwordx4: no VGPR round trip) into an NSTAGE-deep ring: NSTAGE-1 tiles in flight,
+// a counted s_waitcnt vmcnt(N) + raw s_barrier per k-tile so later tiles stay in flight across the barrier; LDS tiles are linear and bank conflicts of the ds_read_b128 fragment reads are removed
+// by an XOR chunk swizzle applied on the SOURCE address and on the read (MI355X_MICROARCH.md, LDS section;
+// cdna_hip_programming.md rule 21).  Zero padding (conv halo, ragged M/N) = loading from a zero page.  fp32 accumulation; the epilogue
 // fuses bias, per-image channel vector (time embedding), GEGLU, residual add, scale and the output
 // layout (row-major slice, or transposed [img][C][tokens] for NCHW results / the V^T attention operand).
 #include "ops.h"
 
 namespace {
 
-template <int BM, int BN, int BK, int MODE>
-__global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a, int ntm, int ntn) {
+// LDS tiles are linear [rows][BK] (global_load_lds writes wave-uniform base + lane*16), so bank conflicts of the
+// ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte chunk index that is applied to the
+// per-lane SOURCE address when staging and to the read address when fetching fragments (same involution).
+template <int BK>
+__device__ __forceinline__ int chunk_swz(int row) {
+    if (BK == 64) return (row >> 1) & 7;          // 128-B rows: 2 rows per 256-B bank line
+    return (0 - (row >> 2)) & 3;                   // 64-B rows: 4 rows per bank line; {0,3,2,1} keeps mixed-chunk groups apart
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int LDS_LD = BK + 8;           // halfs; (BK*2+16) bytes = odd number of 16-B slots
-    constexpr int WM = BM / 2, WN = BN / 2;  // per-wave tile
+    constexpr int NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // per-wave tile
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int CPR = BK / 8;              // 16-B chunks per tile row
-    constexpr int RPP = 256 / CPR;           // rows staged per pass
-    constexpr int APASS = BM / RPP, BPASS = BN / RPP;
-    static_assert(APASS >= 1 && BPASS >= 1, "tile too small for 256 threads");
+    constexpr int RPW = 64 / CPR;            // rows written by one wave-wide global_load_lds (1 KiB)
+    constexpr int APASS = BM / (NW * RPW), BPASS = BN / (NW * RPW);
+    static_assert(APASS >= 1 && BPASS >= 1, "tile too small for the workgroup");
 
-    half_t* As = (half_t*)smem_raw;                  // [2][BM][LDS_LD]
-    half_t* Bs = As + 2 * BM * LDS_LD;               // [2][BN][LDS_LD]
+    half_t* As = (half_t*)smem_raw;                  // [NSTAGE][BM][BK]
+    half_t* Bs = As + NSTAGE * BM * BK;              // [NSTAGE][BN][BK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     // XCD-aware bijective remap: each XCD (blockIdx % 8) walks a contiguous range of tiles so the
     // A rows / weight panels it re-reads stay in that XCD's private L2.
@@ -51,16 +61,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a, int ntm, int nt
     const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-thread staging coordinates ----
-    const int srow = tid / CPR;          // row within a pass
-    const int sc8 = (tid % CPR) * 8;     // channel offset of this thread's 16-B chunk
-    size_t a_off[APASS];                 // MODE ROWS/TEMPORAL: element offset of row start; CONV2D: image base pixel
+    // ---- per-lane staging coordinates: pass i, this wave writes rows [(i*NW+wave)*RPW, +RPW) of the tile ----
+    const int lrow = lane / CPR, lpos = lane % CPR;
+    size_t a_off[APASS];                 // ROWS/TEMPORAL: element offset of the row start; CONV2D: image base pixel
     int a_y[APASS], a_x[APASS];          // CONV2D: oy*stride-pad, ox*stride-pad; TEMPORAL: a_y = frame index
     bool a_ok[APASS];
+    int a_c8[APASS];                     // source chunk (halfs) after the swizzle
     const int pad = (a.taps == 9) ? 1 : 0;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-        const int m = m0 + srow + i * RPP;
+        const int trow = (i * NW + wave) * RPW + lrow;
+        a_c8[i] = (lpos ^ chunk_swz<BK>(trow)) * 8;
+        const int m = m0 + trow;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? m : 0;
         if (MODE == IG_ROWS) {
@@ -84,9 +96,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a, int ntm, int nt
 
     size_t b_off[BPASS];
     bool b_ok[BPASS];
+    int b_c8[BPASS];
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-        const int n = n0 + srow + i * RPP;
+        const int trow = (i * NW + wave) * RPW + lrow;
+        b_c8[i] = (lpos ^ chunk_swz<BK>(trow)) * 8;
+        const int n = n0 + trow;
         b_ok[i] = n < a.Nout;
         b_off[i] = (size_t)(b_ok[i] ? n : 0) * a.Ktot;
     }
@@ -94,44 +109,43 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a, int ntm, int nt
     const half_t* Aptr = (const half_t*)a.A;
     const half_t* Wptr = (const half_t*)a.W;
     const half_t* Rptr = (const half_t*)a.res;
-    h8 areg[APASS], breg[BPASS];
-    const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    auto gload = [&](int kt) {
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+
+    // asynchronous global -> LDS staging of k-tile kt into buffer buf (no VGPR round trip)
+    auto stage = [&](int kt, int buf) {
         const int k0 = kt * BK;
         int tap = 0, c0 = k0;
         if (MODE != IG_ROWS) { tap = k0 / a.Cin; c0 = k0 - tap * a.Cin; }
         int ky = 0, kx = 0;
         if (MODE == IG_CONV2D && a.taps == 9) { ky = tap / 3; kx = tap - 3 * ky; }
+        half_t* Ab = As + buf * BM * BK;
+        half_t* Bb = Bs + buf * BN * BK;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             bool ok = a_ok[i];
             size_t off;
             if (MODE == IG_ROWS) {
-                off = a_off[i] + k0 + sc8;
+                off = a_off[i] + k0 + a_c8[i];
             } else if (MODE == IG_CONV2D) {
                 const int vy = a_y[i] + ky, vx = a_x[i] + kx;
                 ok = ok && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
                 const int sy = vy >> ushift, sx = vx >> ushift;
-                off = (a_off[i] + (size_t)(ok ? sy : 0) * a.Win + (ok ? sx : 0)) * a.lda + c0 + sc8;
+                off = (a_off[i] + (size_t)(ok ? sy : 0) * a.Win + (ok ? sx : 0)) * a.lda + c0 + a_c8[i];
             } else {
                 const int f = a_y[i] + tap - 1;
                 ok = ok && f >= 0 && f < a.F;
-                off = a_off[i] + (ok ? (long)(tap - 1) * a.HW * a.lda : 0) + c0 + sc8;
+                off = a_off[i] + (ok ? (long)(tap - 1) * a.HW * a.lda : 0) + c0 + a_c8[i];
             }
-            areg[i] = ok ? *(const h8*)(Aptr + off) : hzero;
+            const half_t* src = ok ? (Aptr + off) : zeros;          // zero padding = load from a zero page
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ab + (i * NW + wave) * RPW * BK), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i)
-            breg[i] = b_ok[i] ? *(const h8*)(Wptr + b_off[i] + k0 + sc8) : hzero;
-    };
-    auto lds_store = [&](int buf) {
-        half_t* Ab = As + buf * BM * LDS_LD;
-        half_t* Bb = Bs + buf * BN * LDS_LD;
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) *(h8*)(Ab + (srow + i * RPP) * LDS_LD + sc8) = areg[i];
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) *(h8*)(Bb + (srow + i * RPP) * LDS_LD + sc8) = breg[i];
+        for (int i = 0; i < BPASS; ++i) {
+            const half_t* src = b_ok[i] ? (Wptr + b_off[i] + k0 + b_c8[i]) : zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bb + (i * NW + wave) * RPW * BK), 16, 0, 0);
+        }
     };
 
     f4 acc[MI][NI];
@@ -141,35 +155,114 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a, int ntm, int nt
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.Ktot / BK;
-    gload(0);
-    lds_store(0);
-    __syncthreads();
+    // NSTAGE-deep LDS ring: D = NSTAGE-1 tiles are in flight; a counted vmcnt (never 0 in steady state) retires only
+    // the tile about to be consumed, so the LDS-DMA of later tiles stays in flight across the barrier.
+    constexpr int D = NSTAGE - 1;
+    constexpr int LPT = APASS + BPASS;       // global_load_lds instructions per lane per tile
+    static_assert((D - 1) * LPT <= 63, "vmcnt immediate overflow");
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+        if (t < nk) stage(t, t);
 
-    const int frow = lane & 15, fk = (lane >> 4) * 8;
-    int cur = 0;
+    // fragment read coordinates: row (lane&15) of a 16-row fragment, logical chunk (lane>>4) + 4*kk
+    const int frow = lane & 15, fch = lane >> 4;
+    int a_rd[MI], b_rd[NI];       // element offset of the fragment row inside a tile buffer
+    int a_sw[MI], b_sw[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { const int r = wm * WM + mi * 16 + frow; a_rd[mi] = r * BK; a_sw[mi] = chunk_swz<BK>(r); }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { const int r = wn * WN + ni * 16 + frow; b_rd[ni] = r * BK; b_sw[ni] = chunk_swz<BK>(r); }
+
+    int cur = 0;                                    // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);            // global loads stay in flight under the MFMAs
-        const half_t* Ab = As + cur * BM * LDS_LD + (wm * WM + frow) * LDS_LD + fk;
-        const half_t* Bb = Bs + cur * BN * LDS_LD + (wn * WN + frow) * LDS_LD + fk;
+        // tile kt must have landed: allow the D-1 younger tiles to stay outstanding (tail: drain)
+        if (kt + D - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // every wave's part of tile kt is visible; slot of tile kt-1 is free
+        if (kt + D < nk) {
+            int nb = cur + D;
+            if (nb >= NSTAGE) nb -= NSTAGE;
+            stage(kt + D, nb);                      // streams into LDS under the MFMAs below
+        }
+        const half_t* Ab = As + cur * BM * BK;
+        const half_t* Bb = Bs + cur * BN * BK;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             h8 af[MI], bf[NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[mi] = *(const h8*)(Ab + mi * 16 * LDS_LD + kk * 32);
+            for (int mi = 0; mi < MI; ++mi) af[mi] = *(const h8*)(Ab + a_rd[mi] + (((kk * 4 + fch) ^ a_sw[mi]) << 3));
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const h8*)(Bb + ni * 16 * LDS_LD + kk * 32);
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const h8*)(Bb + b_rd[ni] + (((kk * 4 + fch) ^ b_sw[ni]) << 3));
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (kt + 1 < nk) lds_store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
     }
 
     // ---------------- epilogue ----------------
+    if constexpr (SWAP) {
+        // Operands were swapped (D = W.A^T): the lane owns ONE output row m = lane&15 and FOUR consecutive output
+        // columns n = (lane>>4)*4 + i, so bias / residual / result move as 8- or 16-byte vectors (row-major outputs).
+        const int erow = lane & 15, ecol = (lane >> 4) * 4;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            if (a.geglu && (ni & 1)) continue;
+            const int pcb = n0 + wn * WN + ni * 16;
+            if (pcb >= a.Nout) continue;
+            const int pcol = pcb + ecol;
+            const int ocol = a.geglu ? ((pcb >> 5) << 4) + ecol : pcol;
+            const int ocb = ocol - ecol;
+            int si = 0;
+#pragma unroll
+            for (int k = 1; k < 3; ++k)
+                if (k < a.nseg && ocb >= a.seg[k].col_begin) si = k;
+            const IGemmSeg sg = a.seg[si];
+            const int scol = ocol - sg.col_begin;
+            f4 bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+                bh = *(const f4*)(a.bias + pcol);
+                if (a.geglu) bg = *(const f4*)(a.bias + pcol + 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = m0 + wm * WM + mi * 16 + erow;
+                if (row >= a.M) continue;
+                f4 x = acc[mi][ni] + bh;
+                if (a.rowvec) x += *(const f4*)(a.rowvec + (size_t)(row / a.rows_per_img) * a.rowvec_ld + pcol);
+                if (a.geglu) {
+                    const f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)] + bg;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
+                }
+                if (a.act == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
+                }
+                if (Rptr) {
+                    const h4 r = *(const h4*)(Rptr + (size_t)row * a.ldres + ocol);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[i] += (float)r[i];
+                }
+                x *= a.scale;
+                const size_t o = (size_t)row * sg.ld + scol;
+                if (sg.dtype == DT_F16) {
+                    h4 pk = {(half_t)x[0], (half_t)x[1], (half_t)x[2], (half_t)x[3]};
+                    *(h4*)((half_t*)sg.out + o) = pk;
+                } else if (sg.dtype == DT_F32) {
+                    *(f4*)((float*)sg.out + o) = x;
+                } else {
+                    typedef u16 us4 __attribute__((ext_vector_type(4)));
+                    us4 pk = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+                    *(us4*)((u16*)sg.out + o) = pk;
+                }
+            }
+        }
+        return;
+    }
     // C/D fragment map of v_mfma_f32_16x16x32: row = (lane>>4)*4 + i, col = lane&15
     const int erow = (lane >> 4) * 4, ecol = lane & 15;
     constexpr int NSTEP = 1;
@@ -244,37 +337,70 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a, int ntm, int nt
     (void)NSTEP;
 }
 
-template <int BM, int BN, int BK, int MODE>
-int launch_cfg(const IGemmArgs& a, hipStream_t s) {
-    constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(half_t);
+const half_t* zero_page() {
+    static half_t* z = nullptr;
+    if (!z) {
+        if (hipMalloc((void**)&z, 4096) != hipSuccess) return nullptr;
+        hipMemset(z, 0, 4096);
+    }
+    return z;
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
+int launch_cfg2(const IGemmArgs& a, hipStream_t s) {
+    constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(half_t);
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, MODE>,
+        HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
+    const half_t* zeros = zero_page();
+    CTRL_CHECK(zeros != nullptr, "igemm: could not allocate the zero page");
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
     PROF_WORK(2.0 * a.M * a.Nout * a.Ktot, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
-    LAUNCH(tag, (igemm_kernel<BM, BN, BK, MODE>), dim3(ntm * ntn), dim3(256), smem, s, a, ntm, ntn);
+    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
+           a, ntm, ntn, zeros);
     return 0;
+}
+
+// Row-major outputs whose operands are 8-byte aligned use the swapped-operand kernel (vector epilogue); anything with a
+// transposed (NCHW / V^T) segment keeps the natural orientation, whose lanes own 4 consecutive tokens of one channel.
+bool can_swap(const IGemmArgs& a) {
+    bool swap = (a.Nout % 16 == 0);
+    for (int i = 0; i < a.nseg; ++i)
+        swap = swap && a.seg[i].fmt == SEG_ROW && (a.seg[i].ld % 4 == 0) && (((uintptr_t)a.seg[i].out & 15) == 0);
+    if (a.res) swap = swap && (a.ldres % 4 == 0) && (((uintptr_t)a.res & 7) == 0);
+    if (a.bias) swap = swap && (((uintptr_t)a.bias & 15) == 0);
+    if (a.rowvec) swap = swap && (a.rowvec_ld % 4 == 0) && (((uintptr_t)a.rowvec & 15) == 0);
+    return swap;
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE>
+int launch_cfg(const IGemmArgs& a, hipStream_t s) {
+    if (can_swap(a)) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, true>(a, s);
+    return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, false>(a, s);
 }
 
 template <int MODE>
 int dispatch(const IGemmArgs& a, hipStream_t s) {
     const bool bk64 = (a.Cin % 64) == 0;
-    // Prefer 128x128 tiles; fall back to 64x64 when the big tiling would leave most of the 256 CUs idle
-    // or the N extent is not a multiple of 128 but is of 64 (e.g. 320, 960).
-    const long big = (long)((a.M + 127) / 128) * ((a.Nout + 127) / 128);
-    const bool n_waste = (a.Nout % 128) != 0 && (a.Nout % 128) <= 64 && a.Nout < 1024;
-    const bool small = big < 192 || n_waste;
-    if (bk64) {
-        if (!small) return launch_cfg<128, 128, 64, MODE>(a, s);
-        return launch_cfg<64, 64, 64, MODE>(a, s);
-    } else {
-        if (!small) return launch_cfg<128, 128, 32, MODE>(a, s);
-        return launch_cfg<64, 64, 32, MODE>(a, s);
+    // Tile choice: 256x128 (8 waves) when the grid still over-fills the 256 CUs, 128x128 otherwise, 64x64 for small
+    // problems.  N extents that are not multiples of 128 pay padded columns, so the waste is weighed against tile size.
+    auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Nout + bn - 1) / bn); };
+    auto eff = [&](int bn) { return (double)a.Nout / (double)(((a.Nout + bn - 1) / bn) * bn); };
+    // 256x256 (8 waves, 128x64 per wave): fewest LDS bytes per FLOP -- the limiter of the smaller tiles on this chip
+    // (vector-epilogue variant only: the scalar-epilogue one does not fit the register file at this tile size)
+    if (tiles(256, 256) >= 200 && eff(256) > 0.9 && can_swap(a)) return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s);
+    if (!bk64) {
+        if (tiles(128, 128) >= 192) return launch_cfg<128, 128, 32, 2, 2, 3, MODE>(a, s);
+        return launch_cfg<64, 64, 32, 2, 2, 3, MODE>(a, s);
     }
+    if (tiles(256, 128) >= 400 && eff(128) > 0.8) return launch_cfg<256, 128, 64, 4, 2, 3, MODE>(a, s);
+    if (tiles(128, 128) >= 192 && eff(128) > 0.8) return launch_cfg<128, 128, 64, 2, 4, 4, MODE>(a, s);
+    if (tiles(128, 64) >= 192) return launch_cfg<128, 64, 64, 2, 2, 3, MODE>(a, s);
+    return launch_cfg<64, 64, 64, 2, 2, 3, MODE>(a, s);
 }
 
 }  // namespace
