@@ -14,8 +14,10 @@
 //                    movement) because K rows are fetched from LDS through a bit-2<->bit-3 swapped row
 //                    index; V is supplied transposed ([C][tokens], written that way by the QKV GEMM
 //                    epilogue) so its A-operand is one ds_read_b128 of 8 consecutive keys.
-//   K / V^T tiles (64 keys) are staged global -> VGPR -> LDS, double-buffered; LDS rows are padded to an
-//   odd number of 16-byte slots (bank-conflict-free b128 fragment reads).
+//   K / V^T tiles (64 keys) stream global -> LDS through the asynchronous LDS-DMA (global_load_lds_dwordx4) into a
+//   3-deep ring: two tiles are always in flight, a counted s_waitcnt vmcnt + one raw s_barrier per tile; linear LDS
+//   tiles with an XOR chunk swizzle on the source address and on the fragment read (bank-conflict-free b128 reads).
+//   Contract: the V^T buffer's pad columns [Lk, roundup8(Lk)) must hold finite values (the producer zero-fills).
 #include "ops.h"
 
 namespace {
@@ -24,20 +26,28 @@ __device__ __forceinline__ int krow_perm(int i) {   // swap bits 2 and 3 (identi
     return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
 
+// XOR chunk swizzles of the linear LDS tiles (applied to the staging SOURCE address and to the fragment read; the
+// LDS-DMA destination itself is wave-uniform base + lane*16).  128-byte rows: 2 rows per 256-B bank line -> 3 bits of
+// (row>>1); 192/320-byte rows (12/20 chunks): the row start advances 4 slots mod 16 -> 2 bits of (row>>2).
+template <int ROW_CHUNKS>
+__device__ __forceinline__ int tile_swz(int row) {
+    return ROW_CHUNKS == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
 template <int D>
-__global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
-    constexpr int DK = (D + 15) / 16 * 16;      // QK^T reduction extent (zero padded)
-    constexpr int KS = DK / 16;                 // k-steps of the 32x32x16 MFMA
-    constexpr int DB = (D + 31) / 32;           // 32-row output blocks of O^T
-    constexpr int KLD = DK + 8;                 // K tile row stride (halfs)
-    constexpr int VLD = 64 + 8;                 // V^T tile row stride (halfs)
-    constexpr int KCHUNKS = 64 * (DK / 8);      // 16-B chunks in a K tile
-    constexpr int VCHUNKS = D * 8;              // 16-B chunks in a V^T tile (only rows < D are staged)
-    constexpr int KCH = (KCHUNKS + 255) / 256, VCH = (VCHUNKS + 255) / 256;
+__global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_t* zeros) {
+    constexpr int DP = (D + 31) / 32 * 32;      // padded head dim (zero filled): 64, 64, 96, 160
+    constexpr int KS = DP / 16;                 // k-steps of the 32x32x16 MFMA for QK^T
+    constexpr int DB = DP / 32;                 // 32-row output blocks of O^T
+    constexpr int KCPR = DP / 8;                // 16-B chunks per K-tile row
+    constexpr int PASSES = DP / 32;             // 4-KiB staging passes per tile (K tile = V^T tile = 64*DP halfs)
+    constexpr int NSTAGE = 3;                   // LDS ring depth: 2 tiles in flight
+    constexpr int LPT = 2 * PASSES;             // global_load_lds per lane per tile
+    constexpr int TILE = 64 * DP;               // halfs per K (or V^T) tile
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    half_t* Ks = (half_t*)smem_raw;                 // [2][64][KLD]
-    half_t* Vs = Ks + 2 * 64 * KLD;                 // [2][DB*32][VLD]
+    half_t* Ks = (half_t*)smem_raw;             // [NSTAGE][64][DP]
+    half_t* Vs = Ks + NSTAGE * TILE;            // [NSTAGE][DP][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
@@ -59,56 +69,53 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
             const int d0 = ks * 16 + hi * 8;
             qf[ks] = (d0 < D) ? *(const h8*)(qp + d0) : hzero;
         }
+        // Retire the Q loads HERE: a pending ordinary load at loop entry makes hipcc put s_waitcnt vmcnt(0) in front of
+        // the first MFMA of every iteration, which would drain the LDS-DMA ring each tile.
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
 
     const int kb = (a.kvB == 1) ? 0 : b;     // K/V shared by every batch (broadcast encoder states)
     const half_t* Kbase = (const half_t*)a.K + (size_t)kb * Lk * a.ldk + (size_t)h * D;
     const half_t* Vbase = (const half_t*)a.Vt + ((size_t)kb * a.heads + h) * D * (size_t)a.Lkpad;
 
-    h8 kreg[KCH], vreg[VCH];
-    auto gload = [&](int t) {
+    // ---- per-lane staging coordinates (constant over tiles) ----
+    int k_row[PASSES], v_key[PASSES];
+    size_t k_off[PASSES], v_off[PASSES];
+    bool k_dok[PASSES], v_dok[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int ci = (i * 4 + wave) * 64 + lane;            // chunk index inside the tile
+        const int kr = ci / KCPR, kp = ci - kr * KCPR;
+        const int ksrc = kp ^ tile_swz<KCPR>(kr);
+        k_row[i] = kr;
+        k_dok[i] = ksrc * 8 < D;
+        k_off[i] = (size_t)kr * a.ldk + ksrc * 8;
+        const int vr = ci >> 3, vp = ci & 7;
+        const int vsrc = vp ^ tile_swz<8>(vr);
+        v_key[i] = vsrc * 8;
+        v_dok[i] = vr < D;
+        v_off[i] = (size_t)vr * a.Lkpad + vsrc * 8;
+    }
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+    auto stage = [&](int t, int slot) {
         const int kt0 = t * 64;
+        half_t* Kb = Ks + slot * TILE;
+        half_t* Vb = Vs + slot * TILE;
 #pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / (DK / 8), ch = idx - row * (DK / 8);
-            const int key = kt0 + row;
-            const bool ok = (idx < KCHUNKS) && (key < Lk) && (ch * 8 < D);
-            kreg[i] = ok ? *(const h8*)(Kbase + (size_t)key * a.ldk + ch * 8) : hzero;
-        }
-        const bool tail = (kt0 + 64 > Lk);
-#pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx >> 3, ch = idx & 7;
-            const bool ok = (idx < VCHUNKS) && (kt0 + ch * 8 < Lk);
-            h8 v = ok ? *(const h8*)(Vbase + (size_t)row * a.Lkpad + kt0 + ch * 8) : hzero;
-            if (tail && ok) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (kt0 + ch * 8 + j >= Lk) v[j] = (half_t)0.f;
-            }
-            vreg[i] = v;
-        }
-    };
-    auto lds_store = [&](int buf) {
-        half_t* Kb = Ks + buf * 64 * KLD;
-        half_t* Vb = Vs + buf * DB * 32 * VLD;
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < KCHUNKS) {
-                const int row = idx / (DK / 8), ch = idx - row * (DK / 8);
-                *(h8*)(Kb + row * KLD + ch * 8) = kreg[i];
-            }
+        for (int i = 0; i < PASSES; ++i) {
+            const bool ok = k_dok[i] && (kt0 + k_row[i] < Lk);
+            const half_t* src = ok ? (Kbase + (size_t)kt0 * a.ldk + k_off[i]) : zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Kb + (i * 4 + wave) * 512), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < VCHUNKS) {
-                const int row = idx >> 3, ch = idx & 7;
-                *(h8*)(Vb + row * VLD + ch * 8) = vreg[i];
-            }
+        for (int i = 0; i < PASSES; ++i) {
+            // whole 8-key chunks at or beyond Lk come from the zero page; the chunk straddling Lk relies on the
+            // V^T pad columns being finite (the producer zero-fills them) -- their probabilities are exactly 0
+            const bool ok = v_dok[i] && (kt0 + v_key[i] < Lk);
+            const half_t* src = ok ? (Vbase + kt0 + v_off[i]) : zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vb + (i * 4 + wave) * 512), 16, 0, 0);
         }
     };
 
@@ -120,27 +127,43 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
     float m_run = -1e30f, l_run = 0.f;
 
     const int ntiles = (Lk + 63) / 64;
-    gload(0);
-    lds_store(0);
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t)
+        if (t < ntiles) stage(t, t);
 
+    // fragment read offsets (halfs) inside a tile
     const int krow = krow_perm(lq);
+    int k_rd[2], k_sw[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) { const int r = mb * 32 + krow; k_rd[mb] = r * DP; k_sw[mb] = tile_swz<KCPR>(r); }
+    int v_rd[DB], v_sw[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { const int r = db * 32 + lq; v_rd[db] = r * 64; v_sw[db] = tile_swz<8>(r); }
+
     int cur = 0;
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) gload(t + 1);
-        const half_t* Kb = Ks + cur * 64 * KLD;
-        const half_t* Vb = Vs + cur * DB * 32 * VLD;
+        if (t + NSTAGE - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // tile t visible to every wave; the slot of tile t-1 is free
+        if (t + NSTAGE - 1 < ntiles) {
+            int ns = cur + NSTAGE - 1;
+            if (ns >= NSTAGE) ns -= NSTAGE;
+            stage(t + NSTAGE - 1, ns);
+        }
+        const half_t* Kb = Ks + cur * TILE;
+        const half_t* Vb = Vs + cur * TILE;
 
         // ---- S^T = K . Q^T  (two 32-key blocks) ----
         f16v sacc[2];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[mb][r] = 0.f;
-            const half_t* kp = Kb + (mb * 32 + krow) * KLD + hi * 8;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const h8 kf = *(const h8*)(kp + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const h8 kf = *(const h8*)(Kb + k_rd[mb] + (((ks * 2 + hi) ^ k_sw[mb]) << 3));
                 sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[mb], 0, 0, 0);
             }
         }
@@ -163,40 +186,40 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * c);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        // rescale only when some query's running maximum moved (exact: alpha == 1 otherwise); wave-uniform branch
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            m_run = m_new;
+        }
         float psum = 0.f;
         h8 pf[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[mb][r] * c - m_new);
+                const float p = __builtin_amdgcn_exp2f(sacc[mb][r] * c - m_run);
                 psum += p;
                 pf[mb][r >> 3][r & 7] = (half_t)p;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const half_t* vp = Vb + lq * VLD + mb * 32 + s2 * 16 + hi * 8;
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const h8 vf = *(const h8*)(vp + db * 32 * VLD);
+                    const h8 vf = *(const h8*)(Vb + v_rd[db] + (((mb * 4 + s2 * 2 + hi) ^ v_sw[db]) << 3));
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[mb][s2], o[db], 0, 0, 0);
                 }
             }
-
-        if (t + 1 < ntiles) lds_store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
     }
 
     // ---- finalize: O[q][d] = O^T[d][q] / l ----
@@ -220,18 +243,30 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
     }
 }
 
+const half_t* attn_zero_page() {
+    static half_t* z = nullptr;
+    if (!z) {
+        if (hipMalloc((void**)&z, 4096) != hipSuccess) return nullptr;
+        hipMemset(z, 0, 4096);
+    }
+    return z;
+}
+
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
-    constexpr int DK = (D + 15) / 16 * 16, DB = (D + 31) / 32;
-    constexpr size_t smem = (size_t)2 * (64 * (DK + 8) + DB * 32 * (64 + 8)) * sizeof(half_t);
+    constexpr int DP = (D + 31) / 32 * 32;
+    constexpr size_t smem = (size_t)3 * 2 * 64 * DP * sizeof(half_t);
     static bool attr_done = false;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
+    const half_t* zeros = attn_zero_page();
+    CTRL_CHECK(zeros != nullptr, "flash_attn: could not allocate the zero page");
     dim3 grid((a.Lq + 127) / 128, a.heads, a.B);
     PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
-    LAUNCH("flash_attn", (flash_attn_kernel<D>), grid, dim3(256), smem, s, a);
+    prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
+    LAUNCH("flash_attn", (flash_attn_kernel<D>), grid, dim3(256), smem, s, a, zeros);
     return 0;
 }
 

@@ -37,6 +37,7 @@ void prof_after(hipStream_t s);
 extern bool g_prof_on;
 extern double g_prof_flops, g_prof_bytes;     // algorithmic work of the NEXT launch (set by the op, consumed by prof_before)
 #define PROF_WORK(flops, bytes) do { if (g_prof_on) { g_prof_flops = (double)(flops); g_prof_bytes = (double)(bytes); } } while (0)
+void prof_detail(const char* fmt, ...);       // optional per-launch shape note (dumped when CTRL_PROF_DUMP=<file> is set)
 
 #define LAUNCH(tag, kern, grid, block, shmem, stream, ...)                        \
     do {                                                                          \

@@ -359,6 +359,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(zeros != nullptr, "igemm: could not allocate the zero page");
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
     PROF_WORK(2.0 * a.M * a.Nout * a.Ktot, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
+    prof_detail("M%d N%d K%d taps%d tile%dx%dx%d swap%d geglu%d", a.M, a.Nout, a.Ktot, a.taps, BM, BN, BK, (int)SWAP, a.geglu);
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
     LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
            a, ntm, ntn, zeros);

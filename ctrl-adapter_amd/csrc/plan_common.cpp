@@ -137,6 +137,7 @@ static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, con
     const int Lpad = (L + 63) / 64 * 64;
     half_t* qk = cx.h((size_t)M * 2 * Ci);
     half_t* vt = cx.h((size_t)B * Ci * Lpad);
+    if (L % 8) RUN(cx, op_fill_zero(vt, (size_t)B * Ci * Lpad * sizeof(half_t), cx.s));   // attention contract: finite pad columns
     IGemmArgs g = {};
     g.A = xn; g.lda = dim; g.mode = IG_ROWS; g.Cin = dim; g.taps = 1;
     g.W = w.qkv.w; g.M = M; g.Nout = 3 * Ci; g.Ktot = dim; g.scale = 1.f;
@@ -174,6 +175,7 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const half_t*
     const int Mk = e.batch * e.Lk;
     half_t* k = cx.h((size_t)Mk * Ci);
     half_t* vt = cx.h((size_t)e.batch * Ci * Lkpad);
+    if (e.Lk % 8) RUN(cx, op_fill_zero(vt, (size_t)e.batch * Ci * Lkpad * sizeof(half_t), cx.s));   // finite pad columns
     IGemmArgs g = {};
     g.A = e.h16; g.lda = e.cross; g.mode = IG_ROWS; g.Cin = e.cross; g.taps = 1;
     g.W = w.kv.w; g.M = Mk; g.Nout = 2 * Ci; g.Ktot = e.cross; g.scale = 1.f;

@@ -5,6 +5,9 @@
 #include <map>
 #include <vector>
 #include <cstring>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
 
 static thread_local std::string g_err;
 void ctrl_set_error(const std::string& s) { g_err = s; }
@@ -12,17 +15,24 @@ void ctrl_set_error(const std::string& s) { g_err = s; }
 bool g_prof_on = false;
 double g_prof_flops = 0, g_prof_bytes = 0;
 namespace {
-struct Rec { const char* tag; hipEvent_t e0, e1; double flops, bytes; };
+struct Rec { const char* tag; hipEvent_t e0, e1; double flops, bytes; std::string detail; };
+std::string g_detail;
 struct Sum { double ms = 0, flops = 0, bytes = 0; int n = 0; };
 std::vector<Rec> g_recs;
 std::vector<std::pair<std::string, Sum>> g_summary;
 }
 void prof_before(const char* tag, hipStream_t s) {
-    Rec r; r.tag = tag; r.flops = g_prof_flops; r.bytes = g_prof_bytes;
+    Rec r; r.tag = tag; r.flops = g_prof_flops; r.bytes = g_prof_bytes; r.detail = g_detail; g_detail.clear();
     g_prof_flops = g_prof_bytes = 0;
     hipEventCreate(&r.e0); hipEventCreate(&r.e1);
     hipEventRecord(r.e0, s);
     g_recs.push_back(r);
+}
+void prof_detail(const char* fmt, ...) {
+    if (!g_prof_on) return;
+    char buf[256];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_detail = buf;
 }
 void prof_after(hipStream_t s) { hipEventRecord(g_recs.back().e1, s); }
 
@@ -34,13 +44,17 @@ int ctrl_prof_end(void) {
     g_prof_on = false;
     HIP_TRY(hipDeviceSynchronize());
     std::map<std::string, Sum> acc;
+    FILE* dump = nullptr;
+    if (const char* path = getenv("CTRL_PROF_DUMP")) dump = fopen(path, "w");
     for (auto& r : g_recs) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (dump) fprintf(dump, "%s\t%.4f\t%.1f\t%s\n", r.tag, ms, r.flops > 0 ? r.flops / (ms * 1e-3) / 1e12 : 0.0, r.detail.c_str());
         auto& a = acc[r.tag];
         a.ms += ms; a.n += 1; a.flops += r.flops; a.bytes += r.bytes;
         hipEventDestroy(r.e0); hipEventDestroy(r.e1);
     }
+    if (dump) fclose(dump);
     g_recs.clear();
     g_summary.assign(acc.begin(), acc.end());
     return 0;

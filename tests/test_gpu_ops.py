@@ -153,7 +153,8 @@ def test_flash_attn(ops, gpu, D, heads, Lq, Lk):
         k[0, Lk - 70] = q[0, 5] * 4.0
     ref = _attn_ref(q, k, v, heads)
     Lkpad = (Lk + 63) // 64 * 64
-    vt = torch.full((B, Cc, Lkpad), float("nan"), dtype=torch.float16)   # pad columns must be ignored
+    vt = torch.full((B, Cc, Lkpad), float("nan"), dtype=torch.float16)   # pad columns beyond roundup8(Lk) are never read
+    vt[:, :, :(Lk + 7) // 8 * 8] = 0                                      # contract: [Lk, roundup8(Lk)) finite
     vt[:, :, :Lk] = v.half().permute(0, 2, 1)
     out = ops.flash_attn(q.half().reshape(B * Lq, Cc).to(gpu), Cc, k.half().reshape(B * Lk, Cc).to(gpu), Cc,
                          vt.to(gpu), Lkpad, B, heads, D, Lq, Lk)
