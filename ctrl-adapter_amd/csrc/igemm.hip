@@ -21,6 +21,7 @@
 // fuses bias, per-image channel vector (time embedding), GEGLU, residual add, scale and the output
 // layout (row-major slice, or transposed [img][C][tokens] for NCHW results / the V^T attention operand).
 #include "ops.h"
+#include <cstdlib>
 
 namespace {
 
@@ -173,34 +174,91 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) { const int r = wn * WN + ni * 16 + frow; b_rd[ni] = r * BK; b_sw[ni] = chunk_swz<BK>(r); }
 
-    int cur = 0;                                    // ring slot of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed: allow the D-1 younger tiles to stay outstanding (tail: drain)
-        if (kt + D - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();               // every wave's part of tile kt is visible; slot of tile kt-1 is free
-        if (kt + D < nk) {
-            int nb = cur + D;
-            if (nb >= NSTAGE) nb -= NSTAGE;
-            stage(kt + D, nb);                      // streams into LDS under the MFMAs below
+    // One k-tile = LOAD (every fragment read of the tile issued back to back into distinct registers -- left alone,
+    // hipcc re-uses one operand register and serialises {ds_read, lgkmcnt(0), 4 MFMAs} per fragment) + COMPUTE (MFMAs).
+    constexpr int KK = BK / 32;
+    h8 af[KK][MI], bf[KK][NI];
+    auto load_frags = [&](int slot) {
+        const half_t* Ab = As + slot * BM * BK;
+        const half_t* Bb = Bs + slot * BN * BK;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bf[kk][ni] = *(const h8*)(Bb + b_rd[ni] + (((kk * 4 + fch) ^ b_sw[ni]) << 3));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[kk][mi] = *(const h8*)(Ab + a_rd[mi] + (((kk * 4 + fch) ^ a_sw[mi]) << 3));
         }
-        const half_t* Ab = As + cur * BM * BK;
-        const half_t* Bb = Bs + cur * BN * BK;
+    };
+    auto compute = [&]() {
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            h8 af[MI], bf[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[mi] = *(const h8*)(Ab + a_rd[mi] + (((kk * 4 + fch) ^ a_sw[mi]) << 3));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const h8*)(Bb + b_rd[ni] + (((kk * 4 + fch) ^ b_sw[ni]) << 3));
+        for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][ni], af[kk][mi], acc[mi][ni], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
         }
-        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+    };
+    // wait until this wave's LDS-DMA share of tile t has landed, leaving the D-1 younger tiles in flight
+    auto wait_tile = [&](int t) {
+        if (t + D - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto slot_of = [&](int t) { return t % NSTAGE; };
+
+    if constexpr (NW == 8 && (BM / WAVES_M) * (BN / WAVES_N) >= 128 * 64) {
+        // (only for 128x64 per-wave tiles: with 64x64 wave tiles the LOAD phase outlasts the MFMAs and staggering loses)
+        // Two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD) run half a tile apart: in every barrier
+        // interval one group issues its fragment reads + LDS-DMA while the other one issues MFMAs, so the LDS pipe and
+        // the matrix pipe are busy at the same time instead of alternating.
+        //   interval 2k   : group 0 LOAD(k)      group 1 COMPUTE(k-1)
+        //   interval 2k+1 : group 0 COMPUTE(k)   group 1 LOAD(k)
+        // Tile k is complete (every wave waited for its own share) before the barrier that opens interval 2k; its ring
+        // slot is re-filled from interval 2k+2 on (tile k+NSTAGE-1 is issued during LOAD(k)... of the NEXT tile).
+        const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;
+        if (grp == 0) {
+            for (int k = 0; k < nk; ++k) {
+                wait_tile(k);
+                __builtin_amdgcn_s_barrier();                     // interval 2k
+                if (k + D < nk) stage(k + D, slot_of(k + D));
+                load_frags(slot_of(k));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                     // interval 2k+1
+                __builtin_amdgcn_s_setprio(1);
+                compute();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();                         // pairs with group 1's last barrier
+        } else {
+            wait_tile(0);
+            __builtin_amdgcn_s_barrier();                         // interval 0 (group 0 loads tile 0)
+            for (int k = 0; k < nk; ++k) {
+                __builtin_amdgcn_s_barrier();                     // interval 2k+1
+                if (k + D < nk) stage(k + D, slot_of(k + D));
+                load_frags(slot_of(k));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < nk) wait_tile(k + 1);
+                __builtin_amdgcn_s_barrier();                     // interval 2k+2
+                __builtin_amdgcn_s_setprio(1);
+                compute();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_tile(kt);
+            __builtin_amdgcn_s_barrier();               // every wave's part of tile kt is visible; slot of tile kt-1 is free
+            if (kt + D < nk) stage(kt + D, slot_of(kt + D));  // streams into LDS under the MFMAs below
+            load_frags(slot_of(kt));
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---------------- epilogue ----------------
@@ -393,6 +451,8 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     auto eff = [&](int bn) { return (double)a.Nout / (double)(((a.Nout + bn - 1) / bn) * bn); };
     // 256x256 (8 waves, 128x64 per wave): fewest LDS bytes per FLOP -- the limiter of the smaller tiles on this chip
     // (vector-epilogue variant only: the scalar-epilogue one does not fit the register file at this tile size)
+    if (getenv("CTRL_IGEMM_CFG") && atoi(getenv("CTRL_IGEMM_CFG")) == 1 && tiles(128, 256) >= 200 && eff(256) > 0.9 && can_swap(a))
+        return launch_cfg2<128, 256, 32, 2, 2, 3, MODE, true>(a, s);     // experiment: 4 waves x (64x128), 2 blocks/CU
     if (tiles(256, 256) >= 200 && eff(256) > 0.9 && can_swap(a)) return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s);
     if (!bk64) {
         if (tiles(128, 128) >= 192) return launch_cfg<128, 128, 32, 2, 2, 3, MODE>(a, s);
