@@ -153,7 +153,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
         const half_t* Kb = Ks + cur * TILE;
         const half_t* Vb = Vs + cur * TILE;
 
-        // ---- S^T = K . Q^T  (two 32-key blocks) ----
+        // ---- S^T = K . Q^T  (two 32-key blocks); all K and V^T fragment reads of the tile are issued up front so the
+        //      LDS latency is paid once (K) or hidden under the softmax (V^T) ----
+        h8 kfr[KS][2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) kfr[ks][mb] = *(const h8*)(Kb + k_rd[mb] + (((ks * 2 + hi) ^ k_sw[mb]) << 3));
+        h8 vfr[4][DB];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) vfr[c4][db] = *(const h8*)(Vb + v_rd[db] + (((c4 * 2 + hi) ^ v_sw[db]) << 3));
+        __builtin_amdgcn_sched_barrier(0);
         f16v sacc[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -162,10 +174,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const h8 kf = *(const h8*)(Kb + k_rd[mb] + (((ks * 2 + hi) ^ k_sw[mb]) << 3));
-                sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[mb], 0, 0, 0);
-            }
+            for (int mb = 0; mb < 2; ++mb)
+                sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[ks][mb], qf[ks], sacc[mb], 0, 0, 0);
         }
         // register r of block mb holds key  kt0 + 32*mb + 16*(r>>3) + 8*hi + (r&7)  (see krow_perm)
         const int kt0 = t * 64;
@@ -214,10 +224,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const h8 vf = *(const h8*)(Vb + v_rd[db] + (((mb * 4 + s2 * 2 + hi) ^ v_sw[db]) << 3));
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[mb][s2], o[db], 0, 0, 0);
-                }
+                for (int db = 0; db < DB; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr[mb * 2 + s2][db], pf[mb][s2], o[db], 0, 0, 0);
             }
         cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
     }
