@@ -12,7 +12,8 @@
 
 namespace {
 
-// x [imgs][rows][C]; grid (chunks, imgs); each thread owns an 8-channel chunk and strides over rows.
+// x [imgs][rows][C]; grid (chunks, imgs); each thread owns an 8-channel chunk and strides over rows, four 16-byte
+// loads in flight per thread (these kernels are pure HBM streaming: memory-level parallelism is what matters).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats,
                                                        int rows, int C, int G, int rows_per_block) {
     extern __shared__ float sh[];   // [2*C]: per-channel sum, sumsq
@@ -30,7 +31,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
     if (tr < rpi) {
         const half_t* xp = x + ((size_t)img * rows) * C + tc * 8;
-        for (int r = r0 + tr; r < r1; r += rpi) {
+        int r = r0 + tr;
+        for (; r + 3 * rpi < r1; r += 4 * rpi) {
+            h8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const h8*)(xp + (size_t)(r + u * rpi) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; ss[j] += f * f; }
+        }
+        for (; r < r1; r += rpi) {
             const h8 v = *(const h8*)(xp + (size_t)r * C);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
@@ -51,38 +62,56 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     }
 }
 
+// same decomposition as the statistics pass: a thread folds mean / rstd / gamma / beta of its 8 channels into one
+// (scale, shift) pair each, once, then streams its rows: y = x*scale + shift (optional SiLU)
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        half_t* __restrict__ y, int rows, int C, int G, float eps,
-                                                       int silu, size_t total_chunks) {
+                                                       int silu, int rows_per_block) {
+    const int tid = threadIdx.x;
     const int lpr = C >> 3;
+    const int rpi = 256 / lpr;
+    const int tr = tid / lpr, tc = tid - tr * lpr;
+    if (tr >= rpi) return;
+    const int img = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
     const int cg = C / G;
     const float inv_cnt = 1.0f / ((float)rows * (float)cg);
-    for (size_t ch = (size_t)blockIdx.x * 256 + threadIdx.x; ch < total_chunks; ch += (size_t)gridDim.x * 256) {
-        const size_t row = ch / lpr;
-        const int c0 = (int)(ch - row * lpr) * 8;
-        const int img = (int)(row / rows);
-        const h8 v = *(const h8*)(x + row * C + c0);
+    float sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = tc * 8 + j;
+        const int g = c / cg;
+        const float s = stats[((size_t)img * G + g) * 2], ss = stats[((size_t)img * G + g) * 2 + 1];
+        const float mean = s * inv_cnt;
+        const float var = fmaxf(ss * inv_cnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        sc[j] = rstd * gamma[c];
+        sf[j] = beta[c] - mean * sc[j];
+    }
+    const size_t base = ((size_t)img * rows) * C + tc * 8;
+    const half_t* xp = x + base;
+    half_t* yp = y + base;
+    auto xform = [&](const h8& v) {
         h8 o;
-        int gprev = -1;
-        float mean = 0.f, rstd = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j;
-            const int g = c / cg;
-            if (g != gprev) {
-                const float s = stats[((size_t)img * G + g) * 2], ss = stats[((size_t)img * G + g) * 2 + 1];
-                mean = s * inv_cnt;
-                const float var = fmaxf(ss * inv_cnt - mean * mean, 0.f);
-                rstd = rsqrtf(var + eps);
-                gprev = g;
-            }
-            float f = ((float)v[j] - mean) * rstd * gamma[c] + beta[c];
+            float f = (float)v[j] * sc[j] + sf[j];
             if (silu) f = silu_f(f);
             o[j] = (half_t)f;
         }
-        *(h8*)(y + row * C + c0) = o;
+        return o;
+    };
+    int r = r0 + tr;
+    for (; r + 3 * rpi < r1; r += 4 * rpi) {
+        h8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const h8*)(xp + (size_t)(r + u * rpi) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(h8*)(yp + (size_t)(r + u * rpi) * C) = xform(v[u]);
     }
+    for (; r < r1; r += rpi) *(h8*)(yp + (size_t)r * C) = xform(*(const h8*)(xp + (size_t)r * C));
 }
 
 // one wavefront per row; C <= 64*8*NCH
@@ -134,14 +163,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 
 }  // namespace
 
+static int gn_rows_per_block(int imgs, int rows_per_img, int C) {
+    // aim for ~2048 workgroups in total (8 per CU) with at least a few iterations of the 4x-unrolled loop each
+    const int rpi = 256 / (C / 8);
+    int chunks = (2048 + imgs - 1) / imgs;
+    int rpb = (rows_per_img + chunks - 1) / chunks;
+    if (rpb < 8 * rpi) rpb = 8 * rpi;
+    rpb = ((rpb + rpi - 1) / rpi) * rpi;
+    return rpb;
+}
+
 int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_stats: C must be a multiple of 8 and of G, <= 2048");
     CTRL_CHECK(G <= 256, "gn_stats: G too large");
-    // ~64 workgroups per image keep atomics few while filling the chip for batch >= 4
-    int rows_per_block = (rows_per_img + 63) / 64;
-    const int rpi = 256 / (C / 8);
-    rows_per_block = ((rows_per_block + rpi - 1) / rpi) * rpi;
-    if (rows_per_block < rpi) rows_per_block = rpi;
+    const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
     PROF_WORK(0, 2.0 * imgs * rows_per_img * C);
     LAUNCH("gn_stats", gn_stats_kernel, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
@@ -151,13 +186,12 @@ int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C
 
 int op_gn_apply(const half_t* x, const float* stats, const float* gamma, const float* beta, half_t* y,
                 int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s) {
-    CTRL_CHECK(C % 8 == 0 && C % G == 0, "gn_apply: C must be a multiple of 8 and of G");
-    const size_t total = (size_t)imgs * rows_per_img * (C / 8);
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_apply: C must be a multiple of 8 and of G, <= 2048");
+    const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C);
+    const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
     PROF_WORK(0, 4.0 * imgs * rows_per_img * C);
-    LAUNCH("gn_apply", gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-           x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, total);
+    LAUNCH("gn_apply", gn_apply_kernel, dim3(chunks, imgs), dim3(256), 0, s,
+           x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block);
     return 0;
 }
 
