@@ -42,11 +42,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int CPR = BK / 8;              // 16-B chunks per tile row
     constexpr int RPW = 64 / CPR;            // rows written by one wave-wide global_load_lds (1 KiB)
-    constexpr int APASS = BM / (NW * RPW), BPASS = BN / (NW * RPW);
-    static_assert(APASS >= 1 && BPASS >= 1, "tile too small for the workgroup");
+    constexpr int APASS = BM / (NW * RPW);
+    constexpr int BPASS = (BN + NW * RPW - 1) / (NW * RPW);       // BN = 320: the last pass is half empty ...
+    constexpr int BNP = BPASS * NW * RPW;                          // ... so the LDS B tile is padded to whole passes
+    static_assert(APASS >= 1 && BM % (NW * RPW) == 0, "tile too small for the workgroup");
+    static_assert(WN % 16 == 0 && WM % 16 == 0, "wave tile must be a multiple of the 16x16 fragment");
 
     half_t* As = (half_t*)smem_raw;                  // [NSTAGE][BM][BK]
-    half_t* Bs = As + NSTAGE * BM * BK;              // [NSTAGE][BN][BK]
+    half_t* Bs = As + NSTAGE * BM * BK;              // [NSTAGE][BNP][BK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
         const int trow = (i * NW + wave) * RPW + lrow;
         b_c8[i] = (lpos ^ chunk_swz<BK>(trow)) * 8;
         const int n = n0 + trow;
-        b_ok[i] = n < a.Nout;
+        b_ok[i] = (n < a.Nout) && (trow < BN);
         b_off[i] = (size_t)(b_ok[i] ? n : 0) * a.Ktot;
     }
 
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
         int ky = 0, kx = 0;
         if (MODE == IG_CONV2D && a.taps == 9) { ky = tap / 3; kx = tap - 3 * ky; }
         half_t* Ab = As + buf * BM * BK;
-        half_t* Bb = Bs + buf * BN * BK;
+        half_t* Bb = Bs + buf * BNP * BK;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             bool ok = a_ok[i];
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
     h8 af[KK][MI], bf[KK][NI];
     auto load_frags = [&](int slot) {
         const half_t* Ab = As + slot * BM * BK;
-        const half_t* Bb = Bs + slot * BN * BK;
+        const half_t* Bb = Bs + slot * BNP * BK;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -406,7 +409,9 @@ const half_t* zero_page() {
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
 int launch_cfg2(const IGemmArgs& a, hipStream_t s) {
-    constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(half_t);
+    constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
+    constexpr int BNP = (BN + PASSROWS - 1) / PASSROWS * PASSROWS;
+    constexpr size_t smem = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
     static bool attr_done = false;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>,
@@ -454,6 +459,8 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     if (getenv("CTRL_IGEMM_CFG") && atoi(getenv("CTRL_IGEMM_CFG")) == 1 && tiles(128, 256) >= 200 && eff(256) > 0.9 && can_swap(a))
         return launch_cfg2<128, 256, 32, 2, 2, 3, MODE, true>(a, s);     // experiment: 4 waves x (64x128), 2 blocks/CU
     if (tiles(256, 256) >= 200 && eff(256) > 0.9 && can_swap(a)) return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s);
+    // N = 320 / 640 / 960 / 1280 / 1920 / 3840 (every conv and QKV width of the path): 256x320 tile, 128x80 per wave
+    if (a.Nout % 320 == 0 && tiles(256, 320) >= 160 && can_swap(a) && !a.geglu) return launch_cfg2<256, 320, 32, 2, 4, 4, MODE, true>(a, s);
     if (!bk64) {
         if (tiles(128, 128) >= 192) return launch_cfg<128, 128, 32, 2, 2, 3, MODE>(a, s);
         return launch_cfg<64, 64, 32, 2, 2, 3, MODE>(a, s);

@@ -32,12 +32,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     if (tr < rpi) {
         const half_t* xp = x + ((size_t)img * rows) * C + tc * 8;
         int r = r0 + tr;
-        for (; r + 3 * rpi < r1; r += 4 * rpi) {
-            h8 v[4];
+        for (; r + 7 * rpi < r1; r += 8 * rpi) {
+            h8 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const h8*)(xp + (size_t)(r + u * rpi) * C);
+            for (int u = 0; u < 8; ++u) v[u] = *(const h8*)(xp + (size_t)(r + u * rpi) * C);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; ss[j] += f * f; }
         }
@@ -163,10 +163,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 
 }  // namespace
 
-static int gn_rows_per_block(int imgs, int rows_per_img, int C) {
-    // aim for ~2048 workgroups in total (8 per CU) with at least a few iterations of the 4x-unrolled loop each
+static int gn_rows_per_block(int imgs, int rows_per_img, int C, int target_blocks) {
+    // aim for ~target_blocks workgroups in total with at least a few iterations of the 4x-unrolled loop each
     const int rpi = 256 / (C / 8);
-    int chunks = (2048 + imgs - 1) / imgs;
+    int chunks = (target_blocks + imgs - 1) / imgs;
     int rpb = (rows_per_img + chunks - 1) / chunks;
     if (rpb < 8 * rpi) rpb = 8 * rpi;
     rpb = ((rpb + rpi - 1) / rpi) * rpi;
@@ -176,7 +176,8 @@ static int gn_rows_per_block(int imgs, int rows_per_img, int C) {
 int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_stats: C must be a multiple of 8 and of G, <= 2048");
     CTRL_CHECK(G <= 256, "gn_stats: G too large");
-    const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C);
+    // fewer, fatter workgroups than the apply pass: every workgroup ends with 2*G global atomics on the same 2*G words
+    const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 768);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
     PROF_WORK(0, 2.0 * imgs * rows_per_img * C);
     LAUNCH("gn_stats", gn_stats_kernel, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
@@ -187,7 +188,7 @@ int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C
 int op_gn_apply(const half_t* x, const float* stats, const float* gamma, const float* beta, half_t* y,
                 int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s) {
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_apply: C must be a multiple of 8 and of G, <= 2048");
-    const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C);
+    const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 2048);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
     PROF_WORK(0, 4.0 * imgs * rows_per_img * C);
     LAUNCH("gn_apply", gn_apply_kernel, dim3(chunks, imgs), dim3(256), 0, s,
