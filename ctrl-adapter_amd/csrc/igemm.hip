@@ -266,36 +266,35 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
 
     // ---------------- epilogue ----------------
     if constexpr (SWAP) {
-        // Operands were swapped (D = W.A^T): the lane owns ONE output row m = lane&15 and FOUR consecutive output
-        // columns n = (lane>>4)*4 + i, so bias / residual / result move as 8- or 16-byte vectors (row-major outputs).
+        // Operands were swapped (D = W.A^T): a lane owns ONE output row (lane&15) and FOUR consecutive columns
+        // (lane>>4)*4+i of each 16x16 fragment.  Bias / time vector / GEGLU / SiLU are applied in registers; the
+        // 16-row slab of the wave tile then goes through a wave-private LDS staging area (the k-loop ring is dead) and
+        // leaves as whole 16-byte pieces of full output rows: residual reads and result writes are coalesced 128-byte+
+        // row segments instead of 8-byte fragments scattered over 16 rows.
+        __syncthreads();                                   // every wave is done with the ring
+        constexpr int OWMAX = WN;                          // output columns of the wave tile (half of it with GEGLU)
+        constexpr int SLD = OWMAX + 4;                     // floats; +16 B keeps the b128 accesses conflict-light
+        float* stg = (float*)smem_raw + wave * (16 * SLD);
         const int erow = lane & 15, ecol = (lane >> 4) * 4;
+        const int OW = a.geglu ? WN / 2 : WN;
+        const int OWC = OW >> 3;                           // 8-column chunks per row
+        const int wcol0 = a.geglu ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN);     // first output column of the wave tile
+        const int nout_eff = a.geglu ? (a.Nout >> 1) : a.Nout;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            if (a.geglu && (ni & 1)) continue;
-            const int pcb = n0 + wn * WN + ni * 16;
-            if (pcb >= a.Nout) continue;
-            const int pcol = pcb + ecol;
-            const int ocol = a.geglu ? ((pcb >> 5) << 4) + ecol : pcol;
-            const int ocb = ocol - ecol;
-            int si = 0;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row_w = m0 + wm * WM + mi * 16 + erow;
 #pragma unroll
-            for (int k = 1; k < 3; ++k)
-                if (k < a.nseg && ocb >= a.seg[k].col_begin) si = k;
-            const IGemmSeg sg = a.seg[si];
-            const int scol = ocol - sg.col_begin;
-            f4 bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) {
-                bh = *(const f4*)(a.bias + pcol);
-                if (a.geglu) bg = *(const f4*)(a.bias + pcol + 16);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int row = m0 + wm * WM + mi * 16 + erow;
-                if (row >= a.M) continue;
-                f4 x = acc[mi][ni] + bh;
-                if (a.rowvec) x += *(const f4*)(a.rowvec + (size_t)(row / a.rows_per_img) * a.rowvec_ld + pcol);
+            for (int ni = 0; ni < NI; ++ni) {
+                if (a.geglu && (ni & 1)) continue;
+                const int pcb = n0 + wn * WN + ni * 16;
+                if (pcb >= a.Nout) continue;
+                const int pcol = pcb + ecol;
+                f4 x = acc[mi][ni];
+                if (a.bias) x += *(const f4*)(a.bias + pcol);
+                if (a.rowvec && row_w < a.M) x += *(const f4*)(a.rowvec + (size_t)(row_w / a.rows_per_img) * a.rowvec_ld + pcol);
                 if (a.geglu) {
-                    const f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)] + bg;
+                    f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)];
+                    if (a.bias) g += *(const f4*)(a.bias + pcol + 16);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
                 }
@@ -303,24 +302,47 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
 #pragma unroll
                     for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
                 }
+                const int lcol = (a.geglu ? (ni >> 1) * 16 : ni * 16) + ecol;
+                *(f4*)(stg + erow * SLD + lcol) = x;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are in order; pin compiler order
+            for (int idx = lane; idx < 16 * OWC; idx += 64) {
+                const int r = idx / OWC, c8 = idx - r * OWC;
+                const int row = m0 + wm * WM + mi * 16 + r;
+                const int ocol = wcol0 + c8 * 8;
+                if (row >= a.M || ocol >= nout_eff) continue;
+                const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
+                float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if (Rptr) {
-                    const h4 r = *(const h4*)(Rptr + (size_t)row * a.ldres + ocol);
+                    const h8 rr = *(const h8*)(Rptr + (size_t)row * a.ldres + ocol);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) x[i] += (float)r[i];
+                    for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
                 }
-                x *= a.scale;
-                const size_t o = (size_t)row * sg.ld + scol;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] *= a.scale;
+                int si = 0;
+#pragma unroll
+                for (int k = 1; k < 3; ++k)
+                    if (k < a.nseg && ocol >= a.seg[k].col_begin) si = k;
+                const IGemmSeg sg = a.seg[si];
+                const size_t o = (size_t)row * sg.ld + (ocol - sg.col_begin);
                 if (sg.dtype == DT_F16) {
-                    h4 pk = {(half_t)x[0], (half_t)x[1], (half_t)x[2], (half_t)x[3]};
-                    *(h4*)((half_t*)sg.out + o) = pk;
+                    h8 pk;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
+                    *(h8*)((half_t*)sg.out + o) = pk;
                 } else if (sg.dtype == DT_F32) {
-                    *(f4*)((float*)sg.out + o) = x;
+                    *(f4*)((float*)sg.out + o) = f4{x[0], x[1], x[2], x[3]};
+                    *(f4*)((float*)sg.out + o + 4) = f4{x[4], x[5], x[6], x[7]};
                 } else {
-                    typedef u16 us4 __attribute__((ext_vector_type(4)));
-                    us4 pk = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
-                    *(us4*)((u16*)sg.out + o) = pk;
+                    typedef u16 us8 __attribute__((ext_vector_type(8)));
+                    us8 pk;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
+                    *(us8*)((u16*)sg.out + o) = pk;
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
         }
         return;
     }
@@ -411,7 +433,9 @@ template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE
 int launch_cfg2(const IGemmArgs& a, hipStream_t s) {
     constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
     constexpr int BNP = (BN + PASSROWS - 1) / PASSROWS * PASSROWS;
-    constexpr size_t smem = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
+    constexpr size_t ring = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
+    constexpr size_t stage_bytes = (size_t)WAVES_M * WAVES_N * 16 * (BN / WAVES_N + 4) * sizeof(float);
+    constexpr size_t smem = ring > stage_bytes ? ring : stage_bytes;
     static bool attr_done = false;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>,
@@ -434,8 +458,9 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s) {
 bool can_swap(const IGemmArgs& a) {
     bool swap = (a.Nout % 16 == 0);
     for (int i = 0; i < a.nseg; ++i)
-        swap = swap && a.seg[i].fmt == SEG_ROW && (a.seg[i].ld % 4 == 0) && (((uintptr_t)a.seg[i].out & 15) == 0);
-    if (a.res) swap = swap && (a.ldres % 4 == 0) && (((uintptr_t)a.res & 7) == 0);
+        swap = swap && a.seg[i].fmt == SEG_ROW && (a.seg[i].ld % 8 == 0) && (((uintptr_t)a.seg[i].out & 15) == 0) &&
+               (a.seg[i].col_begin % 8 == 0);
+    if (a.res) swap = swap && (a.ldres % 8 == 0) && (((uintptr_t)a.res & 15) == 0);
     if (a.bias) swap = swap && (((uintptr_t)a.bias & 15) == 0);
     if (a.rowvec) swap = swap && (a.rowvec_ld % 4 == 0) && (((uintptr_t)a.rowvec & 15) == 0);
     return swap;

@@ -138,13 +138,19 @@ static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, con
     half_t* qk = cx.h((size_t)M * 2 * Ci);
     half_t* vt = cx.h((size_t)B * Ci * Lpad);
     if (L % 8) RUN(cx, op_fill_zero(vt, (size_t)B * Ci * Lpad * sizeof(half_t), cx.s));   // attention contract: finite pad columns
+    // Q|K leave row-major through the coalesced vector epilogue; V is written transposed ([batch][C][tokens], the
+    // attention kernel's A operand) by a second launch over the V rows of the packed weight -- one launch with mixed
+    // layouts would force the scalar epilogue on all three thirds
     IGemmArgs g = {};
     g.A = xn; g.lda = dim; g.mode = IG_ROWS; g.Cin = dim; g.taps = 1;
-    g.W = w.qkv.w; g.M = M; g.Nout = 3 * Ci; g.Ktot = dim; g.scale = 1.f;
-    g.nseg = 2;
+    g.W = w.qkv.w; g.M = M; g.Nout = 2 * Ci; g.Ktot = dim; g.scale = 1.f;
+    g.nseg = 1;
     g.seg[0] = IGemmSeg{qk, 2 * Ci, 0, 2 * Ci, SEG_ROW, DT_F16, 1, 0};
-    g.seg[1] = IGemmSeg{vt, Lpad, 2 * Ci, Ci, SEG_TRANSPOSED, DT_F16, L, 0};
     RUN(cx, op_igemm(g, cx.s));
+    IGemmArgs gv = g;
+    gv.W = w.qkv.w + (size_t)2 * Ci * dim; gv.Nout = Ci;
+    gv.seg[0] = IGemmSeg{vt, Lpad, 0, Ci, SEG_TRANSPOSED, DT_F16, L, 0};
+    RUN(cx, op_igemm(gv, cx.s));
     half_t* o = cx.h((size_t)M * Ci);
     TRY(run_attention(cx, qk, 2 * Ci, qk + Ci, 2 * Ci, vt, Lpad, o, Ci, B, B, w.heads, w.D, L, L));
     TRY(run_linear(cx, w.out, o, Ci, out, dim, M, resid, dim));
@@ -178,11 +184,14 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const half_t*
     if (e.Lk % 8) RUN(cx, op_fill_zero(vt, (size_t)e.batch * Ci * Lkpad * sizeof(half_t), cx.s));   // finite pad columns
     IGemmArgs g = {};
     g.A = e.h16; g.lda = e.cross; g.mode = IG_ROWS; g.Cin = e.cross; g.taps = 1;
-    g.W = w.kv.w; g.M = Mk; g.Nout = 2 * Ci; g.Ktot = e.cross; g.scale = 1.f;
-    g.nseg = 2;
+    g.W = w.kv.w; g.M = Mk; g.Nout = Ci; g.Ktot = e.cross; g.scale = 1.f;
+    g.nseg = 1;
     g.seg[0] = IGemmSeg{k, Ci, 0, Ci, SEG_ROW, DT_F16, 1, 0};
-    g.seg[1] = IGemmSeg{vt, Lkpad, Ci, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
     RUN(cx, op_igemm(g, cx.s));
+    IGemmArgs gv = g;
+    gv.W = w.kv.w + (size_t)Ci * e.cross;
+    gv.seg[0] = IGemmSeg{vt, Lkpad, 0, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
+    RUN(cx, op_igemm(gv, cx.s));
     half_t* o = cx.h((size_t)M * Ci);
     TRY(run_attention(cx, q, Ci, k, Ci, vt, Lkpad, o, Ci, B, e.batch == 1 ? 1 : B, w.heads, w.D, L, e.Lk));
     TRY(run_linear(cx, w.out, o, Ci, out, dim, M, x, dim));
