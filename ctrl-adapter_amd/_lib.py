@@ -25,7 +25,8 @@ class IGemmDesc(C.Structure):
                 ("W", C.c_void_p), ("M", C.c_int32), ("Nout", C.c_int32), ("Ktot", C.c_int32), ("pad1_", C.c_int32),
                 ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_ld", C.c_int32), ("rows_per_img", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int64), ("scale", C.c_float), ("geglu", C.c_int32),
-                ("nseg", C.c_int32), ("act", C.c_int32), ("seg", IGemmSeg * 3)]
+                ("nseg", C.c_int32), ("act", C.c_int32), ("res_f32", C.c_int32), ("pad3_", C.c_int32),
+                ("out16", C.c_void_p), ("ld16", C.c_int64), ("seg", IGemmSeg * 3)]
 
 
 class AttnDesc(C.Structure):

@@ -18,16 +18,16 @@ int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream) {
     CTRL_CHECK(d != nullptr, "temporal_attn: null descriptor");
     return op_temporal_attn(*d, S(stream));
 }
-int ctrl_op_gn_stats(const void* x, float* stats, int imgs, int rows_per_img, int C, int G, void* stream) {
-    return op_gn_stats(CH(x), stats, imgs, rows_per_img, C, G, S(stream));
+int ctrl_op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, void* stream) {
+    return op_gn_stats(x, x_dtype, stats, imgs, rows_per_img, C, G, S(stream));
 }
-int ctrl_op_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
+int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream) {
-    return op_gn_apply(CH(x), stats, gamma, beta, H(y), imgs, rows_per_img, C, G, eps, silu, S(stream));
+    return op_gn_apply(x, x_dtype, stats, gamma, beta, H(y), imgs, rows_per_img, C, G, eps, silu, S(stream));
 }
-int ctrl_op_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+int ctrl_op_layernorm(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                       int M, int C, float eps, void* stream) {
-    return op_layernorm(CH(x), ldx, gamma, beta, H(y), ldy, M, C, eps, S(stream));
+    return op_layernorm(x, x_dtype, ldx, gamma, beta, H(y), ldy, M, C, eps, S(stream));
 }
 int ctrl_op_nchw_to_nhwc(const void* x, int dtype, void* y, int N, int C, int HW, void* stream) {
     return op_nchw_to_nhwc(x, dtype, H(y), N, C, HW, S(stream));
@@ -45,11 +45,11 @@ int ctrl_op_linear_small(const float* x, int64_t ldx, const void* w, const float
                          int M, int N, int K, int in_silu, int out_silu, void* stream) {
     return op_linear_small(x, ldx, CH(w), b, out, ldo, M, N, K, in_silu, out_silu, S(stream));
 }
-int ctrl_op_blend(const void* xs, const void* xt, const float* mix, void* y, size_t n, void* stream) {
-    return op_blend(CH(xs), CH(xt), mix, H(y), n, S(stream));
+int ctrl_op_blend(const void* xs, int xs_dtype, const void* xt, int xt_dtype, const float* mix, void* y, int y_dtype, size_t n, void* stream) {
+    return op_blend(xs, xs_dtype, xt, xt_dtype, mix, y, y_dtype, n, S(stream));
 }
-int ctrl_op_add_rowvec(const void* x, const float* v, int64_t ldv, void* y, size_t M, int C, int rows_per_img, int vmod, void* stream) {
-    return op_add_rowvec(CH(x), v, ldv, H(y), M, C, rows_per_img, vmod, S(stream));
+int ctrl_op_add_rowvec(const void* x, int x_dtype, const float* v, int64_t ldv, void* y, int y_dtype, size_t M, int C, int rows_per_img, int vmod, void* stream) {
+    return op_add_rowvec(x, x_dtype, v, ldv, y, y_dtype, M, C, rows_per_img, vmod, S(stream));
 }
 int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w, const float* bias, void* out,
                            int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, void* stream) {

@@ -126,31 +126,55 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void blend_kernel(const half_t* __restrict__ xs, const half_t* __restrict__ xt,
-                                                    const float* __restrict__ mix, half_t* __restrict__ y, size_t nchunks) {
-    const float alpha = 1.0f / (1.0f + __expf(-mix[0]));
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
-        const h8 a = ((const h8*)xs)[i], b = ((const h8*)xt)[i];
+// 8-element chunk i of an fp16 or fp32 tensor (the fp32 residual stream) as floats, and back
+__device__ __forceinline__ void ld8(const void* p, size_t i, int dt, float (&o)[8]) {
+    if (dt == DT_F32) {
+        const f4 a = ((const f4*)p)[2 * i], b = ((const f4*)p)[2 * i + 1];
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    } else {
+        const h8 v = ((const h8*)p)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+    }
+}
+__device__ __forceinline__ void st8(void* p, size_t i, int dt, const float (&v)[8]) {
+    if (dt == DT_F32) {
+        ((f4*)p)[2 * i] = f4{v[0], v[1], v[2], v[3]};
+        ((f4*)p)[2 * i + 1] = f4{v[4], v[5], v[6], v[7]};
+    } else {
         h8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(alpha * (float)a[j] + (1.0f - alpha) * (float)b[j]);
-        ((h8*)y)[i] = o;
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+        ((h8*)p)[i] = o;
     }
 }
 
-__global__ __launch_bounds__(256) void add_rowvec_kernel(const half_t* __restrict__ x, const float* __restrict__ v, long ldv,
-                                                         half_t* __restrict__ y, size_t nchunks, int C, int rows_per_img, int vmod) {
+__global__ __launch_bounds__(256) void blend_kernel(const void* __restrict__ xs, int xs_dt, const void* __restrict__ xt, int xt_dt,
+                                                    const float* __restrict__ mix, void* __restrict__ y, int y_dt, size_t nchunks) {
+    const float alpha = 1.0f / (1.0f + __expf(-mix[0]));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+        float a[8], b[8], o[8];
+        ld8(xs, i, xs_dt, a);
+        ld8(xt, i, xt_dt, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = alpha * a[j] + (1.0f - alpha) * b[j];
+        st8(y, i, y_dt, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ v, long ldv,
+                                                         void* __restrict__ y, int y_dt, size_t nchunks, int C, int rows_per_img, int vmod) {
     const int lpr = C >> 3;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
         const size_t row = i / lpr;
         const int c0 = (int)(i - row * lpr) * 8;
         const size_t img = (row / rows_per_img) % vmod;
-        const h8 a = ((const h8*)x)[i];
+        float a[8];
+        ld8(x, i, x_dt, a);
         const float* vp = v + img * ldv + c0;
-        h8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] + vp[j]);
-        ((h8*)y)[i] = o;
+        for (int j = 0; j < 8; ++j) a[j] += vp[j];
+        st8(y, i, y_dt, a);
     }
 }
 
@@ -279,15 +303,17 @@ int op_linear_small(const float* x, long ldx, const half_t* w, const float* b, f
     LAUNCH("linear_small", linear_small_kernel<8>, grid, dim3(256), 0, s, x, ldx, w, b, out, ldo, M, N, K, in_silu, out_silu);
     return 0;
 }
-int op_blend(const half_t* xs, const half_t* xt, const float* mix, half_t* y, size_t n, hipStream_t s) {
+int op_blend(const void* xs, int xs_dt, const void* xt, int xt_dt, const float* mix, void* y, int y_dt, size_t n, hipStream_t s) {
     CTRL_CHECK(n % 8 == 0, "blend: element count must be a multiple of 8");
-    LAUNCH("blend", blend_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, xs, xt, mix, y, n / 8);
+    CTRL_CHECK(xs_dt != DT_BF16 && xt_dt != DT_BF16 && y_dt != DT_BF16, "blend: fp16 / fp32 only");
+    LAUNCH("blend", blend_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, xs, xs_dt, xt, xt_dt, mix, y, y_dt, n / 8);
     return 0;
 }
-int op_add_rowvec(const half_t* x, const float* v, long ldv, half_t* y, size_t M, int C, int rows_per_img, int vmod, hipStream_t s) {
+int op_add_rowvec(const void* x, int x_dt, const float* v, long ldv, void* y, int y_dt, size_t M, int C, int rows_per_img, int vmod, hipStream_t s) {
     CTRL_CHECK(C % 8 == 0, "add_rowvec: C must be a multiple of 8");
+    CTRL_CHECK(x_dt != DT_BF16 && y_dt != DT_BF16, "add_rowvec: fp16 / fp32 only");
     const size_t nch = M * (size_t)(C / 8);
-    LAUNCH("add_rowvec", add_rowvec_kernel, dim3(grid_for(nch)), dim3(256), 0, s, x, v, ldv, y, nch, C, rows_per_img, vmod);
+    LAUNCH("add_rowvec", add_rowvec_kernel, dim3(grid_for(nch)), dim3(256), 0, s, x, x_dt, v, ldv, y, y_dt, nch, C, rows_per_img, vmod);
     return 0;
 }
 int op_fill_zero(void* p, size_t bytes, hipStream_t s) {

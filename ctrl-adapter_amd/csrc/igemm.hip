@@ -314,12 +314,25 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
                 const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
                 float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if (Rptr) {
-                    const h8 rr = *(const h8*)(Rptr + (size_t)row * a.ldres + ocol);
+                    if (a.res_f32) {
+                        const float* rp = (const float*)a.res + (size_t)row * a.ldres + ocol;
+                        const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
+                        for (int i = 0; i < 4; ++i) { x[i] += r0[i]; x[4 + i] += r1[i]; }
+                    } else {
+                        const h8 rr = *(const h8*)(Rptr + (size_t)row * a.ldres + ocol);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] *= a.scale;
+                if (a.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
+                    h8 pk;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
+                    *(h8*)((half_t*)a.out16 + (size_t)row * a.ld16 + ocol) = pk;
+                }
                 int si = 0;
 #pragma unroll
                 for (int k = 1; k < 3; ++k)
@@ -381,7 +394,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
                     x = x * gelu_erf_f(g);
                 }
                 if (a.act == 1) x = silu_f(x);
-                if (Rptr && row < a.M) x += (float)Rptr[(size_t)row * a.ldres + ocol];
+                if (Rptr && row < a.M)
+                    x += a.res_f32 ? ((const float*)a.res)[(size_t)row * a.ldres + ocol] : (float)Rptr[(size_t)row * a.ldres + ocol];
                 v[i] = x * a.scale;
             }
             if (sg.fmt == SEG_ROW) {
@@ -461,6 +475,7 @@ bool can_swap(const IGemmArgs& a) {
         swap = swap && a.seg[i].fmt == SEG_ROW && (a.seg[i].ld % 8 == 0) && (((uintptr_t)a.seg[i].out & 15) == 0) &&
                (a.seg[i].col_begin % 8 == 0);
     if (a.res) swap = swap && (a.ldres % 8 == 0) && (((uintptr_t)a.res & 15) == 0);
+    if (a.out16) swap = swap && (a.ld16 % 8 == 0) && (((uintptr_t)a.out16 & 15) == 0);
     if (a.bias) swap = swap && (((uintptr_t)a.bias & 15) == 0);
     if (a.rowvec) swap = swap && (a.rowvec_ld % 4 == 0) && (((uintptr_t)a.rowvec & 15) == 0);
     return swap;
@@ -506,6 +521,7 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "igemm: A/W must be 16-byte aligned");
     CTRL_CHECK(a.nseg >= 1 && a.nseg <= 3, "igemm: nseg must be 1..3");
     CTRL_CHECK(!a.geglu || (a.Nout % 32) == 0, "igemm: GEGLU needs Nout % 32 == 0");
+    CTRL_CHECK(!a.out16 || (a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a)), "igemm: the fp16 mirror needs a single aligned row-major output");
     for (int i = 0; i < a.nseg; ++i) {
         CTRL_CHECK(a.seg[i].col_begin % 16 == 0, "igemm: segment boundary must be a multiple of 16");
         CTRL_CHECK(a.seg[i].out != nullptr, "igemm: null segment output");

@@ -12,9 +12,22 @@
 
 namespace {
 
+// 8 consecutive channels as fp32, from the fp16 activations or the fp32 residual stream
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void load8<half_t>(const half_t* p, float (&o)[8]) {
+    const h8 v = *(const h8*)p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&o)[8]) {
+    const f4 a = *(const f4*)p, b = *(const f4*)(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+
 // x [imgs][rows][C]; grid (chunks, imgs); each thread owns an 8-channel chunk and strides over rows, four 16-byte
 // loads in flight per thread (these kernels are pure HBM streaming: memory-level parallelism is what matters).
-__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
                                                        int rows, int C, int G, int rows_per_block) {
     extern __shared__ float sh[];   // [2*C]: per-channel sum, sumsq
     const int tid = threadIdx.x;
@@ -30,21 +43,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
     if (tr < rpi) {
-        const half_t* xp = x + ((size_t)img * rows) * C + tc * 8;
+        const T* xp = x + ((size_t)img * rows) * C + tc * 8;
+        constexpr int U = sizeof(T) == 2 ? 8 : 4;       // loads in flight per thread
         int r = r0 + tr;
-        for (; r + 7 * rpi < r1; r += 8 * rpi) {
-            h8 v[8];
+        for (; r + (U - 1) * rpi < r1; r += U * rpi) {
+            float v[U][8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *(const h8*)(xp + (size_t)(r + u * rpi) * C);
+            for (int u = 0; u < U; ++u) load8<T>(xp + (size_t)(r + u * rpi) * C, v[u]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; ss[j] += f * f; }
+                for (int j = 0; j < 8; ++j) { const float f = v[u][j]; s[j] += f; ss[j] += f * f; }
         }
         for (; r < r1; r += rpi) {
-            const h8 v = *(const h8*)(xp + (size_t)r * C);
+            float v[8];
+            load8<T>(xp + (size_t)r * C, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; ss[j] += f * f; }
+            for (int j = 0; j < 8; ++j) { const float f = v[j]; s[j] += f; ss[j] += f * f; }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -64,7 +79,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
 
 // same decomposition as the statistics pass: a thread folds mean / rstd / gamma / beta of its 8 channels into one
 // (scale, shift) pair each, once, then streams its rows: y = x*scale + shift (optional SiLU)
-__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, const float* __restrict__ stats,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        half_t* __restrict__ y, int rows, int C, int G, float eps,
                                                        int silu, int rows_per_block) {
@@ -91,13 +107,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
         sf[j] = beta[c] - mean * sc[j];
     }
     const size_t base = ((size_t)img * rows) * C + tc * 8;
-    const half_t* xp = x + base;
+    const T* xp = x + base;
     half_t* yp = y + base;
-    auto xform = [&](const h8& v) {
+    auto xform = [&](const float (&v)[8]) {
         h8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] * sc[j] + sf[j];
+            float f = v[j] * sc[j] + sf[j];
             if (silu) f = silu_f(f);
             o[j] = (half_t)f;
         }
@@ -105,33 +121,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     };
     int r = r0 + tr;
     for (; r + 3 * rpi < r1; r += 4 * rpi) {
-        h8 v[4];
+        float v[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const h8*)(xp + (size_t)(r + u * rpi) * C);
+        for (int u = 0; u < 4; ++u) load8<T>(xp + (size_t)(r + u * rpi) * C, v[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) *(h8*)(yp + (size_t)(r + u * rpi) * C) = xform(v[u]);
     }
-    for (; r < r1; r += rpi) *(h8*)(yp + (size_t)r * C) = xform(*(const h8*)(xp + (size_t)r * C));
+    for (; r < r1; r += rpi) {
+        float v[8];
+        load8<T>(xp + (size_t)r * C, v);
+        *(h8*)(yp + (size_t)r * C) = xform(v);
+    }
 }
 
 // one wavefront per row; C <= 64*8*NCH
-template <int NCH>
-__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long ldx,
+template <int NCH, typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         half_t* __restrict__ y, long ldy, int M, int C, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
-    const half_t* xp = x + (size_t)row * ldx;
+    const T* xp = x + (size_t)row * ldx;
     float v[NCH][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c0 = (lane + i * 64) * 8;
         if (c0 < C) {
-            const h8 t = *(const h8*)(xp + c0);
+            load8<T>(xp + c0, v[i]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+            for (int j = 0; j < 8; ++j) s += v[i][j];
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
@@ -173,37 +193,56 @@ static int gn_rows_per_block(int imgs, int rows_per_img, int C, int target_block
     return rpb;
 }
 
-int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
+int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
+    CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_stats: input must be fp16 or fp32");
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_stats: C must be a multiple of 8 and of G, <= 2048");
     CTRL_CHECK(G <= 256, "gn_stats: G too large");
     // fewer, fatter workgroups than the apply pass: every workgroup ends with 2*G global atomics on the same 2*G words
     const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 768);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
-    PROF_WORK(0, 2.0 * imgs * rows_per_img * C);
-    LAUNCH("gn_stats", gn_stats_kernel, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
-           x, stats, rows_per_img, C, G, rows_per_block);
+    PROF_WORK(0, (x_dtype == DT_F32 ? 4.0 : 2.0) * imgs * rows_per_img * C);
+    if (x_dtype == DT_F32)
+        LAUNCH("gn_stats", gn_stats_kernel<float>, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
+               (const float*)x, stats, rows_per_img, C, G, rows_per_block);
+    else
+        LAUNCH("gn_stats", gn_stats_kernel<half_t>, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
+               (const half_t*)x, stats, rows_per_img, C, G, rows_per_block);
     return 0;
 }
 
-int op_gn_apply(const half_t* x, const float* stats, const float* gamma, const float* beta, half_t* y,
+int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
                 int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s) {
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_apply: C must be a multiple of 8 and of G, <= 2048");
     const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 2048);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
-    PROF_WORK(0, 4.0 * imgs * rows_per_img * C);
-    LAUNCH("gn_apply", gn_apply_kernel, dim3(chunks, imgs), dim3(256), 0, s,
-           x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block);
+    CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_apply: input must be fp16 or fp32");
+    PROF_WORK(0, (x_dtype == DT_F32 ? 6.0 : 4.0) * imgs * rows_per_img * C);
+    if (x_dtype == DT_F32)
+        LAUNCH("gn_apply", gn_apply_kernel<float>, dim3(chunks, imgs), dim3(256), 0, s,
+               (const float*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block);
+    else
+        LAUNCH("gn_apply", gn_apply_kernel<half_t>, dim3(chunks, imgs), dim3(256), 0, s,
+               (const half_t*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block);
     return 0;
 }
 
-int op_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
+int op_layernorm(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
                  int M, int C, float eps, hipStream_t s) {
     CTRL_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C must be a multiple of 8 and <= 2048");
     CTRL_CHECK(ldx % 8 == 0 && ldy % 8 == 0, "layernorm: leading dims must be multiples of 8");
+    CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "layernorm: input must be fp16 or fp32");
     const dim3 grid((M + 3) / 4), block(256);
-    PROF_WORK(0, 4.0 * M * C);
-    if (C <= 512) LAUNCH("layernorm", layernorm_kernel<1>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);
-    else if (C <= 1024) LAUNCH("layernorm", layernorm_kernel<2>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);
-    else LAUNCH("layernorm", layernorm_kernel<4>, grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, C, eps);
+    PROF_WORK(0, (x_dtype == DT_F32 ? 6.0 : 4.0) * M * C);
+#define LN_LAUNCH(NCH)                                                                                              \
+    do {                                                                                                            \
+        if (x_dtype == DT_F32)                                                                                      \
+            LAUNCH("layernorm", (layernorm_kernel<NCH, float>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, y, ldy, M, C, eps); \
+        else                                                                                                        \
+            LAUNCH("layernorm", (layernorm_kernel<NCH, half_t>), grid, block, 0, s, (const half_t*)x, ldx, gamma, beta, y, ldy, M, C, eps); \
+    } while (0)
+    if (C <= 512) LN_LAUNCH(1);
+    else if (C <= 1024) LN_LAUNCH(2);
+    else LN_LAUNCH(4);
+#undef LN_LAUNCH
     return 0;
 }

@@ -36,12 +36,12 @@ int op_temporal_attn(const TAttnArgs& a, hipStream_t s);
 // ------------------------------------------------------------------------------------------
 // GroupNorm statistics over [img][rows_per_img][C]: stats[img][G][2] += (sum, sumsq)   (fp32 atomics;
 // caller zeroes `stats` once per forward)
-int op_gn_stats(const half_t* x, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s);
+int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s);
 // y = (x-mean)*rstd*gamma+beta (optionally SiLU); x,y [imgs*rows][C]
-int op_gn_apply(const half_t* x, const float* stats, const float* gamma, const float* beta, half_t* y,
+int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
                 int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s);
 // LayerNorm over the last dim of x [M][C] -> y fp16
-int op_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
+int op_layernorm(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
                  int M, int C, float eps, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
@@ -62,9 +62,9 @@ int op_frameidx_sincos(float* out, int N, int F, int dim, hipStream_t s);
 int op_linear_small(const float* x, long ldx, const half_t* w, const float* b, float* out, long ldo,
                     int M, int N, int K, int in_silu, int out_silu, hipStream_t s);
 // y[m][c] = a*x1[m][c] + b*x2[m][c]   (AlphaBlender; a=alpha, b=1-alpha read from device: alpha=sigmoid(*mix))
-int op_blend(const half_t* x_spatial, const half_t* x_temporal, const float* mix_factor, half_t* y, size_t n, hipStream_t s);
+int op_blend(const void* x_spatial, int xs_dt, const void* x_temporal, int xt_dt, const float* mix_factor, void* y, int y_dt, size_t n, hipStream_t s);
 // y[m][c] = x[m][c] + v[(m / rows_per_img) % vmod][c]   (fp32 per-image vector broadcast add)
-int op_add_rowvec(const half_t* x, const float* v, long ldv, half_t* y, size_t M, int C, int rows_per_img, int vmod, hipStream_t s);
+int op_add_rowvec(const void* x, int x_dt, const float* v, long ldv, void* y, int y_dt, size_t M, int C, int rows_per_img, int vmod, hipStream_t s);
 // fill fp16/any
 int op_fill_zero(void* p, size_t bytes, hipStream_t s);
 // K-way weighted merge of NCHW tensors: out = sum_e w[widx[e]] * x_e   (router merge; weights on device)

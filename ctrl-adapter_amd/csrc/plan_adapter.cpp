@@ -125,7 +125,7 @@ struct AFwd {
 };
 
 // temporal ResNet on frame-major rows [(b f) hw][C]
-int run_temporal_resnet(Ctx& cx, const TResnetW& w, const half_t* x, half_t* out, const AFwd& a, int HW, int C,
+int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, const AFwd& a, int HW, int C,
                         const float* temb /*[N][C]*/) {
     const size_t mk = cx.mark();
     const int N = a.N, M = N * HW;
@@ -133,46 +133,48 @@ int run_temporal_resnet(Ctx& cx, const TResnetW& w, const half_t* x, half_t* out
     RUN(cx, op_linear_small(temb, C, w.temb.w, w.temb.b, tp, C, N, C, C, 1, 0, cx.s));
     half_t* n1 = cx.h((size_t)M * C);
     TRY(run_groupnorm(cx, w.norm1, x, n1, a.B, a.F * HW, 1e-6f, true));     // statistics span the clip's frames
-    half_t* h1 = cx.h((size_t)M * C);
+    TV h1 = stream_alloc(cx, (size_t)M * C, false);
     IGemmArgs g = {};
     g.A = n1; g.lda = C; g.mode = IG_TEMPORAL; g.Cin = C; g.taps = 3; g.F = a.F; g.HW = HW;
     g.W = w.conv1.w; g.M = M; g.Nout = C; g.Ktot = 3 * C; g.bias = w.conv1.b;
     g.rowvec = tp; g.rowvec_ld = C; g.rows_per_img = HW; g.scale = 1.f;
-    g.nseg = 1; g.seg[0] = IGemmSeg{h1, C, 0, C, SEG_ROW, DT_F16, 1, 0};
+    set_out(g, h1, C, C);
     RUN(cx, op_igemm(g, cx.s));
     half_t* n2 = n1;
     TRY(run_groupnorm(cx, w.norm2, h1, n2, a.B, a.F * HW, 1e-6f, true));
     IGemmArgs g2 = g;
-    g2.A = n2; g2.W = w.conv2.w; g2.bias = w.conv2.b; g2.rowvec = nullptr; g2.res = x; g2.ldres = C;
-    g2.seg[0] = IGemmSeg{out, C, 0, C, SEG_ROW, DT_F16, 1, 0};
+    g2.A = n2; g2.W = w.conv2.w; g2.bias = w.conv2.b; g2.rowvec = nullptr;
+    set_res(g2, x, C);
+    set_out(g2, out, C, C);
     RUN(cx, op_igemm(g2, cx.s));
     cx.release(mk);
     return 0;
 }
 
 // TemporalBasicTransformerBlock on frame-major tokens X [(b f) L][512]; every op but the attention is per token
-int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const half_t* X, half_t* out, const AFwd& a, int L) {
+int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, const AFwd& a, int L) {
     const size_t mk = cx.mark();
     const int M = a.N * L, dim = w.dim, Ci = w.attn1.inner;
     // x = ff_in(norm_in(x)) + x
     half_t* xn = cx.h((size_t)M * dim);
-    RUN(cx, op_layernorm(X, dim, w.norm_in.g, w.norm_in.b, xn, dim, M, dim, 1e-5f, cx.s));
+    TRY(run_layernorm(cx, w.norm_in, X, xn, M, dim));
     half_t* mid = cx.h((size_t)M * 4 * dim);
-    TRY(run_linear(cx, w.ffin1, xn, dim, mid, 4 * dim, M, nullptr, 0));
-    half_t* x0 = cx.h((size_t)M * dim);
+    TRY(run_linear(cx, w.ffin1, xn, dim, tv16(mid), 4 * dim, M, TV(), 0));
+    TV x0 = stream_alloc(cx, (size_t)M * dim, false);
     TRY(run_linear(cx, w.ffin2, mid, 4 * dim, x0, dim, M, X, dim));
     // x = attn1(norm1(x)) + x  (sequence = frames)
-    RUN(cx, op_layernorm(x0, dim, w.norm1.g, w.norm1.b, xn, dim, M, dim, 1e-5f, cx.s));
+    TRY(run_layernorm(cx, w.norm1, x0, xn, M, dim));
     half_t* qkv = cx.h((size_t)M * 3 * Ci);
-    TRY(run_linear(cx, w.attn1.qkv, xn, dim, qkv, 3 * Ci, M, nullptr, 0));
+    TRY(run_linear(cx, w.attn1.qkv, xn, dim, tv16(qkv), 3 * Ci, M, TV(), 0));
     half_t* o = cx.h((size_t)M * Ci);
     TAttnArgs ta = {};
     ta.QKV = qkv; ta.ld = 3 * Ci; ta.O = o; ta.ldo = Ci; ta.Bc = a.B; ta.F = a.F; ta.HW = L; ta.heads = w.attn1.heads;
     ta.scale = 0.125f;
     RUN(cx, op_temporal_attn(ta, cx.s));
-    half_t* x1 = cx.h((size_t)M * dim);
+    TV x1 = stream_alloc(cx, (size_t)M * dim, false);
     TRY(run_linear(cx, w.attn1.out, o, Ci, x1, dim, M, x0, dim));
     // x = attn2(norm2(x), first-frame context) + x : one key => query independent (note N5)
+    TV x2 = stream_alloc(cx, (size_t)M * dim, false);
     {
         const EhsCtx& e = a.e_first;
         float* v = cx.f((size_t)e.batch * Ci);
@@ -180,13 +182,13 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const half_t* X, half_t* out,
         float* ov = cx.f((size_t)e.batch * dim);
         RUN(cx, op_linear_small(v, Ci, w.attn2.out.w, w.attn2.out.b, ov, dim, e.batch, dim, Ci, 0, 0, cx.s));
         // rows are (b f p); context index = clip b  -> (row / (F*L)) % batch
-        RUN(cx, op_add_rowvec(x1, ov, dim, x0, (size_t)M, dim, a.F * L, e.batch, cx.s));
+        RUN(cx, op_add_rowvec(x1.p, x1.dt, ov, dim, x2.p, x2.dt, (size_t)M, dim, a.F * L, e.batch, cx.s));
     }
     // x = ff(norm3(x)) + x
-    RUN(cx, op_layernorm(x0, dim, w.norm3.g, w.norm3.b, xn, dim, M, dim, 1e-5f, cx.s));
-    half_t* mid2 = cx.h((size_t)M * 4 * dim);
-    TRY(run_linear(cx, w.ff1, xn, dim, mid2, 4 * dim, M, nullptr, 0));
-    TRY(run_linear(cx, w.ff2, mid2, 4 * dim, out, dim, M, x0, dim));
+    TRY(run_layernorm(cx, w.norm3, x2, xn, M, dim));
+    half_t* mid2 = mid;
+    TRY(run_linear(cx, w.ff1, xn, dim, tv16(mid2), 4 * dim, M, TV(), 0));
+    TRY(run_linear(cx, w.ff2, mid2, 4 * dim, out, dim, M, x2, dim));
     cx.release(mk);
     return 0;
 }
@@ -197,8 +199,10 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
     const size_t mk = cx.mark();
     const int N = a.N, C = b.C;
     const bool sr = c.add_spatial_resnet, tr = c.add_temporal_resnet, st = c.add_spatial_transformer, tt = c.add_temporal_transformer;
-    half_t* x = cx.h((size_t)N * h * w * C);
-    RUN(cx, op_nchw_to_nhwc(in, a.in_dt, x, N, C, h * w, cx.s));
+    const bool has_tf = st || tt;
+    half_t* x0 = cx.h((size_t)N * h * w * C);
+    RUN(cx, op_nchw_to_nhwc(in, a.in_dt, x0, N, C, h * w, cx.s));
+    TV x = tv16(x0);
     int H = h, W = w;
     // resnet time embedding (:206-209): Timesteps(C) -> Linear -> SiLU -> Linear ; identical for every layer
     float* temb = nullptr;
@@ -224,66 +228,73 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
         const AdapterLayerW& Lw = b.layers[i];
         const int up = (i == 0) ? b.up : 1;
         const bool last = (i + 1 == nl);
+        // an fp16 copy of the layer's resnet output is needed only when nothing but a layout change follows it
+        const bool need16 = !has_tf;
         if (sr) {
             float* tp = cx.f((size_t)N * C);
             RUN(cx, op_linear_small(temb, C, Lw.sres_temb.w, Lw.sres_temb.b, tp, C, N, C, C, 1, 0, cx.s));
-            half_t* y = cx.h((size_t)N * H * up * W * up * C);
+            TV y = stream_alloc(cx, (size_t)N * H * up * W * up * C, need16 && !tr);
             TRY(run_resnet(cx, Lw.sres, x, y, N, H, W, up, tp, C, 1e-6f));
             x = y; H *= up; W *= up;
         } else if (up > 1) {
             CTRL_FAIL("adapter: up-sampling without a spatial resnet (F.interpolate path, :235-237) is not implemented");
         }
         if (tr) {
-            half_t* yt = cx.h((size_t)N * H * W * C);
+            TV yt = stream_alloc(cx, (size_t)N * H * W * C, need16 && !sr);
             TRY(run_temporal_resnet(cx, Lw.tres, x, yt, a, H * W, C, temb));
             if (sr) {
-                half_t* yb = cx.h((size_t)N * H * W * C);
-                RUN(cx, op_blend(x, yt, Lw.res_mix, yb, (size_t)N * H * W * C, cx.s));
+                TV yb = stream_alloc(cx, (size_t)N * H * W * C, false);
+                if (need16) { yb = tv16(cx.h((size_t)N * H * W * C)); }
+                RUN(cx, op_blend(x.p, x.dt, yt.p, yt.dt, Lw.res_mix, yb.p, yb.dt, (size_t)N * H * W * C, cx.s));
                 x = yb;
             } else {
                 x = yt;
             }
         }
-        if (st || tt) {
+        if (has_tf) {
             const int Lt = H * W, M = N * Lt;
             half_t* n = cx.h((size_t)M * C);
             TRY(run_groupnorm(cx, b.norm, x, n, N, Lt, 1e-6f, false));
-            half_t* tok = cx.h((size_t)M * INNER);
-            TRY(run_linear(cx, b.proj_in, n, C, tok, INNER, M, nullptr, 0));
-            half_t* smix = nullptr;
+            TV tok = stream_alloc(cx, (size_t)M * INNER, false);
+            TRY(run_linear(cx, b.proj_in, n, C, tok, INNER, M, TV(), 0));
+            TV smix;
             if (st) {
-                half_t* t2 = cx.h((size_t)M * INNER);
+                TV t2 = stream_alloc(cx, (size_t)M * INNER, !tt);      // proj_out operand when no temporal block follows
                 TRY(run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e));
                 tok = t2; smix = t2;
             }
             if (tt) {
-                half_t* t3 = cx.h((size_t)M * INNER);
-                RUN(cx, op_add_rowvec(tok, femb, INNER, t3, (size_t)M, INNER, Lt, a.F, cx.s));
-                half_t* t4 = cx.h((size_t)M * INNER);
+                TV t3 = stream_alloc(cx, (size_t)M * INNER, false);
+                RUN(cx, op_add_rowvec(tok.p, tok.dt, femb, INNER, t3.p, t3.dt, (size_t)M, INNER, Lt, a.F, cx.s));
+                TV t4 = stream_alloc(cx, (size_t)M * INNER, !st);
                 TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt));
                 if (st) {
-                    RUN(cx, op_blend(smix, t4, Lw.tr_mix, t3, (size_t)M * INNER, cx.s));
-                    tok = t3;
+                    // the blended tokens are consumed only as proj_out's operand: fp16
+                    half_t* t5 = cx.h((size_t)M * INNER);
+                    RUN(cx, op_blend(smix.p, smix.dt, t4.p, t4.dt, Lw.tr_mix, t5, DT_F16, (size_t)M * INNER, cx.s));
+                    tok = tv16(t5);
                 } else {
                     tok = t4;
                 }
             }
             // proj_out + residual (:286-289); the last layer writes the NCHW result directly
             IGemmArgs g = {};
-            g.A = tok; g.lda = INNER; g.mode = IG_ROWS; g.Cin = INNER; g.taps = 1;
+            g.A = tok.m16; g.lda = INNER; g.mode = IG_ROWS; g.Cin = INNER; g.taps = 1;
             g.W = b.proj_out.w; g.M = M; g.Nout = C; g.Ktot = INNER; g.bias = b.proj_out.b;
-            g.res = x; g.ldres = C; g.scale = 1.f; g.nseg = 1;
+            g.scale = 1.f;
+            set_res(g, x, C);
             if (last) {
+                g.nseg = 1;
                 g.seg[0] = IGemmSeg{out, Lt, 0, C, SEG_TRANSPOSED, a.out_dt, Lt, 0};
                 RUN(cx, op_igemm(g, cx.s));
             } else {
-                half_t* y = cx.h((size_t)M * C);
-                g.seg[0] = IGemmSeg{y, C, 0, C, SEG_ROW, DT_F16, 1, 0};
+                TV y = stream_alloc(cx, (size_t)M * C, true);      // next layer's shortcut conv reads the fp16 copy
+                set_out(g, y, C, C);
                 RUN(cx, op_igemm(g, cx.s));
                 x = y;
             }
         } else if (last) {
-            RUN(cx, op_nhwc_to_nchw(x, out, a.out_dt, N, C, H * W, 1.f, cx.s));
+            RUN(cx, op_nhwc_to_nchw(x.m16, out, a.out_dt, N, C, H * W, 1.f, cx.s));
         }
     }
     cx.release(mk);
@@ -416,10 +427,12 @@ int ctrl_adapter_forward(ctrl_adapter* h, const void* const* ins, int in_dtype, 
     hipStream_t s = (hipStream_t)stream;
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
+    dry.f32stream = stream_f32_enabled();
     TRY(adapter_run(dry, h->w, k));
     TRY(h->arena.ensure(workspace_bytes(dry), s));
     h->arena.off = 0;
     Ctx cx{&h->arena, s, false};
+    cx.f32stream = dry.f32stream;
     cx.stats_total = dry.stats_total;
     return adapter_run(cx, h->w, k);
 }

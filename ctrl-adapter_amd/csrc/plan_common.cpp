@@ -62,14 +62,19 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
 }
 
 // ------------------------------------------------------------------------------------------ runners
-int run_groupnorm(Ctx& cx, const Norm& n, const half_t* x, half_t* y, int imgs, int rows, float eps, bool silu) {
+int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu) {
     float* st = cx.stats((size_t)imgs * 32 * 2);
-    RUN(cx, op_gn_stats(x, st, imgs, rows, n.C, 32, cx.s));
-    RUN(cx, op_gn_apply(x, st, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s));
+    RUN(cx, op_gn_stats(x.p, x.dt, st, imgs, rows, n.C, 32, cx.s));
+    RUN(cx, op_gn_apply(x.p, x.dt, st, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s));
     return 0;
 }
 
-int run_conv(Ctx& cx, const ConvW& c, const half_t* x, half_t* y, int N, int Hin, int Win, const ConvOpts& o) {
+int run_layernorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int M, int dim) {
+    RUN(cx, op_layernorm(x.p, x.dt, dim, n.g, n.b, y, dim, M, dim, 1e-5f, cx.s));
+    return 0;
+}
+
+int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int Hin, int Win, const ConvOpts& o) {
     const int k = c.taps == 9 ? 3 : 1, pad = c.taps == 9 ? 1 : 0;
     const int Hout = (Hin * o.up + 2 * pad - k) / o.stride + 1, Wout = (Win * o.up + 2 * pad - k) / o.stride + 1;
     IGemmArgs g = {};
@@ -77,41 +82,42 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, half_t* y, int N, int Hin
     g.Hin = Hin; g.Win = Win; g.Hout = Hout; g.Wout = Wout; g.stride = o.stride; g.up = o.up;
     g.W = c.w; g.M = N * Hout * Wout; g.Nout = c.Cout; g.Ktot = c.taps * c.Cin;
     g.bias = c.b; g.rowvec = o.rowvec; g.rowvec_ld = o.rowvec_ld; g.rows_per_img = Hout * Wout;
-    g.res = o.res; g.ldres = c.Cout; g.scale = 1.f; g.act = o.act;
-    g.nseg = 1;
-    g.seg[0] = IGemmSeg{y, c.Cout, 0, c.Cout, SEG_ROW, DT_F16, 1, 0};
+    g.scale = 1.f; g.act = o.act;
+    set_res(g, o.res, c.Cout);
+    set_out(g, y, c.Cout, c.Cout);
     RUN(cx, op_igemm(g, cx.s));
     return 0;
 }
 
-int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, half_t* y, long ldy, int M, const half_t* res, long ldres) {
+int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, long ldy, int M, const TV& res, long ldres) {
     IGemmArgs g = {};
     g.A = x; g.lda = ldx; g.mode = IG_ROWS; g.Cin = l.K; g.taps = 1;
     g.W = l.w; g.M = M; g.Nout = l.N; g.Ktot = l.K;
-    g.bias = l.b; g.res = res; g.ldres = ldres; g.scale = 1.f; g.geglu = l.geglu ? 1 : 0;
-    const int on = l.geglu ? l.N / 2 : l.N;
-    g.nseg = 1;
-    g.seg[0] = IGemmSeg{y, ldy, 0, on, SEG_ROW, DT_F16, 1, 0};
+    g.bias = l.b; g.scale = 1.f; g.geglu = l.geglu ? 1 : 0;
+    set_res(g, res, ldres);
+    set_out(g, y, ldy, l.geglu ? l.N / 2 : l.N);
     RUN(cx, op_igemm(g, cx.s));
     return 0;
 }
 
-int run_resnet(Ctx& cx, const ResnetW& w, const half_t* x, half_t* out, int N, int H, int W, int up,
+int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int H, int W, int up,
                const float* temb_proj, int temb_ld, float eps) {
     const int Ho = H * up, Wo = W * up;
     const size_t m = cx.mark();
     half_t* a = cx.h((size_t)N * H * W * w.Cin);
     TRY(run_groupnorm(cx, w.norm1, x, a, N, H * W, eps, true));
-    half_t* h1 = cx.h((size_t)N * Ho * Wo * w.Cout);
+    // conv1 output feeds only GroupNorm: keep it in the stream dtype (its statistics are taken from this copy)
+    TV h1 = stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
     ConvOpts o1; o1.up = up; o1.rowvec = temb_proj; o1.rowvec_ld = temb_ld;
     TRY(run_conv(cx, w.conv1, a, h1, N, H, W, o1));
     half_t* b = cx.h((size_t)N * Ho * Wo * w.Cout);
     TRY(run_groupnorm(cx, w.norm2, h1, b, N, Ho * Wo, eps, true));
-    const half_t* sc = x;
+    TV sc = x;
     if (w.has_shortcut) {
-        half_t* s2 = cx.h((size_t)N * Ho * Wo * w.Cout);
+        CTRL_CHECK(cx.dry || x.m16 != nullptr, "resnet: the shortcut conv needs an fp16 copy of its input");
+        TV s2 = stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
         ConvOpts os; os.up = up;
-        TRY(run_conv(cx, w.shortcut, x, s2, N, H, W, os));
+        TRY(run_conv(cx, w.shortcut, x.m16, s2, N, H, W, os));
         sc = s2;
     }
     ConvOpts o2; o2.res = sc;
@@ -130,8 +136,8 @@ static int run_attention(Ctx& cx, const half_t* Q, long ldq, const half_t* K, lo
     return 0;
 }
 
-// self attention on LN'd tokens; returns attn_out_proj(attn) + bias + resid in `out`
-static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, const half_t* resid, half_t* out, int B, int L) {
+// self attention on LN'd tokens; out = attn_out_proj(attn) + bias + resid
+static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, const TV& resid, const TV& out, int B, int L) {
     const size_t mk = cx.mark();
     const int M = B * L, Ci = w.inner;
     const int Lpad = (L + 63) / 64 * 64;
@@ -159,7 +165,7 @@ static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, con
 }
 
 // cross attention; Lk == 1 is the degenerate query-independent case (SURVEY.md note N5)
-static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const half_t* x, int dim, half_t* out, int B, int L,
+static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, int dim, const TV& out, int B, int L,
                           const EhsCtx& e) {
     const size_t mk = cx.mark();
     const int M = B * L, Ci = w.inner;
@@ -169,14 +175,14 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const half_t*
         RUN(cx, op_linear_small(e.f32, e.cross, w.v.w, nullptr, v, Ci, e.batch, Ci, e.cross, 0, 0, cx.s));
         float* o = cx.f((size_t)e.batch * dim);
         RUN(cx, op_linear_small(v, Ci, w.out.w, w.out.b, o, dim, e.batch, dim, Ci, 0, 0, cx.s));
-        RUN(cx, op_add_rowvec(x, o, dim, out, (size_t)M, dim, L, e.batch, cx.s));
+        RUN(cx, op_add_rowvec(x.p, x.dt, o, dim, out.p, out.dt, (size_t)M, dim, L, e.batch, cx.s));
         cx.release(mk);
         return 0;
     }
     half_t* xn = cx.h((size_t)M * dim);
-    RUN(cx, op_layernorm(x, dim, ln.g, ln.b, xn, dim, M, dim, 1e-5f, cx.s));
+    TRY(run_layernorm(cx, ln, x, xn, M, dim));
     half_t* q = cx.h((size_t)M * Ci);
-    TRY(run_linear(cx, w.q, xn, dim, q, Ci, M, nullptr, 0));
+    TRY(run_linear(cx, w.q, xn, dim, tv16(q), Ci, M, TV(), 0));
     const int Lkpad = (e.Lk + 63) / 64 * 64;
     const int Mk = e.batch * e.Lk;
     half_t* k = cx.h((size_t)Mk * Ci);
@@ -199,30 +205,29 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const half_t*
     return 0;
 }
 
-static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const half_t* x, int dim, half_t* out, int M,
-                  bool residual) {
+static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const TV& x, int dim, const TV& out, int M) {
     const size_t mk = cx.mark();
     half_t* xn = cx.h((size_t)M * dim);
-    RUN(cx, op_layernorm(x, dim, ln.g, ln.b, xn, dim, M, dim, 1e-5f, cx.s));
+    TRY(run_layernorm(cx, ln, x, xn, M, dim));
     const int inner = ff1.N / 2;
     half_t* hmid = cx.h((size_t)M * inner);
-    TRY(run_linear(cx, ff1, xn, dim, hmid, inner, M, nullptr, 0));
-    TRY(run_linear(cx, ff2, hmid, inner, out, ff2.N, M, residual ? x : nullptr, dim));
+    TRY(run_linear(cx, ff1, xn, dim, tv16(hmid), inner, M, TV(), 0));
+    TRY(run_linear(cx, ff2, hmid, inner, out, ff2.N, M, x, dim));
     cx.release(mk);
     return 0;
 }
 
-int run_basic_tb(Ctx& cx, const BasicTBW& w, const half_t* X, half_t* out, int B, int L, const EhsCtx& e) {
+int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e) {
     CTRL_CHECK(e.batch == 1 || e.batch == B, "encoder_hidden_states batch must be 1 or equal to the sample batch");
     const size_t mk = cx.mark();
     const int M = B * L, dim = w.dim;
     half_t* xn = cx.h((size_t)M * dim);
-    RUN(cx, op_layernorm(X, dim, w.norm1.g, w.norm1.b, xn, dim, M, dim, 1e-5f, cx.s));
-    half_t* x1 = cx.h((size_t)M * dim);
+    TRY(run_layernorm(cx, w.norm1, X, xn, M, dim));
+    TV x1 = stream_alloc(cx, (size_t)M * dim, false);
     TRY(run_self_attn(cx, w.attn1, xn, dim, X, x1, B, L));
-    half_t* x2 = xn;     // xn is dead after the QKV projection: reuse it
+    TV x2 = stream_alloc(cx, (size_t)M * dim, false);
     TRY(run_cross_attn(cx, w.attn2, w.norm2, x1, dim, x2, B, L, e));
-    TRY(run_ff(cx, w.norm3, w.ff1, w.ff2, x2, dim, out, M, true));
+    TRY(run_ff(cx, w.norm3, w.ff1, w.ff2, x2, dim, out, M));
     cx.release(mk);
     return 0;
 }

@@ -6,6 +6,7 @@
 //   * block runners (GroupNorm+SiLU, ResnetBlock2D, BasicTransformerBlock, ...) that enqueue the HIP kernels
 #pragma once
 #include "ops.h"
+#include <cstdlib>
 #include <functional>
 #include <string>
 #include <unordered_map>
@@ -199,6 +200,7 @@ struct Ctx {
     Arena* ar;
     hipStream_t s;
     bool dry;
+    bool f32stream = true;     // residual streams kept in fp32 (set from CTRL_STREAM_F32, default on)
     // pooled GroupNorm statistics (zeroed once per forward with a single memset)
     float* stats_base = nullptr;
     size_t stats_off = 0, stats_total = 0;
@@ -260,22 +262,62 @@ int build_attn_cross(ParamSink& ps, const std::string& pre, int dim, int cross, 
 int build_basic_tb(ParamSink& ps, const std::string& pre, int dim, int heads, int D, int cross, BasicTBW* w);
 int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads, int D, int cross, TemporalTBW* w);
 
+// fp32 residual streams are the default; CTRL_STREAM_F32=0 selects fp16 streams (faster by a few %, ~2x the error)
+inline bool stream_f32_enabled() {
+    const char* e = getenv("CTRL_STREAM_F32");
+    return !(e && e[0] == '0');
+}
+
+// ------------------------------------------------------------------------------------------ tensor views
+// A residual-stream tensor: master copy `p` in dtype `dt` (fp32 when Ctx::f32stream, else fp16) and, where a GEMM / conv
+// consumes it as an operand, an fp16 copy `m16` (== p for an fp16 master; written by the producing GEMM's epilogue as
+// a mirror for an fp32 master).  Keeping the stream in fp32 removes the accumulated fp16 rounding of ~60 sequential
+// residual updates (the dominant error term of the chained ControlNet -> adapter path).
+struct TV {
+    void* p = nullptr;
+    int dt = DT_F16;
+    half_t* m16 = nullptr;
+    bool ok() const { return p != nullptr; }
+};
+inline TV tv16(const half_t* x) { TV t; t.p = (void*)x; t.dt = DT_F16; t.m16 = (half_t*)x; return t; }
+inline TV stream_alloc(Ctx& cx, size_t n, bool need16) {
+    TV t;
+    if (cx.f32stream) {
+        t.p = cx.f(n); t.dt = DT_F32;
+        t.m16 = need16 ? cx.h(n) : nullptr;
+    } else {
+        t.m16 = cx.h(n); t.p = t.m16; t.dt = DT_F16;
+    }
+    return t;
+}
+inline void set_out(IGemmArgs& g, const TV& out, long ld, int ncols) {
+    g.nseg = 1;
+    g.seg[0] = IGemmSeg{out.p, ld, 0, ncols, SEG_ROW, out.dt, 1, 0};
+    g.out16 = nullptr; g.ld16 = 0;
+    if (out.dt == DT_F32 && out.m16) { g.out16 = out.m16; g.ld16 = ld; }
+}
+inline void set_res(IGemmArgs& g, const TV& res, long ld) {
+    g.res = res.p; g.ldres = ld; g.res_f32 = (res.ok() && res.dt == DT_F32) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------ block runners
-// y = GroupNorm(x) (optional SiLU);  x,y [imgs*rows][C] fp16
-int run_groupnorm(Ctx& cx, const Norm& n, const half_t* x, half_t* y, int imgs, int rows, float eps, bool silu);
-// 3x3 / 1x1 conv through the implicit GEMM, NHWC -> NHWC (out fp16 row-major)
+// y = GroupNorm(x) (optional SiLU);  x [imgs*rows][C] fp16 or fp32 stream, y fp16
+int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu);
+// 3x3 / 1x1 conv through the implicit GEMM, NHWC fp16 operand -> NHWC stream tensor
 struct ConvOpts {
     int stride = 1, up = 1;
     const float* rowvec = nullptr; int rowvec_ld = 0;
-    const half_t* res = nullptr;
+    TV res;
     int act = 0;
 };
-int run_conv(Ctx& cx, const ConvW& c, const half_t* x, half_t* y, int N, int Hin, int Win, const ConvOpts& o);
-int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, half_t* y, long ldy, int M, const half_t* res, long ldres);
-// out = ResnetBlock2D(x, temb); temb_proj = rowvec [N][ld] (already time_emb_proj(SiLU(emb)) incl. bias)
-int run_resnet(Ctx& cx, const ResnetW& w, const half_t* x, half_t* out, int N, int H, int W, int up,
+int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int Hin, int Win, const ConvOpts& o);
+int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, long ldy, int M, const TV& res, long ldres);
+// out = ResnetBlock2D(x, temb); temb_proj = rowvec [N][ld] (already time_emb_proj(SiLU(emb)) incl. bias).
+// x.m16 must exist when the block has a shortcut conv (it is that conv's operand).
+int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int H, int W, int up,
                const float* temb_proj, int temb_ld, float eps);
 // Encoder-hidden-state context prepared once per forward: fp16 copy [B*Lk][cross] (+ fp32 copy when Lk == 1)
 struct EhsCtx { const half_t* h16 = nullptr; const float* f32 = nullptr; int batch = 1, Lk = 0, cross = 0; };
-// X [B*L][dim] (in place semantic: returns new buffer `out`)
-int run_basic_tb(Ctx& cx, const BasicTBW& w, const half_t* X, half_t* out, int B, int L, const EhsCtx& e);
+// X [B*L][dim] stream -> out stream (out.m16 is filled when the caller needs a GEMM-operand copy)
+int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e);
+int run_layernorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int M, int dim);

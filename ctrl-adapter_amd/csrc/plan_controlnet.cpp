@@ -160,19 +160,19 @@ struct FwdArgs {
     void* const* outs; int out_dt;
 };
 
-int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& pout, const BasicTBW& tb, const half_t* x,
-                      half_t* out, int N, int H, int W, const EhsCtx& e) {
+int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& pout, const BasicTBW& tb, const TV& x,
+                      const TV& out, int N, int H, int W, const EhsCtx& e) {
     const size_t mk = cx.mark();
     const int C = tn.C, M = N * H * W;
     half_t* n = cx.h((size_t)M * C);
     TRY(run_groupnorm(cx, tn, x, n, N, H * W, 1e-6f, false));
-    half_t* t0 = cx.h((size_t)M * C);
+    TV t0 = stream_alloc(cx, (size_t)M * C, false);
     ConvOpts o;
     TRY(run_conv(cx, pin, n, t0, N, H, W, o));
-    half_t* t1 = n;      // n is dead after proj_in
+    TV t1 = stream_alloc(cx, (size_t)M * C, true);      // its fp16 mirror is proj_out's operand
     TRY(run_basic_tb(cx, tb, t0, t1, N, H * W, e));
     ConvOpts oo; oo.res = x;
-    TRY(run_conv(cx, pout, t1, out, N, H, W, oo));
+    TRY(run_conv(cx, pout, t1.m16, out, N, H, W, oo));
     cx.release(mk);
     return 0;
 }
@@ -203,7 +203,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
 
     // ---- 2. stem: conv_in(sample) (:802-807) ----
     const int H = a.Hs, W = a.Ws;
-    half_t* x = cx.h((size_t)N * H * W * c0);          // block input (also residual slot 0)
+    TV x = stream_alloc(cx, (size_t)N * H * W * c0, true);     // block input (also residual slot 0)
     half_t* stem = nullptr;
     if (!(a.flags & CTRL_SKIP_CONV_IN)) {
         stem = cx.h((size_t)N * H * W * c0);
@@ -220,32 +220,34 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
             const int co = w.ce_chain_c[i], st = w.ce_chain_stride[i];
             const int ho = (hh - 1) / st + 1, wo = (ww - 1) / st + 1;
             const bool last = (i + 1 == nl);
-            half_t* y = last ? x : cx.h((size_t)N * ho * wo * co);
+            half_t* y16 = last ? nullptr : cx.h((size_t)N * ho * wo * co);
             if ((int)i < w.n_direct) {
-                RUN(cx, op_conv3x3_direct(cur, cur_dt, nchw, w.ce_direct[i].w, w.ce_direct[i].b, y, N, ch, co, hh, ww, st, 1, cx.s));
+                CTRL_CHECK(!last, "controlnet: the conditioning embedder must end with an implicit-GEMM layer");
+                RUN(cx, op_conv3x3_direct(cur, cur_dt, nchw, w.ce_direct[i].w, w.ce_direct[i].b, y16, N, ch, co, hh, ww, st, 1, cx.s));
             } else {
-                ConvOpts o; o.stride = st; o.act = last ? 0 : 1; o.res = last ? stem : nullptr;
-                TRY(run_conv(cx, w.ce_gemm[gi++], (const half_t*)cur, y, N, hh, ww, o));
+                ConvOpts o; o.stride = st; o.act = last ? 0 : 1;
+                if (last && stem) o.res = tv16(stem);
+                TRY(run_conv(cx, w.ce_gemm[gi++], (const half_t*)cur, last ? x : tv16(y16), N, hh, ww, o));
             }
-            cur = y; cur_dt = DT_F16; nchw = 0; ch = co; hh = ho; ww = wo;
+            cur = y16; cur_dt = DT_F16; nchw = 0; ch = co; hh = ho; ww = wo;
         }
         CTRL_CHECK(hh == H && ww == W, "controlnet_cond must be 8x the latent resolution");
         cx.release(mk);
     }
 
     // ---- 3. down blocks (:820-833) ----
-    std::vector<const half_t*> res; std::vector<int> res_c, res_h, res_w;
+    std::vector<TV> res; std::vector<int> res_c, res_h, res_w;
     res.push_back(x); res_c.push_back(c0); res_h.push_back(H); res_w.push_back(W);
     int h = H, wd = W;
-    const half_t* cur = x;
+    TV cur = x;
     for (int i = 0; i < 4; ++i) {
         const DownBlockW& d = w.down[i];
         for (size_t j = 0; j < d.resnets.size(); ++j) {
-            half_t* r = cx.h((size_t)N * h * wd * d.Cout);
+            TV r = stream_alloc(cx, (size_t)N * h * wd * d.Cout, true);
             TRY(run_resnet(cx, d.resnets[j], cur, r, N, h, wd, 1, tproj + d.resnets[j].temb_off, w.temb_total, c.norm_eps));
             cur = r;
             if (d.has_attn) {
-                half_t* t = cx.h((size_t)N * h * wd * d.Cout);
+                TV t = stream_alloc(cx, (size_t)N * h * wd * d.Cout, true);
                 TRY(run_transformer2d(cx, d.tnorm[j], d.proj_in[j], d.proj_out[j], d.tb[j], cur, t, N, h, wd, e));
                 cur = t;
             }
@@ -253,9 +255,9 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         }
         if (d.has_down) {
             const int ho = (h - 1) / 2 + 1, wo = (wd - 1) / 2 + 1;
-            half_t* y = cx.h((size_t)N * ho * wo * d.Cout);
+            TV y = stream_alloc(cx, (size_t)N * ho * wo * d.Cout, true);
             ConvOpts o; o.stride = 2;
-            TRY(run_conv(cx, d.down, cur, y, N, h, wd, o));
+            TRY(run_conv(cx, d.down, cur.m16, y, N, h, wd, o));
             cur = y; h = ho; wd = wo;
             res.push_back(cur); res_c.push_back(d.Cout); res_h.push_back(h); res_w.push_back(wd);
         }
@@ -263,11 +265,11 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     // ---- 4. mid block (:836-846) ----
     {
         const int C = c.block_out_channels[3];
-        half_t* m0 = cx.h((size_t)N * h * wd * C);
+        TV m0 = stream_alloc(cx, (size_t)N * h * wd * C, true);
         TRY(run_resnet(cx, w.mid_r0, cur, m0, N, h, wd, 1, tproj + w.mid_r0.temb_off, w.temb_total, c.norm_eps));
-        half_t* m1 = cx.h((size_t)N * h * wd * C);
+        TV m1 = stream_alloc(cx, (size_t)N * h * wd * C, true);
         TRY(run_transformer2d(cx, w.mid_tnorm, w.mid_pin, w.mid_pout, w.mid_tb, m0, m1, N, h, wd, e));
-        half_t* m2 = cx.h((size_t)N * h * wd * C);
+        TV m2 = stream_alloc(cx, (size_t)N * h * wd * C, true);
         TRY(run_resnet(cx, w.mid_r1, m1, m2, N, h, wd, 1, tproj + w.mid_r1.temb_off, w.temb_total, c.norm_eps));
         res.push_back(m2); res_c.push_back(C); res_h.push_back(h); res_w.push_back(wd);
     }
@@ -282,7 +284,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         const ConvW& z = w.zero_convs[i];
         const int HW = res_h[i] * res_w[i];
         IGemmArgs g = {};
-        g.A = res[i]; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1;
+        g.A = res[i].m16; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1;
         g.W = z.w; g.M = N * HW; g.Nout = z.Cout; g.Ktot = z.Cin; g.bias = z.b; g.scale = sc;
         g.nseg = 1;
         g.seg[0] = IGemmSeg{a.outs[i], HW, 0, z.Cout, SEG_TRANSPOSED, a.out_dt, HW, 0};
@@ -343,10 +345,12 @@ int ctrl_controlnet_forward(ctrl_controlnet* h, const void* sample, int sample_d
     // sizing pass (no launches) -> workspace; then the real pass
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
+    dry.f32stream = stream_f32_enabled();
     TRY(controlnet_run(dry, h->w, a));
     TRY(h->arena.ensure(workspace_bytes(dry), s));
     h->arena.off = 0;
     Ctx cx{&h->arena, s, false};
+    cx.f32stream = dry.f32stream;
     cx.stats_total = dry.stats_total;
     return controlnet_run(cx, h->w, a);
 }

@@ -47,7 +47,7 @@ def pack_vec(v, geglu=False):
 
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
-          res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0):
+          res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0):
     """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
@@ -62,6 +62,9 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.rows_per_img = rows_per_img
     d.res = res.data_ptr() if res is not None else None
     d.ldres = ldres
+    d.res_f32 = int(res is not None and res.dtype == torch.float32)
+    d.out16 = out16.data_ptr() if out16 is not None else None
+    d.ld16 = ld16
     d.scale = scale; d.geglu = int(geglu)
     d.nseg = len(segs)
     for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):
@@ -127,16 +130,17 @@ def groupnorm(x, gamma, beta, imgs, rows_per_img, G=32, eps=1e-5, silu=False):
     stats = torch.zeros(imgs, G, 2, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     lib = L.lib()
-    L.check(lib.ctrl_op_gn_stats(L.ptr(x), L.ptr(stats), imgs, rows_per_img, Cc, G, L.cur_stream()))
-    L.check(lib.ctrl_op_gn_apply(L.ptr(x), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(y), imgs, rows_per_img, Cc, G,
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    L.check(lib.ctrl_op_gn_stats(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), imgs, rows_per_img, Cc, G, L.cur_stream()))
+    L.check(lib.ctrl_op_gn_apply(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(y), imgs, rows_per_img, Cc, G,
                                  C.c_float(eps), int(silu), L.cur_stream()))
     return y
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
     M, Cc = x.shape
-    y = torch.empty_like(x)
-    L.check(L.lib().ctrl_op_layernorm(L.ptr(x), C.c_int64(Cc), L.ptr(gamma), L.ptr(beta), L.ptr(y), C.c_int64(Cc), M, Cc,
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    L.check(L.lib().ctrl_op_layernorm(L.ptr(x), L.dtype_code(x.dtype), C.c_int64(Cc), L.ptr(gamma), L.ptr(beta), L.ptr(y), C.c_int64(Cc), M, Cc,
                                       C.c_float(eps), L.cur_stream()))
     return y
 
@@ -180,14 +184,16 @@ def linear_small(x, w_packed, bias=None, in_silu=False, out_silu=False):
 
 def blend(xs, xt, mix):
     y = torch.empty_like(xs)
-    L.check(L.lib().ctrl_op_blend(L.ptr(xs), L.ptr(xt), L.ptr(mix), L.ptr(y), C.c_size_t(xs.numel()), L.cur_stream()))
+    L.check(L.lib().ctrl_op_blend(L.ptr(xs), L.dtype_code(xs.dtype), L.ptr(xt), L.dtype_code(xt.dtype), L.ptr(mix), L.ptr(y),
+                                  L.dtype_code(y.dtype), C.c_size_t(xs.numel()), L.cur_stream()))
     return y
 
 
 def add_rowvec(x, v, rows_per_img, vmod):
     M, Cc = x.shape
     y = torch.empty_like(x)
-    L.check(L.lib().ctrl_op_add_rowvec(L.ptr(x), L.ptr(v), C.c_int64(v.shape[-1]), L.ptr(y), C.c_size_t(M), Cc, rows_per_img, vmod, L.cur_stream()))
+    L.check(L.lib().ctrl_op_add_rowvec(L.ptr(x), L.dtype_code(x.dtype), L.ptr(v), C.c_int64(v.shape[-1]), L.ptr(y), L.dtype_code(y.dtype),
+                                       C.c_size_t(M), Cc, rows_per_img, vmod, L.cur_stream()))
     return y
 
 

@@ -68,11 +68,14 @@ typedef struct ctrl_igemm_desc {
     int32_t pad1_;
     const float* bias;  /* [Nout] or NULL */
     const float* rowvec; int32_t rowvec_ld; int32_t rows_per_img;   /* + rowvec[(m/rows_per_img)*ld + n] */
-    const void* res; int64_t ldres;                                 /* + res[m*ldres + n] (fp16) */
+    const void* res; int64_t ldres;                                 /* + res[m*ldres + n] (fp16, or fp32 if res_f32) */
     float scale;
     int32_t geglu;      /* weights packed in interleaved (hidden,gate) 16-column blocks; out width Nout/2 */
     int32_t nseg;
     int32_t act;        /* 0 none, 1 SiLU applied after bias/rowvec (before residual) */
+    int32_t res_f32;    /* residual is fp32 (the fp32 residual stream) */
+    int32_t pad3_;
+    void* out16; int64_t ld16;   /* optional fp16 row-major mirror of the (single, row-major) output: GEMM-operand copy of an fp32 stream */
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
@@ -96,10 +99,11 @@ typedef struct ctrl_tattn_desc {
 } ctrl_tattn_desc;
 int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream);
 
-int ctrl_op_gn_stats(const void* x, float* stats, int imgs, int rows_per_img, int C, int G, void* stream);
-int ctrl_op_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
+/* x_dtype: CTRL_F16 or CTRL_F32 (fp32 residual stream) */
+int ctrl_op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, void* stream);
+int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
-int ctrl_op_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+int ctrl_op_layernorm(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                       int M, int C, float eps, void* stream);
 int ctrl_op_nchw_to_nhwc(const void* x, int dtype, void* y, int N, int C, int HW, void* stream);
 int ctrl_op_nhwc_to_nchw(const void* x, void* y, int dtype, int N, int C, int HW, float scale, void* stream);
@@ -107,8 +111,10 @@ int ctrl_avgpool_nchw(const void* x, void* y, int dtype, int NC, int Hin, int Wi
 int ctrl_op_timestep_sincos(const float* t, int t_count, float* out, int N, int dim, void* stream);
 int ctrl_op_linear_small(const float* x, int64_t ldx, const void* w, const float* b, float* out, int64_t ldo,
                          int M, int N, int K, int in_silu, int out_silu, void* stream);
-int ctrl_op_blend(const void* x_spatial, const void* x_temporal, const float* mix_factor, void* y, size_t n, void* stream);
-int ctrl_op_add_rowvec(const void* x, const float* v, int64_t ldv, void* y, size_t M, int C, int rows_per_img, int vmod, void* stream);
+int ctrl_op_blend(const void* x_spatial, int xs_dtype, const void* x_temporal, int xt_dtype, const float* mix_factor,
+                  void* y, int y_dtype, size_t n, void* stream);
+int ctrl_op_add_rowvec(const void* x, int x_dtype, const float* v, int64_t ldv, void* y, int y_dtype, size_t M, int C,
+                       int rows_per_img, int vmod, void* stream);
 int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w, const float* bias, void* out,
                            int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, void* stream);
 /* load-time packers */

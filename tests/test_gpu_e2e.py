@@ -4,8 +4,9 @@
   * size-independent properties at batch 8 (batch consistency, linearity in conditioning_scale, zero slots)
 Tolerance: rel-inf = max|a-b| / max|b| per output tensor.  The HIP path stores activations
 in fp16 with fp32 accumulation / statistics / softmax; weights and inputs are fp16-representable on both sides.
-The north-star bound is 1e-3 on the adapter residuals; TOL below is the asserted bound and the achieved values are
-printed (and recorded in profiles/)."""
+Residual streams are fp32.  Asserted: adapter residuals <= 1e-3 (the north-star bound), also when
+chained behind the HIP ControlNet at the full SDXL shapes; ControlNet outputs <= 1.5e-3.  Achieved values are printed
+(and recorded in profiles/)."""
 import pytest
 import torch
 
@@ -15,7 +16,8 @@ from conftest import rel_inf
 from oracle.init import seeded_init, seeded_tensor
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-3
+TOL = 1.5e-3          # ControlNet outputs (13 tensors, ~60 layers deep)
+TOL_ADAPTER = 1e-3    # the north-star bound on the adapter residuals (BASELINE.json)
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +61,7 @@ def test_adapter_sdxl_golden(P, gpu):
     out, mid = ad([d.half().to(gpu) for d in downs], sparsity_masking=None, num_frames=1, timestep=torch.tensor(749.0),
                   encoder_hidden_states=seeded_tensor((2, 77, 2048), 290).half().to(gpu))
     assert mid is None
-    errs = [check_digest(t, d, TOL, "adapter_sdxl out %d" % i) for i, (t, d) in enumerate(zip(out, g["out"]))]
+    errs = [check_digest(t, d, TOL_ADAPTER, "adapter_sdxl out %d" % i) for i, (t, d) in enumerate(zip(out, g["out"]))]
     print("PARITY adapter_sdxl golden per-slot rel_inf: " + " ".join("%.2e" % e for e in errs))
     for i in (9, 10, 11):
         assert out[i].abs().max().item() == 0.0 and out[i].shape == downs[i].shape
@@ -71,7 +73,7 @@ def test_adapter_video_golden(P, gpu):
     downs, midin = cases.pyramid_inputs(N=8, h0=8, seed=300, with_mid=True)
     out, mid = ad([d.half().to(gpu) for d in downs], mid_block_res_sample=midin.half().to(gpu), num_frames=4,
                   timestep=torch.tensor(961.0), encoder_hidden_states=seeded_tensor((1, 1, 1024), 390).half().to(gpu))
-    errs = [check_digest(t, d, TOL, "adapter_video out %d" % i) for i, (t, d) in enumerate(zip(list(out) + [mid], g["out"]))]
+    errs = [check_digest(t, d, TOL_ADAPTER, "adapter_video out %d" % i) for i, (t, d) in enumerate(zip(list(out) + [mid], g["out"]))]
     print("PARITY adapter_video golden per-slot rel_inf: " + " ".join("%.2e" % e for e in errs))
 
 
@@ -130,7 +132,7 @@ def test_full_size_sdxl_vs_oracle_and_batch_properties(P, controlnet, gpu):
     e_ad = [rel_inf(a, b) for a, b in zip(o1[:9], ro[:9])]
     print("PARITY full-size controlnet rel_inf: " + " ".join("%.2e" % e for e in e_cn))
     print("PARITY full-size adapter    rel_inf: " + " ".join("%.2e" % e for e in e_ad))
-    assert max(e_cn) <= TOL and max(e_ad) <= TOL
+    assert max(e_cn) <= TOL and max(e_ad) <= TOL_ADAPTER
     # batch 8: every image of a replicated batch must reproduce the single-image result
     d8, m8, o8 = run(8)
     for a, b in zip(o8[:9], o1[:9]):

@@ -41,6 +41,21 @@ def test_linear(ops, gpu, M, N, K):
     report("linear %dx%dx%d" % (M, N, K), rel_inf(out, ref))
 
 
+def test_linear_f32_stream(ops, gpu):
+    """fp32 residual stream: fp32 residual in, fp32 master out + fp16 operand mirror (ctrl_igemm_desc.res_f32 / out16)"""
+    M, N, K = 700, 512, 320
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+    r = torch.randn(M, N, generator=torch.Generator().manual_seed(4))          # NOT fp16-representable
+    ref = x @ w.t() + b + r
+    wp = ops.pack_linear_w(w.to(gpu))
+    out = torch.empty(M, N, dtype=torch.float32, device=gpu)
+    mirror = torch.empty(M, N, dtype=torch.float16, device=gpu)
+    ops.igemm(x.half().to(gpu), K, wp, M, N, K, bias=b.to(gpu), res=r.to(gpu), ldres=N,
+              segs=[(out, N, 0, N, ops.SEG_ROW, 1)], out16=mirror, ld16=N)
+    report("linear f32 stream master", rel_inf(out, ref), 2e-5)
+    report("linear f32 stream mirror", rel_inf(mirror, ref))
+
+
 def test_linear_geglu(ops, gpu):
     M, K, inner = 260, 512, 2048
     x, w, b = rnd(M, K, seed=1), rnd(2 * inner, K, seed=2, scale=0.05), rnd(2 * inner, seed=3)
@@ -186,6 +201,8 @@ def test_groupnorm(ops, gpu, Cc, hw, silu):
         ref = F.silu(ref)
     out = ops.groupnorm(x.half().to(gpu), g.to(gpu), b.to(gpu), n, hw, eps=1e-5, silu=silu)
     report("groupnorm C%d hw%d" % (Cc, hw), rel_inf(out, ref))
+    out = ops.groupnorm(x.to(gpu), g.to(gpu), b.to(gpu), n, hw, eps=1e-5, silu=silu)          # fp32 stream input
+    report("groupnorm C%d hw%d (fp32 in)" % (Cc, hw), rel_inf(out, ref))
 
 
 @pytest.mark.parametrize("Cc", [512, 320, 640, 1280])
@@ -195,6 +212,8 @@ def test_layernorm(ops, gpu, Cc):
     ref = F.layer_norm(x, (Cc,), g, b, eps=1e-5)
     out = ops.layernorm(x.half().to(gpu), g.to(gpu), b.to(gpu))
     report("layernorm C%d" % Cc, rel_inf(out, ref))
+    out = ops.layernorm(x.to(gpu), g.to(gpu), b.to(gpu))                                         # fp32 stream input
+    report("layernorm C%d (fp32 in)" % Cc, rel_inf(out, ref))
 
 
 def test_layout_and_pool(ops, gpu):
@@ -235,6 +254,7 @@ def test_blend_addvec(ops, gpu):
     mix = torch.tensor([0.3])
     al = torch.sigmoid(mix)
     report("blend", rel_inf(ops.blend(a.half().to(gpu), b.half().to(gpu), mix.to(gpu)), al * a + (1 - al) * b))
+    report("blend fp32", rel_inf(ops.blend(a.to(gpu), b.to(gpu), mix.to(gpu)), al * a + (1 - al) * b), 1e-6)
     v = rnd(4, 320, seed=3)
     ref = a.reshape(4, 25, 320) + v[:, None]
     report("add_rowvec", rel_inf(ops.add_rowvec(a.half().to(gpu), v.to(gpu), 25, 4), ref.reshape(100, 320)))
