@@ -26,6 +26,7 @@ class IGemmDesc(C.Structure):
                 ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_ld", C.c_int32), ("rows_per_img", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int64), ("scale", C.c_float), ("geglu", C.c_int32),
                 ("nseg", C.c_int32), ("act", C.c_int32), ("res_f32", C.c_int32), ("pad3_", C.c_int32),
+                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
                 ("out16", C.c_void_p), ("ld16", C.c_int64), ("seg", IGemmSeg * 3)]
 
 

@@ -35,7 +35,7 @@ __device__ __forceinline__ int chunk_swz(int row) {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // per-wave tile
@@ -57,7 +57,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
     // XCD-aware bijective remap: each XCD (blockIdx % 8) walks a contiguous range of tiles so the
     // A rows / weight panels it re-reads stay in that XCD's private L2.
     const int nblk = ntm * ntn;
-    int bid = blockIdx.x;
+    // split-K: blockIdx.x = split * nblk + tile; every split accumulates a contiguous range of k-tiles and writes its
+    // fp32 partial tile to slab `split` of the scratch buffer (reduced + finished by splitk_finish_kernel)
+    const int split = blockIdx.x / nblk;
+    int bid = blockIdx.x - split * nblk;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
@@ -116,10 +119,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
 
     typedef const void __attribute__((address_space(1)))* gptr_t;
     typedef void __attribute__((address_space(3)))* lptr_t;
+    const int kt_begin = split * ((a.Ktot / BK + splitk - 1) / splitk);
 
     // asynchronous global -> LDS staging of k-tile kt into buffer buf (no VGPR round trip)
     auto stage = [&](int kt, int buf) {
-        const int k0 = kt * BK;
+        const int k0 = (kt_begin + kt) * BK;
         int tap = 0, c0 = k0;
         if (MODE != IG_ROWS) { tap = k0 / a.Cin; c0 = k0 - tap * a.Cin; }
         int ky = 0, kx = 0;
@@ -158,7 +162,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.Ktot / BK;
+    const int nk_total = a.Ktot / BK;
+    const int nk_per = (nk_total + splitk - 1) / splitk;
+    const int kt_begin_ = split * nk_per;
+    const int nk = min(nk_per, nk_total - kt_begin_);
     // NSTAGE-deep LDS ring: D = NSTAGE-1 tiles are in flight; a counted vmcnt (never 0 in steady state) retires only
     // the tile about to be consumed, so the LDS-DMA of later tiles stays in flight across the barrier.
     constexpr int D = NSTAGE - 1;
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
                 for (int k = 1; k < 3; ++k)
                     if (k < a.nseg && ocol >= a.seg[k].col_begin) si = k;
                 const IGemmSeg sg = a.seg[si];
-                const size_t o = (size_t)row * sg.ld + (ocol - sg.col_begin);
+                const size_t o = (size_t)row * sg.ld + (ocol - sg.col_begin) + (size_t)split * a.M * a.Nout;   // split > 0 only for fp32 slabs
                 if (sg.dtype == DT_F16) {
                     h8 pk;
 #pragma unroll
@@ -434,6 +441,61 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
     (void)NSTEP;
 }
 
+// split-K tail: out = epilogue( sum_s slab[s] ), 8 consecutive columns per thread (row-major outputs only)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmArgs a, const float* __restrict__ ws, int splitk) {
+    const int nc8 = a.Nout >> 3;
+    const size_t total = (size_t)a.M * nc8, slab = (size_t)a.M * a.Nout;
+    const IGemmSeg sg = a.seg[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / nc8;
+        const int col = (int)(i - row * nc8) * 8;
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splitk; ++s) {
+            const float* p = ws + s * slab + row * a.Nout + col;
+            const f4 u = *(const f4*)p, v = *(const f4*)(p + 4);
+            x[0] += u[0]; x[1] += u[1]; x[2] += u[2]; x[3] += u[3]; x[4] += v[0]; x[5] += v[1]; x[6] += v[2]; x[7] += v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (a.bias) x[j] += a.bias[col + j];
+            if (a.rowvec) x[j] += a.rowvec[(row / a.rows_per_img) * a.rowvec_ld + col + j];
+            if (a.act == 1) x[j] = silu_f(x[j]);
+        }
+        if (a.res) {
+            if (a.res_f32) {
+                const float* rp = (const float*)a.res + row * a.ldres + col;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] += rp[j];
+            } else {
+                const h8 rr = *(const h8*)((const half_t*)a.res + row * a.ldres + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] += (float)rr[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] *= a.scale;
+        const size_t o = row * sg.ld + col;
+        if (sg.dtype == DT_F32) {
+            *(f4*)((float*)sg.out + o) = f4{x[0], x[1], x[2], x[3]};
+            *(f4*)((float*)sg.out + o + 4) = f4{x[4], x[5], x[6], x[7]};
+        } else if (sg.dtype == DT_F16) {
+            h8 pk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = (half_t)x[j];
+            *(h8*)((half_t*)sg.out + o) = pk;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ((u16*)sg.out)[o + j] = f32_to_bf16(x[j]);
+        }
+        if (a.out16) {
+            h8 pk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = (half_t)x[j];
+            *(h8*)((half_t*)a.out16 + row * a.ld16 + col) = pk;
+        }
+    }
+}
+
 const half_t* zero_page() {
     static half_t* z = nullptr;
     if (!z) {
@@ -444,7 +506,7 @@ const half_t* zero_page() {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
-int launch_cfg2(const IGemmArgs& a, hipStream_t s) {
+int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
     constexpr int BNP = (BN + PASSROWS - 1) / PASSROWS * PASSROWS;
     constexpr size_t ring = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
@@ -462,8 +524,24 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s) {
     PROF_WORK(2.0 * a.M * a.Nout * a.Ktot, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     prof_detail("M%d N%d K%d taps%d tile%dx%dx%d swap%d geglu%d", a.M, a.Nout, a.Ktot, a.taps, BM, BN, BK, (int)SWAP, a.geglu);
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
+    if (splitk > 1) {
+        // partial sums go to fp32 slabs [splitk][M][Nout]; every epilogue term is applied once, by the finish kernel
+        IGemmArgs p = a;
+        p.bias = nullptr; p.rowvec = nullptr; p.res = nullptr; p.res_f32 = 0; p.act = 0; p.scale = 1.f; p.out16 = nullptr;
+        p.nseg = 1;
+        p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
+        prof_detail("M%d N%d K%d taps%d tile%dx%dx%d splitk%d", a.M, a.Nout, a.Ktot, a.taps, BM, BN, BK, splitk);
+        LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn * splitk),
+               dim3(WAVES_M * WAVES_N * 64), smem, s, p, ntm, ntn, zeros, splitk);
+        const size_t total = (size_t)a.M * (a.Nout / 8);
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        PROF_WORK(0, 4.0 * splitk * a.M * a.Nout);
+        LAUNCH("splitk_finish", splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)a.splitk_ws, splitk);
+        return 0;
+    }
     LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
-           a, ntm, ntn, zeros);
+           a, ntm, ntn, zeros, 1);
     return 0;
 }
 
@@ -481,6 +559,22 @@ bool can_swap(const IGemmArgs& a) {
     return swap;
 }
 
+}  // namespace
+// number of K splits op_igemm will use for this problem (1 = none); callers size splitk_ws = factor*M*Nout*4 bytes
+int igemm_splitk_factor(const IGemmArgs& a) {
+    if (a.geglu || a.nseg != 1 || a.seg[0].fmt != SEG_ROW || a.Nout % 64 != 0 || a.Cin % 32 != 0 || a.mode == IG_TEMPORAL) return 1;
+    const int bn = (a.Nout % 320 == 0) ? 320 : 256;
+    if (a.Nout % bn != 0) return 1;
+    const long tiles = (long)((a.M + 255) / 256) * (a.Nout / bn);
+    const int nk = a.Ktot / 32;
+    if (tiles >= 160 || nk < 64) return 1;
+    int sk = (int)((256 + tiles - 1) / tiles);
+    if (sk > 16) sk = 16;
+    while (sk > 1 && nk / sk < 16) --sk;
+    return sk;
+}
+namespace {
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE>
 int launch_cfg(const IGemmArgs& a, hipStream_t s) {
     if (can_swap(a)) return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, true>(a, s);
@@ -495,6 +589,15 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Nout + bn - 1) / bn); };
     auto eff = [&](int bn) { return (double)a.Nout / (double)(((a.Nout + bn - 1) / bn) * bn); };
     // 256x256 (8 waves, 128x64 per wave): fewest LDS bytes per FLOP -- the limiter of the smaller tiles on this chip
+    // split-K: small-M / long-K problems (the ControlNet's low-resolution 3x3 convs) leave most CUs idle with 256-row
+    // tiles and run far below MFMA speed with small tiles; splitting the reduction fills the chip with the wide tile
+    {
+        const int sk = (a.splitk_ws && can_swap(a)) ? igemm_splitk_factor(a) : 1;
+        if (sk > 1 && (size_t)a.splitk_ws_bytes >= (size_t)sk * a.M * a.Nout * sizeof(float) && (((uintptr_t)a.splitk_ws & 15) == 0)) {
+            if (a.Nout % 320 == 0) return launch_cfg2<256, 320, 32, 2, 4, 4, MODE, true>(a, s, sk);
+            return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
+        }
+    }
     // (vector-epilogue variant only: the scalar-epilogue one does not fit the register file at this tile size)
     if (getenv("CTRL_IGEMM_CFG") && atoi(getenv("CTRL_IGEMM_CFG")) == 1 && tiles(128, 256) >= 200 && eff(256) > 0.9 && can_swap(a))
         return launch_cfg2<128, 256, 32, 2, 2, 3, MODE, true>(a, s);     // experiment: 4 waves x (64x128), 2 blocks/CU

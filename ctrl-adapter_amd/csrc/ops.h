@@ -15,6 +15,8 @@ enum { SEG_ROW = 0, SEG_TRANSPOSED = 1 };
 typedef ctrl_igemm_seg IGemmSeg;     // see include/ctrl_hip.h for field docs
 typedef ctrl_igemm_desc IGemmArgs;
 int op_igemm(const IGemmArgs& a, hipStream_t s);
+// K-split factor op_igemm would use given scratch (1 = no split); scratch needed = factor * M * Nout * sizeof(float)
+int igemm_splitk_factor(const IGemmArgs& a);
 // convenience: plain linear out[M][N] (fp16 row-major) = A[M][K] * W[N][K]^T + bias
 int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, half_t* out, long ldo,
               int M, int N, int K, const half_t* res, long ldres, hipStream_t s);

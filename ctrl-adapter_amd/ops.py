@@ -47,7 +47,7 @@ def pack_vec(v, geglu=False):
 
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
-          res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0):
+          res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None):
     """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
@@ -64,6 +64,8 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.ldres = ldres
     d.res_f32 = int(res is not None and res.dtype == torch.float32)
     d.out16 = out16.data_ptr() if out16 is not None else None
+    d.splitk_ws = splitk_ws.data_ptr() if splitk_ws is not None else None
+    d.splitk_ws_bytes = splitk_ws.numel() * splitk_ws.element_size() if splitk_ws is not None else 0
     d.ld16 = ld16
     d.scale = scale; d.geglu = int(geglu)
     d.nseg = len(segs)
@@ -85,7 +87,7 @@ def linear(x, w_packed, bias=None, res=None, geglu=False):
 
 
 def conv2d(x_nhwc, w_packed, Cout, taps=9, stride=1, up=1, bias=None, rowvec=None, res=None, scale=1.0,
-           out_nchw_dtype=None):
+           out_nchw_dtype=None, splitk_ws=None):
     """x [N][H][W][Cin] fp16 -> [N][Ho][Wo][Cout] fp16 (or NCHW in out_nchw_dtype)"""
     N, H, W, Cin = x_nhwc.shape
     pad = 1 if taps == 9 else 0
@@ -100,7 +102,7 @@ def conv2d(x_nhwc, w_packed, Cout, taps=9, stride=1, up=1, bias=None, rowvec=Non
         out = torch.empty(N, Cout, Ho, Wo, dtype=out_nchw_dtype, device=x_nhwc.device)
         segs = [(out, Ho * Wo, 0, Cout, SEG_TRANSPOSED, Ho * Wo)]
     igemm(x_nhwc, Cin, w_packed, M, Cout, Cin, taps=taps, mode=IG_CONV2D, geom=geom, bias=bias, rowvec=rowvec,
-          rows_per_img=Ho * Wo, res=res, ldres=Cout, scale=scale, segs=segs)
+          rows_per_img=Ho * Wo, res=res, ldres=Cout, scale=scale, segs=segs, splitk_ws=splitk_ws)
     return out
 
 

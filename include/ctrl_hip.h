@@ -75,6 +75,7 @@ typedef struct ctrl_igemm_desc {
     int32_t act;        /* 0 none, 1 SiLU applied after bias/rowvec (before residual) */
     int32_t res_f32;    /* residual is fp32 (the fp32 residual stream) */
     int32_t pad3_;
+    void* splitk_ws; int64_t splitk_ws_bytes;   /* optional fp32 scratch: enables split-K for small-M / long-K problems */
     void* out16; int64_t ld16;   /* optional fp16 row-major mirror of the (single, row-major) output: GEMM-operand copy of an fp32 stream */
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;

@@ -83,6 +83,23 @@ def test_conv3x3(ops, gpu, cin, cout, h, stride, up):
     report("conv3x3 %d->%d s%d up%d" % (cin, cout, stride, up), rel_inf(out.permute(0, 3, 1, 2), ref))
 
 
+@pytest.mark.parametrize("cin,cout,h,n", [(1280, 1280, 8, 8), (640, 640, 16, 8), (1280, 1280, 16, 2)])
+def test_conv3x3_splitk(ops, gpu, cin, cout, h, n):
+    """small-M / long-K convs (ControlNet low-resolution blocks) take the split-K path when scratch is provided"""
+    x = rnd(n, cin, h, h, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=0.02)
+    b, temb, r = rnd(cout, seed=3), rnd(n, cout, seed=4), rnd(n, cout, h, h, seed=5)
+    ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + r
+    wp = ops.pack_conv_w(w.to(gpu))
+    xh = x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    rh = r.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    ws = torch.empty(16 * n * h * h * cout, dtype=torch.float32, device=gpu)
+    out = ops.conv2d(xh, wp, cout, taps=9, bias=b.to(gpu), rowvec=temb.to(gpu), res=rh, splitk_ws=ws)
+    report("conv3x3 split-K %d->%d @%d n%d" % (cin, cout, h, n), rel_inf(out.permute(0, 3, 1, 2), ref))
+    out2 = ops.conv2d(xh, wp, cout, taps=9, bias=b.to(gpu), rowvec=temb.to(gpu), res=rh)       # same problem, no split
+    report("conv3x3 no-split %d->%d @%d n%d" % (cin, cout, h, n), rel_inf(out2.permute(0, 3, 1, 2), ref))
+
+
 def test_conv1x1_nchw_out_scaled(ops, gpu):
     n, cin, cout, h = 2, 320, 320, 16
     x, w, b = rnd(n, cin, h, h, seed=1), rnd(cout, cin, 1, 1, seed=2, scale=0.05), rnd(cout, seed=3)

@@ -47,12 +47,16 @@ def main():
         print("gemm M%d N%d K%d geglu=%d: %.3f ms  %.1f TFLOP/s" % (M, N, K, geglu, ms, 2.0 * M * N * K / ms / 1e9))
     print("== conv3x3 ==")
     for (n, c, co, h, up) in [(8, 320, 320, 128, 1), (8, 320, 320, 64, 2), (8, 640, 640, 64, 1), (8, 1280, 1280, 32, 1),
-                              (8, 320, 320, 64, 1), (8, 1280, 1280, 8, 1)]:
+                              (8, 320, 320, 64, 1), (8, 1280, 1280, 8, 1), (8, 1280, 1280, 16, 1), (8, 640, 640, 32, 1)]:
         x = R(n, h, h, c)
         w = R(co, 9 * c)
         ms = timeit(lambda: ops.conv2d(x, w, co, taps=9, up=up), iters=5)
         ho = h * up
         print("conv3x3 n%d %d->%d @%d(up%d): %.3f ms  %.1f TFLOP/s" % (n, c, co, ho, up, ms, 2.0 * n * ho * ho * co * 9 * c / ms / 1e9))
+        if n * ho * ho <= 32768:
+            ws = torch.empty(16 * n * ho * ho * co, dtype=torch.float32, device=dev)
+            ms = timeit(lambda: ops.conv2d(x, w, co, taps=9, up=up, splitk_ws=ws), iters=5)
+            print("   + split-K scratch: %.3f ms  %.1f TFLOP/s" % (ms, 2.0 * n * ho * ho * co * 9 * c / ms / 1e9))
     print("== norms (HBM) ==")
     for (n, hw, c) in [(8, 16384, 320), (8, 4096, 640)]:
         x = R(n, hw, c)
