@@ -158,13 +158,20 @@ def main():
                           "gbs": round(v[3] / reps / (ms * 1e-3) / 1e9, 1) if v[3] else None}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         kd, raw = kernels[dom], prof.rows[dom]
+        # HBM traffic per launch of that class: PMC FETCH_SIZE/WRITE_SIZE passes of this same command, measured with
+        # rocprofv3 (cannot run inside the benchmark), corrected per MI355X_MICROARCH.md, committed under profiles/
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if workload == "sdxl" and n == 8 and os.path.exists(tfile):
+            with open(tfile) as fh:
+                traffic = json.load(fh)["classes"].get(dom, {}).get("hbm_bytes_per_launch_corrected")
         if raw[2] > 0:      # MFMA-bound class (implicit GEMM / flash attention): algorithmic FLOPs / HIP-event time
             roof = {"kernel": dom, "bound": "mfma", "achieved": kd["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(kd["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(kd["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "flops_per_launch": raw[2] / raw[1], "avg_launch_ms": raw[0] / raw[1], "launches_per_step": kd["launches_per_step"]}
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": kd["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kd["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(kd["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": raw[3] / raw[1], "avg_launch_ms": raw[0] / raw[1], "launches_per_step": kd["launches_per_step"]}
 
     # ---- cpu_baseline leg: the fp32 oracle on the host cores, bounded sample (rank 0, N=1 only) ----
