@@ -192,7 +192,7 @@ def main():
             d, m = oc(s, torch.tensor(499.0), xc["ehs_c"], xc["cond"])
             return oa(d, num_frames=1, timestep=torch.tensor(499.0), encoder_hidden_states=xc["ehs_a"])
         c0 = time.perf_counter()
-        reps = 1                                    # bounded sample: one image, one pass (tens of seconds)
+        reps = 4                                    # bounded sample: one image of the batch, ~10-15 s of CPU work
         for _ in range(reps):
             cpu_step()
         per_img = (time.perf_counter() - c0) / reps
