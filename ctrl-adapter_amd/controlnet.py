@@ -98,9 +98,16 @@ class ControlNetModel(ParamTreeModule):
         ehs = encoder_hidden_states
         if ehs.dim() != 3 or ehs.shape[0] != N or ehs.shape[2] != self.config.cross_attention_dim:
             raise ValueError("encoder_hidden_states must be [N, L, %d]" % self.config.cross_attention_dim)
+        out_dtype = sample.dtype if sample.dtype in (torch.float16, torch.bfloat16, torch.float32) else self.dtype
+        if isinstance(conditioning_scale, (int, float)) and conditioning_scale == 0:
+            # control switched off for this step (controlnet_keep == 0, sdxl pipeline :1262-1266): every output of the
+            # reference is `conv(x) * 0`; return the zeros without running the network (SURVEY.md note N8)
+            down = [torch.zeros(N, c, max(Hs // f, 1), max(Ws // f, 1), dtype=out_dtype, device=sample.device)
+                    for c, f in zip(self._slot_channels, self._slot_factor)]
+            mid = torch.zeros(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device)
+            return ControlNetOutput(down, mid) if return_dict else (down, mid)
         plan = self._ensure_plan()
         t = timesteps_to_device_f32(timestep, N, sample.device)
-        out_dtype = sample.dtype if sample.dtype in (torch.float16, torch.bfloat16, torch.float32) else self.dtype
         outs = [torch.empty(N, c, max(Hs // f, 1), max(Ws // f, 1), dtype=out_dtype, device=sample.device)
                 for c, f in zip(self._slot_channels, self._slot_factor)]
         outs.append(torch.empty(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device))

@@ -50,6 +50,8 @@ def test_controlnet_output_container_and_dtypes(controlnet, gpu):
     assert out[0][0].dtype == torch.float32          # fp32 boundary tensors in -> fp32 out
     with pytest.raises(ValueError):
         controlnet(inp["sample"].to(gpu), 999, inp["encoder_hidden_states"].to(gpu), inp["controlnet_cond"][:, :, :32].to(gpu))
+    z = controlnet(inp["sample"].to(gpu), 999, inp["encoder_hidden_states"].to(gpu), inp["controlnet_cond"].to(gpu), conditioning_scale=0)
+    assert all(t.abs().max().item() == 0.0 for t in list(z[0]) + [z[1]]) and z[0][4].shape == out[0][4].shape
     with pytest.raises(RuntimeError):
         controlnet(inp["sample"], 999, inp["encoder_hidden_states"], inp["controlnet_cond"])     # CPU tensors: no fallback
 
@@ -143,3 +145,89 @@ def test_full_size_sdxl_vs_oracle_and_batch_properties(P, controlnet, gpu):
     s = P.pool_latents(lat.half().to(gpu), (64, 64))
     dh, mh = controlnet(s, t, ehs_c.half().to(gpu), cond.half().to(gpu), conditioning_scale=0.25, return_dict=False)
     assert max(rel_inf(a.float() * 4, b) for a, b in zip(dh, d1)) < 2e-3
+
+
+def test_multi_condition_router_pipeline_vs_oracle(P, gpu):
+    """BASELINE.json config 5 in miniature: K=3 ControlNets (MultiControlNetModel) -> router weights -> merge of the
+    active experts (inference quirk N6 reproduced) -> video adapter, against the same chain through the CPU oracle."""
+    from oracle.controlnet import ControlNetOracle, MultiControlNetOracle
+    from oracle.adapter import ControlNetAdapterOracle
+    from oracle.router import RouterOracle, merge_inference
+    torch.set_grad_enabled(False)
+    F_, N, hs = 4, 8, 8                      # 2 clips x 4 frames, 8x8 latents
+    inp = [cases.controlnet_inputs(N=N, hs=hs, seed=700 + 10 * k) for k in range(3)]
+    sample = inp[0]["sample"]
+    ehs_c = inp[0]["encoder_hidden_states"]
+    conds = [i["controlnet_cond"] for i in inp]
+    t = torch.tensor(961.0)
+    masks = [1, 0, 1]
+    act = [0, 2]
+    # ---- oracle chain ----
+    o_nets = [seeded_init(ControlNetOracle(**cases.CONTROLNET_KW).eval(), seed=50 + k) for k in range(3)]
+    o_multi = MultiControlNetOracle([o_nets[k] for k in act])
+    o_router = seeded_init(RouterOracle(num_experts=3, router_type="simple_weights", num_routers=12).eval(), seed=44)
+    o_ad = seeded_init(ControlNetAdapterOracle(**cases.ADAPTER_VIDEO).eval(), seed=33)
+    od, om = o_multi(sample, t, ehs_c, [conds[k] for k in act], [1.0, 1.0], skip_conv_in=True)
+    dw, mw = o_router(sparse_mask=masks)
+    md, mm = merge_inference(od, om, dw, mw, masks, F_)
+    e_img = seeded_tensor((1, 1, 1024), 391)
+    ro, rmid = o_ad(md, mid_block_res_sample=mm, num_frames=F_, timestep=t, encoder_hidden_states=e_img)
+    # ---- HIP chain ----
+    nets = [seeded_init(P.ControlNetModel(**cases.CONTROLNET_KW), seed=50 + k).to(gpu) for k in act]
+    multi = P.MultiControlNetModel(nets)
+    router = seeded_init(P.ControlNetRouter(num_experts=3, router_type="simple_weights", num_routers=12), seed=44).to(gpu)
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_VIDEO), seed=33).to(gpu)
+    gd, gm = multi(sample.half().to(gpu), t, ehs_c.half().to(gpu), [conds[k].half().to(gpu) for k in act], [1.0, 1.0],
+                   return_dict=False, skip_conv_in=True)
+    gdw, gmw = router(sparse_mask=masks)
+    gmd, gmm = router.merge(gd, gm, gdw, gmw, masks, num_frames=F_, inference_quirk=True)
+    go, gmid = ad(gmd, mid_block_res_sample=gmm, num_frames=F_, timestep=t, encoder_hidden_states=e_img.half().to(gpu))
+    errs = [rel_inf(a, b) for a, b in zip(list(go) + [gmid], list(ro) + [rmid])]
+    print("PARITY config-5 chain (3 nets, router, merge, video adapter) rel_inf: " + " ".join("%.2e" % e for e in errs))
+    assert max(errs) <= 1.5e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_boundary_dtypes(P, controlnet, gpu, dt):
+    """fp32 and bf16 tensors at the boundary (the reference runs bf16 autocast): converted in-kernel, same results"""
+    inp = cases.controlnet_inputs()
+    args = lambda d: (inp["sample"].to(d).to(gpu), inp["timestep"].to(gpu), inp["encoder_hidden_states"].to(d).to(gpu),
+                      inp["controlnet_cond"].to(d).to(gpu))
+    ref_d, ref_m = controlnet(*args(torch.float16), return_dict=False)
+    d, m = controlnet(*args(dt), return_dict=False)
+    assert d[0].dtype == dt and m.dtype == dt
+    # against the golden vectors (NOT run-to-run: the ~1e-3 residual error is accumulated rounding noise that any 1e-7
+    # perturbation -- e.g. the order of the GroupNorm statistics atomics -- re-randomises)
+    g = load_golden("controlnet_sd15.pt")["runs"]["plain"]
+    tol = TOL if dt == torch.float32 else 8e-3           # bf16 outputs carry 2^-8 output rounding
+    for i, (t_, dg) in enumerate(zip(list(d) + [m], g)):
+        check_digest(t_, dg, tol, "controlnet[%s] out %d" % (dt, i))
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+    o16, _ = ad(ref_d, num_frames=1, timestep=749, encoder_hidden_states=seeded_tensor((2, 77, 2048), 290).half().to(gpu))
+    odt, _ = ad([x.to(dt) for x in ref_d], num_frames=1, timestep=749,
+                encoder_hidden_states=seeded_tensor((2, 77, 2048), 290).to(dt).to(gpu))
+    assert odt[0].dtype == dt
+    assert max(rel_inf(a, b) for a, b in zip(odt[:9], o16[:9])) < (2e-3 if dt == torch.float32 else 1e-2)
+
+
+def test_fourteen_frames_and_single_clip_per_sample_context(P, gpu):
+    """SVD's script uses 14 frames (inference_scripts/svd/svd_inference_depth.sh:8): a non-power-of-two frame count,
+    one clip, per-frame encoder states (supported for a single clip)"""
+    from oracle.adapter import ControlNetAdapterOracle
+    torch.set_grad_enabled(False)
+    F_ = 14
+    cfg = dict(cases.ADAPTER_VIDEO)
+    cfg.update(add_adapter_location_B=False, add_adapter_location_C=False, add_adapter_location_D=False, add_adapter_location_M=False)
+    ad = seeded_init(P.ControlNetAdapter(**cfg), seed=35).to(gpu)
+    oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=35)
+    downs, _ = cases.pyramid_inputs(N=F_, h0=8, seed=800, with_mid=False)
+    ehs = seeded_tensor((F_, 1, 1024), 801)
+    ts = torch.full((F_,), 500.0)
+    out, mid = ad([d.half().to(gpu) for d in downs], num_frames=F_, timestep=ts.to(gpu), encoder_hidden_states=ehs.half().to(gpu))
+    ro, _ = oa(downs, num_frames=F_, timestep=ts, encoder_hidden_states=ehs)
+    assert mid is None
+    errs = [rel_inf(a, b) for a, b in zip(out[:3], ro[:3])]
+    print("PARITY 14-frame clip rel_inf: " + " ".join("%.2e" % e for e in errs))
+    assert max(errs) <= 1e-3
+    for i in range(3, 12):
+        assert out[i].abs().max().item() == 0.0
