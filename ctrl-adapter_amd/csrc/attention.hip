@@ -19,6 +19,7 @@
 //   tiles with an XOR chunk swizzle on the source address and on the fragment read (bank-conflict-free b128 reads).
 //   Contract: the V^T buffer's pad columns [Lk, roundup8(Lk)) must hold finite values (the producer zero-fills).
 #include "ops.h"
+#include <cstdlib>
 
 namespace {
 
@@ -34,13 +35,14 @@ __device__ __forceinline__ int tile_swz(int row) {
     return ROW_CHUNKS == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_t* zeros) {
+template <int D, int NW, bool BATCH>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(AttnArgs a, const half_t* zeros) {
     constexpr int DP = (D + 31) / 32 * 32;      // padded head dim (zero filled): 64, 64, 96, 160
     constexpr int KS = DP / 16;                 // k-steps of the 32x32x16 MFMA for QK^T
     constexpr int DB = DP / 32;                 // 32-row output blocks of O^T
     constexpr int KCPR = DP / 8;                // 16-B chunks per K-tile row
-    constexpr int PASSES = DP / 32;             // 4-KiB staging passes per tile (K tile = V^T tile = 64*DP halfs)
+    constexpr int PASSES = DP / (8 * NW);       // staging passes per tile: NW KiB each (K tile = V^T tile = 64*DP halfs)
+    static_assert(DP % (8 * NW) == 0, "tile bytes must be a multiple of the workgroup's staging pass");
     constexpr int NSTAGE = 3;                   // LDS ring depth: 2 tiles in flight
     constexpr int LPT = 2 * PASSES;             // global_load_lds per lane per tile
     constexpr int TILE = 64 * DP;               // halfs per K (or V^T) tile
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
     const int Lq = a.Lq, Lk = a.Lk;
     const float c = a.scale * 1.4426950408889634f;   // softmax in the exp2 domain
 
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
     bool k_dok[PASSES], v_dok[PASSES];
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
-        const int ci = (i * 4 + wave) * 64 + lane;            // chunk index inside the tile
+        const int ci = (i * NW + wave) * 64 + lane;           // chunk index inside the tile
         const int kr = ci / KCPR, kp = ci - kr * KCPR;
         const int ksrc = kp ^ tile_swz<KCPR>(kr);
         k_row[i] = kr;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
         for (int i = 0; i < PASSES; ++i) {
             const bool ok = k_dok[i] && (kt0 + k_row[i] < Lk);
             const half_t* src = ok ? (Kbase + (size_t)kt0 * a.ldk + k_off[i]) : zeros;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Kb + (i * 4 + wave) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Kb + (i * NW + wave) * 512), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
             // V^T pad columns being finite (the producer zero-fills them) -- their probabilities are exactly 0
             const bool ok = v_dok[i] && (kt0 + v_key[i] < Lk);
             const half_t* src = ok ? (Vbase + kt0 + v_off[i]) : zeros;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vb + (i * 4 + wave) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vb + (i * NW + wave) * 512), 16, 0, 0);
         }
     };
 
@@ -155,27 +157,38 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
 
         // ---- S^T = K . Q^T  (two 32-key blocks); all K and V^T fragment reads of the tile are issued up front so the
         //      LDS latency is paid once (K) or hidden under the softmax (V^T) ----
-        h8 kfr[KS][2];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) kfr[ks][mb] = *(const h8*)(Kb + k_rd[mb] + (((ks * 2 + hi) ^ k_sw[mb]) << 3));
-        h8 vfr[4][DB];
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-            for (int db = 0; db < DB; ++db) vfr[c4][db] = *(const h8*)(Vb + v_rd[db] + (((c4 * 2 + hi) ^ v_sw[db]) << 3));
-        __builtin_amdgcn_sched_barrier(0);
         f16v sacc[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[mb][r] = 0.f;
+        h8 vfr[4][DB];
+        if constexpr (BATCH) {
+            h8 kfr[KS][2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[ks][mb], qf[ks], sacc[mb], 0, 0, 0);
+                for (int mb = 0; mb < 2; ++mb) kfr[ks][mb] = *(const h8*)(Kb + k_rd[mb] + (((ks * 2 + hi) ^ k_sw[mb]) << 3));
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) vfr[c4][db] = *(const h8*)(Vb + v_rd[db] + (((c4 * 2 + hi) ^ v_sw[db]) << 3));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[ks][mb], qf[ks], sacc[mb], 0, 0, 0);
+        } else {
+            // low-register form (2 workgroups of 8 waves per CU): fragments are fetched right before their MFMAs;
+            // four resident waves per SIMD hide the LDS latency instead of a register-resident batch
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const h8 kf = *(const h8*)(Kb + k_rd[mb] + (((ks * 2 + hi) ^ k_sw[mb]) << 3));
+                    sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[mb], 0, 0, 0);
+                }
         }
         // register r of block mb holds key  kt0 + 32*mb + 16*(r>>3) + 8*hi + (r&7)  (see krow_perm)
         const int kt0 = t * 64;
@@ -224,8 +237,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a, const half_
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-                for (int db = 0; db < DB; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr[mb * 2 + s2][db], pf[mb][s2], o[db], 0, 0, 0);
+                for (int db = 0; db < DB; ++db) {
+                    const h8 vf = BATCH ? vfr[mb * 2 + s2][db]
+                                        : *(const h8*)(Vb + v_rd[db] + ((((mb * 2 + s2) * 2 + hi) ^ v_sw[db]) << 3));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[mb][s2], o[db], 0, 0, 0);
+                }
             }
         cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
     }
@@ -260,21 +276,21 @@ const half_t* attn_zero_page() {
     return z;
 }
 
-template <int D>
+template <int D, int NW, bool BATCH>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr size_t smem = (size_t)3 * 2 * 64 * DP * sizeof(half_t);
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D, NW, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
     const half_t* zeros = attn_zero_page();
     CTRL_CHECK(zeros != nullptr, "flash_attn: could not allocate the zero page");
-    dim3 grid((a.Lq + 127) / 128, a.heads, a.B);
+    dim3 grid((a.Lq + NW * 32 - 1) / (NW * 32), a.heads, a.B);
     PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
-    prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
-    LAUNCH("flash_attn", (flash_attn_kernel<D>), grid, dim3(256), smem, s, a, zeros);
+    prof_detail("B%d h%d D%d Lq%d Lk%d nw%d", a.B, a.heads, a.D, a.Lq, a.Lk, NW);
+    LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH>), grid, dim3(NW * 64), smem, s, a, zeros);
     return 0;
 }
 
@@ -379,10 +395,13 @@ int op_flash_attn(const AttnArgs& a, hipStream_t s) {
     CTRL_CHECK((((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.Vt) & 15) == 0 && ((uintptr_t)a.O & 7) == 0,
                "flash_attn: pointers must be 16-byte aligned");
     switch (a.D) {
-        case 64: return launch_attn<64>(a, s);
-        case 40: return launch_attn<40>(a, s);
-        case 80: return launch_attn<80>(a, s);
-        case 160: return launch_attn<160>(a, s);
+        case 64:
+            // long sequences: 256 queries per workgroup halve the K/V LDS-DMA traffic per FLOP (the limiter at L = 16384)
+            if (a.Lq >= 2048 && !getenv("CTRL_ATTN_NW4")) return launch_attn<64, 8, false>(a, s);
+            return launch_attn<64, 4, true>(a, s);
+        case 40: return launch_attn<40, 4, true>(a, s);
+        case 80: return launch_attn<80, 4, true>(a, s);
+        case 160: return launch_attn<160, 4, true>(a, s);
         default: CTRL_FAIL("flash_attn: unsupported head_dim " + std::to_string(a.D) + " (supported: 40, 64, 80, 160)");
     }
 }

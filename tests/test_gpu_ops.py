@@ -175,7 +175,7 @@ def _attn_ref(q, k, v, heads):
 
 
 @pytest.mark.parametrize("D,heads,Lq,Lk", [(64, 5, 256, 256), (64, 5, 200, 77), (64, 10, 1024, 1024), (40, 8, 256, 256),
-                                           (80, 8, 256, 77), (160, 8, 64, 64), (160, 8, 256, 77), (40, 8, 4096, 4096)])
+                                           (80, 8, 256, 77), (160, 8, 64, 64), (160, 8, 256, 77), (40, 8, 4096, 4096), (64, 5, 2100, 2100), (64, 2, 4096, 77)])
 def test_flash_attn(ops, gpu, D, heads, Lq, Lk):
     B = 2
     Cc = heads * D
