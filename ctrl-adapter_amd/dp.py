@@ -32,7 +32,10 @@ def shard(total_units, rank, world):
 def barrier(sync_cuda=True):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
     if sync_cuda and torch.cuda.is_available():
         torch.cuda.synchronize()
 
