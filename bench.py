@@ -38,18 +38,6 @@ VIDEO_ADAPTER = dict(backbone_model_name="svd", num_blocks=1, num_frames=16, num
                      add_adapter_location_D=True, add_adapter_location_M=True)
 
 
-def attention_flops_sdxl(n):
-    """algorithmic FLOPs (4*B*heads*Lq*Lk*D) of every flash-attention launch of one step, batch n"""
-    fl = 0.0
-    # ControlNet: 8 heads x C/8; self (L x L) + cross (L x 77); 2 layers per resolution + mid
-    for C, L, cnt in ((320, 4096, 2), (640, 1024, 2), (1280, 256, 2), (1280, 64, 1)):
-        fl += cnt * 4.0 * n * C * L * (L + 77)
-    # SDXL adapter: heads = C/64, D = 64 at the up-sampled grid
-    for C, L, cnt in ((320, 16384, 3), (320, 4096, 1), (640, 4096, 2), (640, 1024, 1), (1280, 1024, 2)):
-        fl += cnt * 4.0 * n * C * L * (L + 77)
-    return fl
-
-
 def build_models(dev, workload):
     import ctrl_adapter_amd as P
     from oracle.init import seeded_init      # seeded random weights (shared with the parity tests)

@@ -53,8 +53,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    // XCD-aware work map (1-D grid): workgroup id -> XCD id&7 (observed dispatch order); every XCD owns whole (batch, head)
+    // pairs p = x, x+8, x+16, ... and walks their query tiles back to back, so the workgroups resident on one XCD at any
+    // time stream the SAME K/V tiles through that XCD's private L2 (K+V of one pair at L = 16384 is 4 MiB = one L2).
+    const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pair = (j / qtiles) * 8 + xcd;
+    if (pair >= a.B * a.heads) return;
+    const int b = pair / a.heads, h = pair - b * a.heads;
+    const int q0 = (j % qtiles) * (NW * 32) + wave * 32;
     const int Lq = a.Lq, Lk = a.Lk;
     const float c = a.scale * 1.4426950408889634f;   // softmax in the exp2 domain
 
@@ -287,7 +294,8 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
     }
     const half_t* zeros = attn_zero_page();
     CTRL_CHECK(zeros != nullptr, "flash_attn: could not allocate the zero page");
-    dim3 grid((a.Lq + NW * 32 - 1) / (NW * 32), a.heads, a.B);
+    const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32), pairs = a.B * a.heads;
+    dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
     PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
     prof_detail("B%d h%d D%d Lq%d Lk%d nw%d", a.B, a.heads, a.D, a.Lq, a.Lk, NW);
     LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH>), grid, dim3(NW * 64), smem, s, a, zeros);

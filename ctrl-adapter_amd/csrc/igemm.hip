@@ -368,7 +368,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
     }
     // C/D fragment map of v_mfma_f32_16x16x32: row = (lane>>4)*4 + i, col = lane&15
     const int erow = (lane >> 4) * 4, ecol = lane & 15;
-    constexpr int NSTEP = 1;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         if (a.geglu && (ni & 1)) continue;           // odd fragments are the gates of the even ones
@@ -438,7 +437,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
             }
         }
     }
-    (void)NSTEP;
 }
 
 // split-K tail: out = epilogue( sum_s slab[s] ), 8 consecutive columns per thread (row-major outputs only)
@@ -599,8 +597,6 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
         }
     }
     // (vector-epilogue variant only: the scalar-epilogue one does not fit the register file at this tile size)
-    if (getenv("CTRL_IGEMM_CFG") && atoi(getenv("CTRL_IGEMM_CFG")) == 1 && tiles(128, 256) >= 200 && eff(256) > 0.9 && can_swap(a))
-        return launch_cfg2<128, 256, 32, 2, 2, 3, MODE, true>(a, s);     // experiment: 4 waves x (64x128), 2 blocks/CU
     if (tiles(256, 256) >= 200 && eff(256) > 0.9 && can_swap(a)) return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s);
     // N = 320 / 640 / 960 / 1280 / 1920 / 3840 (every conv and QKV width of the path): 256x320 tile, 128x80 per wave
     if (a.Nout % 320 == 0 && tiles(256, 320) >= 160 && can_swap(a) && !a.geglu) return launch_cfg2<256, 320, 32, 2, 4, 4, MODE, true>(a, s);
