@@ -131,10 +131,18 @@ def test_full_size_sdxl_vs_oracle_and_batch_properties(P, controlnet, gpu):
     rd, rm = oc(torch.nn.functional.adaptive_avg_pool2d(lat, (64, 64)), t, ehs_c, cond)
     ro, _ = oa(rd, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
     e_cn = [rel_inf(a, b) for a, b in zip(list(d1) + [m1], list(rd) + [rm])]
-    e_ad = [rel_inf(a, b) for a, b in zip(o1[:9], ro[:9])]
+    e_chain = [rel_inf(a, b) for a, b in zip(o1[:9], ro[:9])]
+    # the north-star bound is on the adapter given the SAME inputs: feed both sides the oracle's ControlNet features
+    # (rounded to the fp16 the pipelines hand over, sdxl/pipelines/sdxl_controlnet_adapter_pipeline.py:1338)
+    rd16 = [x.half() for x in rd]
+    o_same, _ = ad([x.to(gpu) for x in rd16], num_frames=1, timestep=t, encoder_hidden_states=ehs_a.half().to(gpu))
+    ro_same, _ = oa([x.float() for x in rd16], num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+    e_ad = [rel_inf(a, b) for a, b in zip(o_same[:9], ro_same[:9])]
     print("PARITY full-size controlnet rel_inf: " + " ".join("%.2e" % e for e in e_cn))
-    print("PARITY full-size adapter    rel_inf: " + " ".join("%.2e" % e for e in e_ad))
+    print("PARITY full-size adapter (same inputs) rel_inf: " + " ".join("%.2e" % e for e in e_ad))
+    print("PARITY full-size chain (HIP ControlNet -> HIP adapter vs oracle -> oracle) rel_inf: " + " ".join("%.2e" % e for e in e_chain))
     assert max(e_cn) <= TOL and max(e_ad) <= TOL_ADAPTER
+    assert max(e_chain) <= TOL          # the chain carries the ControlNet's fp16-operand noise into the adapter
     # batch 8: every image of a replicated batch must reproduce the single-image result
     d8, m8, o8 = run(8)
     for a, b in zip(o8[:9], o1[:9]):
