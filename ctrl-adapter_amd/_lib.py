@@ -15,7 +15,7 @@ F32, F16, BF16 = 0, 1, 2
 
 class IGemmSeg(C.Structure):
     _fields_ = [("out", C.c_void_p), ("ld", C.c_int64), ("col_begin", C.c_int32), ("ncols", C.c_int32),
-                ("fmt", C.c_int32), ("dtype", C.c_int32), ("L", C.c_int32), ("pad_", C.c_int32)]
+                ("fmt", C.c_int32), ("dtype", C.c_int32), ("L", C.c_int32), ("pad_", C.c_int32), ("img_map", C.c_void_p)]
 
 
 class IGemmDesc(C.Structure):
@@ -67,9 +67,10 @@ class AdapterConfig(C.Structure):
 
 
 # every symbol include/ctrl_hip.h declares (tests check the library exports all of them)
+ABI_VERSION = 2       # CTRL_ABI_VERSION of include/ctrl_hip.h
 EXPORTS = [
     "ctrl_abi_version", "ctrl_last_error", "ctrl_prof_begin", "ctrl_prof_end", "ctrl_prof_count", "ctrl_prof_get",
-    "ctrl_op_igemm", "ctrl_op_flash_attn", "ctrl_op_temporal_attn", "ctrl_op_gn_stats", "ctrl_op_gn_apply",
+    "ctrl_op_igemm", "ctrl_op_flash_attn", "ctrl_op_temporal_attn", "ctrl_op_gn_stats_floats", "ctrl_op_gn_stats", "ctrl_op_gn_apply",
     "ctrl_op_layernorm", "ctrl_op_nchw_to_nhwc", "ctrl_op_nhwc_to_nchw", "ctrl_avgpool_nchw",
     "ctrl_op_timestep_sincos", "ctrl_op_linear_small", "ctrl_op_blend", "ctrl_op_add_rowvec",
     "ctrl_op_conv3x3_direct", "ctrl_op_pack_conv_w", "ctrl_op_pack_conv_w_direct", "ctrl_op_pack_linear_w",
@@ -78,6 +79,7 @@ EXPORTS = [
     "ctrl_controlnet_destroy", "ctrl_controlnet_forward",
     "ctrl_adapter_param_count", "ctrl_adapter_param_spec", "ctrl_adapter_create", "ctrl_adapter_destroy",
     "ctrl_adapter_forward",
+    "ctrl_adapter_forward_scatter",
     "ctrl_router_weights", "ctrl_router_merge",
 ]
 
@@ -100,7 +102,8 @@ def lib():
                 fn.restype = C.c_int
         _lib.ctrl_controlnet_destroy.restype = None
         _lib.ctrl_adapter_destroy.restype = None
-        if _lib.ctrl_abi_version() != 1:
+        _lib.ctrl_op_gn_stats_floats.restype = C.c_size_t
+        if _lib.ctrl_abi_version() != ABI_VERSION:
             raise RuntimeError("libctrlhip ABI version mismatch")
     return _lib
 

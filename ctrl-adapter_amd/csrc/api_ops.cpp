@@ -18,6 +18,7 @@ int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream) {
     CTRL_CHECK(d != nullptr, "temporal_attn: null descriptor");
     return op_temporal_attn(*d, S(stream));
 }
+size_t ctrl_op_gn_stats_floats(int imgs, int rows_per_img, int C, int G) { return op_gn_stats_floats(imgs, rows_per_img, C, G); }
 int ctrl_op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, void* stream) {
     return op_gn_stats(x, x_dtype, stats, imgs, rows_per_img, C, G, S(stream));
 }

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const void* __restric
 }
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const half_t* __restrict__ x, void* __restrict__ y, int dt,
-                                                           int C, int HW, float scale) {
+                                                           int C, int HW, float scale, const int* __restrict__ img_map) {
     __shared__ float tile[32][65];
     const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 64;
     const int t = threadIdx.x;
@@ -48,11 +48,12 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const half_t* __restr
     __syncthreads();
     {
         const int pl = t & 63;
+        const int nd = img_map ? img_map[n] : n;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int cl = (t >> 6) + 4 * i;
             const int c = c0 + cl, p = p0 + pl;
-            if (c < C && p < HW) store_from_f32(y, ((size_t)n * C + c) * HW + p, dt, tile[cl][pl] * scale);
+            if (c < C && p < HW) store_from_f32(y, ((size_t)nd * C + c) * HW + p, dt, tile[cl][pl] * scale);
         }
     }
 }
@@ -272,9 +273,9 @@ int op_nchw_to_nhwc(const void* x, int dtype, half_t* y, int N, int C, int HW, h
     LAUNCH("nchw_to_nhwc", nchw_to_nhwc_kernel, grid, dim3(256), 0, s, x, dtype, y, C, HW);
     return 0;
 }
-int op_nhwc_to_nchw(const half_t* x, void* y, int dtype, int N, int C, int HW, float scale, hipStream_t s) {
+int op_nhwc_to_nchw(const half_t* x, void* y, int dtype, int N, int C, int HW, float scale, hipStream_t s, const int* img_map) {
     dim3 grid((HW + 63) / 64, (C + 31) / 32, N);
-    LAUNCH("nhwc_to_nchw", nhwc_to_nchw_kernel, grid, dim3(256), 0, s, x, y, dtype, C, HW, scale);
+    LAUNCH("nhwc_to_nchw", nhwc_to_nchw_kernel, grid, dim3(256), 0, s, x, y, dtype, C, HW, scale, img_map);
     return 0;
 }
 int op_avgpool_nchw(const void* x, void* y, int dtype, int NC, int Hin, int Win, int Hout, int Wout, hipStream_t s) {

@@ -412,7 +412,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
                 }
             } else {
                 const int img = rbase / sg.L, tok = rbase - img * sg.L;
-                const size_t base = ((size_t)img * sg.ncols + scol) * sg.ld + tok;
+                const int dimg = sg.img_map ? sg.img_map[img] : img;
+                const size_t base = ((size_t)dimg * sg.ncols + scol) * sg.ld + tok;
                 const bool vec = ((sg.L & 3) == 0) && ((sg.ld & 3) == 0) && (rbase + 3 < a.M);
                 if (vec) {
                     if (sg.dtype == DT_F16) {
@@ -431,7 +432,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
                         const int row = rbase + i;
                         if (row >= a.M) break;
                         const int im = row / sg.L, tk = row - im * sg.L;
-                        store_from_f32(sg.out, ((size_t)im * sg.ncols + scol) * sg.ld + tk, sg.dtype, v[i]);
+                        const int dm = sg.img_map ? sg.img_map[im] : im;
+                        store_from_f32(sg.out, ((size_t)dm * sg.ncols + scol) * sg.ld + tk, sg.dtype, v[i]);
                     }
                 }
             }

@@ -5,9 +5,10 @@
 // (model/adapter_spatial_temporal.py:61); torch.nn.LayerNorm in (Temporal)BasicTransformerBlock.
 //
 // These kernels are HBM-bound: each reads its input once with 16-byte vector loads and reduces with
-// wavefront shuffles / LDS atomics.  GroupNorm is split into a statistics pass (sum, sum of squares per
-// (image, group) via one fp32 atomic pair per workgroup) and an apply pass (normalise + affine + optional
-// SiLU) because one group of an SDXL-sized map (10 ch x 128x128) does not fit one workgroup.
+// wavefront shuffles / LDS.  GroupNorm is split into a statistics pass (sum, sum of squares per (image, group),
+// reduced in a fixed order: no floating-point atomics anywhere, so results are bit-reproducible) and an apply pass
+// (normalise + affine + optional SiLU) because one group of an SDXL-sized map (10 ch x 128x128) does not fit one
+// workgroup.
 #include "ops.h"
 
 namespace {
@@ -24,21 +25,24 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
 }
 
-// x [imgs][rows][C]; grid (chunks, imgs); each thread owns an 8-channel chunk and strides over rows, four 16-byte
-// loads in flight per thread (these kernels are pure HBM streaming: memory-level parallelism is what matters).
+// x [imgs][rows][C]; grid (chunks, imgs); each thread owns an 8-channel chunk and strides over rows, four to eight
+// 16-byte loads in flight per thread (these kernels are pure HBM streaming: memory-level parallelism is what matters).
+// The reduction is ORDER-FIXED so a forward is bit-reproducible run to run: per-thread partials go through LDS slots
+// (no LDS atomics), each (image, chunk) workgroup stores its 2*G partial sums, and the last workgroup of an image to
+// arrive (ticket counter) adds the chunks in index order.  stats layout: [imgs][G][2] results | [imgs] tickets (zero on
+// entry, reset to zero on exit) | [imgs][chunks][G][2] partials.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
                                                        int rows, int C, int G, int rows_per_block) {
-    extern __shared__ float sh[];   // [2*C]: per-channel sum, sumsq
+    extern __shared__ float sh[];   // [rpi][2*C]: per (row lane, channel) sum | sumsq
+    __shared__ int is_last;
     const int tid = threadIdx.x;
     const int lpr = C >> 3;                 // lanes per row
     const int rpi = 256 / lpr;              // rows per iteration
     const int tr = tid / lpr, tc = tid - tr * lpr;
-    const int img = blockIdx.y;
+    const int img = blockIdx.y, imgs = gridDim.y, chunks = gridDim.x;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
-    for (int i = tid; i < 2 * C; i += 256) sh[i] = 0.f;
-    __syncthreads();
     float s[8], ss[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
@@ -61,20 +65,64 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = v[j]; s[j] += f; ss[j] += f * f; }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            atomicAdd(&sh[tc * 8 + j], s[j]);
-            atomicAdd(&sh[C + tc * 8 + j], ss[j]);
-        }
+        float* row = sh + (size_t)tr * 2 * C;
+        *(f4*)(row + tc * 8) = f4{s[0], s[1], s[2], s[3]};
+        *(f4*)(row + tc * 8 + 4) = f4{s[4], s[5], s[6], s[7]};
+        *(f4*)(row + C + tc * 8) = f4{ss[0], ss[1], ss[2], ss[3]};
+        *(f4*)(row + C + tc * 8 + 4) = f4{ss[4], ss[5], ss[6], ss[7]};
     }
     __syncthreads();
+    // group g = tid / 8 is summed by 8 lanes (fixed element -> lane assignment), then a fixed xor tree
     const int cg = C / G;
-    if (tid < G) {
-        float a = 0.f, b = 0.f;
-        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += sh[c]; b += sh[C + c]; }
-        atomicAdd(&stats[((size_t)img * G + tid) * 2 + 0], a);
-        atomicAdd(&stats[((size_t)img * G + tid) * 2 + 1], b);
+    const int g = tid >> 3, part = tid & 7;
+    float a = 0.f, b = 0.f;
+    if (g < G) {
+        const int n = cg * rpi;
+        for (int e = part; e < n; e += 8) {
+            const int t = e / cg, c = g * cg + (e - t * cg);
+            a += sh[(size_t)t * 2 * C + c];
+            b += sh[(size_t)t * 2 * C + C + c];
+        }
     }
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    float* res = stats + (size_t)img * G * 2;
+    unsigned* ticket = (unsigned*)(stats + (size_t)imgs * G * 2) + img;
+    float* part_all = stats + (size_t)imgs * G * 2 + imgs + (size_t)img * chunks * G * 2;
+    if (chunks == 1) {
+        if (g < G && part == 0) { res[g * 2] = a; res[g * 2 + 1] = b; }
+        return;
+    }
+    // Publication without a cache-wide release fence (a `__threadfence()` per workgroup costs an L2 write-back each):
+    // the partials are agent-scope atomic stores (written through to the coherence point), the wave waits for their
+    // acknowledgement, and only then is the ticket taken; the last workgroup reads them back with agent-scope loads.
+    if (g < G && part == 0) {
+        float* pp = part_all + (size_t)blockIdx.x * G * 2;
+        __hip_atomic_store(pp + g * 2, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + g * 2 + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): stores acknowledged
+    __syncthreads();
+    if (tid == 0)
+        is_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(chunks - 1));
+    __syncthreads();
+    if (!is_last) return;
+    if (tid < 2 * G) {
+        const float* pv = part_all + tid;
+        float acc = 0.f;
+        int k = 0;
+        for (; k + 8 <= chunks; k += 8) {   // 8 loads in flight, added in index order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = __hip_atomic_load(pv + (size_t)(k + u) * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; k < chunks; ++k) acc += __hip_atomic_load(pv + (size_t)k * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res[tid] = acc;
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this buffer
 }
 
 // same decomposition as the statistics pass: a thread folds mean / rstd / gamma / beta of its 8 channels into one
@@ -193,19 +241,27 @@ static int gn_rows_per_block(int imgs, int rows_per_img, int C, int target_block
     return rpb;
 }
 
+size_t op_gn_stats_floats(int imgs, int rows_per_img, int C, int G) {
+    if (imgs < 1 || rows_per_img < 1 || C < 8 || G < 1) return 0;
+    const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 768);
+    const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
+    return (size_t)imgs * G * 2 + imgs + (chunks > 1 ? (size_t)imgs * chunks * G * 2 : 0);
+}
+
 int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
     CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_stats: input must be fp16 or fp32");
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_stats: C must be a multiple of 8 and of G, <= 2048");
-    CTRL_CHECK(G <= 256, "gn_stats: G too large");
-    // fewer, fatter workgroups than the apply pass: every workgroup ends with 2*G global atomics on the same 2*G words
+    CTRL_CHECK(G <= 32, "gn_stats: at most 32 groups");
+    // fewer, fatter workgroups than the apply pass: the last workgroup of an image adds all its chunks serially
     const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 768);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
     PROF_WORK(0, (x_dtype == DT_F32 ? 4.0 : 2.0) * imgs * rows_per_img * C);
+    const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
     if (x_dtype == DT_F32)
-        LAUNCH("gn_stats", gn_stats_kernel<float>, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
+        LAUNCH("gn_stats", gn_stats_kernel<float>, dim3(chunks, imgs), dim3(256), lds, s,
                (const float*)x, stats, rows_per_img, C, G, rows_per_block);
     else
-        LAUNCH("gn_stats", gn_stats_kernel<half_t>, dim3(chunks, imgs), dim3(256), 2 * C * sizeof(float), s,
+        LAUNCH("gn_stats", gn_stats_kernel<half_t>, dim3(chunks, imgs), dim3(256), lds, s,
                (const half_t*)x, stats, rows_per_img, C, G, rows_per_block);
     return 0;
 }

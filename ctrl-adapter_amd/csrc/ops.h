@@ -36,8 +36,10 @@ int op_temporal_attn(const TAttnArgs& a, hipStream_t s);
 // ------------------------------------------------------------------------------------------
 // Normalisation
 // ------------------------------------------------------------------------------------------
-// GroupNorm statistics over [img][rows_per_img][C]: stats[img][G][2] += (sum, sumsq)   (fp32 atomics;
-// caller zeroes `stats` once per forward)
+// GroupNorm statistics over [img][rows_per_img][C]: stats[img][G][2] = (sum, sumsq), reduced in a fixed order.
+// `stats` holds op_gn_stats_floats(...) floats (results first, then tickets and per-workgroup partials) and must have
+// been zeroed once (the kernel leaves its tickets zero again).
+size_t op_gn_stats_floats(int imgs, int rows_per_img, int C, int G);
 int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s);
 // y = (x-mean)*rstd*gamma+beta (optionally SiLU); x,y [imgs*rows][C]
 int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
@@ -52,7 +54,8 @@ int op_layernorm(const void* x, int x_dtype, long ldx, const float* gamma, const
 // [N][C][HW] (any dtype) -> [N][HW][C] fp16
 int op_nchw_to_nhwc(const void* x, int dtype, half_t* y, int N, int C, int HW, hipStream_t s);
 // [N][HW][C] fp16 -> [N][C][HW] (any dtype), y = x*scale
-int op_nhwc_to_nchw(const half_t* x, void* y, int dtype, int N, int C, int HW, float scale, hipStream_t s);
+int op_nhwc_to_nchw(const half_t* x, void* y, int dtype, int N, int C, int HW, float scale, hipStream_t s,
+                    const int* img_map = nullptr);   // img_map (device): image n is written at image img_map[n]
 // exact kxk mean pooling of an NCHW tensor (adaptive_avg_pool2d with integer ratio), dtype preserved
 int op_avgpool_nchw(const void* x, void* y, int dtype, int NC, int Hin, int Win, int Hout, int Wout, hipStream_t s);
 // sinusoidal timestep embedding, flip_sin_to_cos=True, shift 0: out[n][dim] fp32 = [cos | sin]

@@ -122,6 +122,7 @@ struct AFwd {
     EhsCtx e;                    // spatial cross-attention context
     EhsCtx e_first;              // temporal cross-attention context (first frame of each clip), Lk == 1 only
     int in_dt, out_dt;
+    const int* out_map = nullptr;   // device: input frame -> output frame (ctrl_adapter_forward_scatter), or null
 };
 
 // temporal ResNet on frame-major rows [(b f) hw][C]
@@ -285,7 +286,7 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             set_res(g, x, C);
             if (last) {
                 g.nseg = 1;
-                g.seg[0] = IGemmSeg{out, Lt, 0, C, SEG_TRANSPOSED, a.out_dt, Lt, 0};
+                g.seg[0] = IGemmSeg{out, Lt, 0, C, SEG_TRANSPOSED, a.out_dt, Lt, 0, a.out_map};
                 RUN(cx, op_igemm(g, cx.s));
             } else {
                 TV y = stream_alloc(cx, (size_t)M * C, true);      // next layer's shortcut conv reads the fp16 copy
@@ -294,7 +295,7 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
                 x = y;
             }
         } else if (last) {
-            RUN(cx, op_nhwc_to_nchw(x.m16, out, a.out_dt, N, C, H * W, 1.f, cx.s));
+            RUN(cx, op_nhwc_to_nchw(x.m16, out, a.out_dt, N, C, H * W, 1.f, cx.s, a.out_map));
         }
     }
     cx.release(mk);
@@ -307,7 +308,16 @@ struct ctrl_adapter {
     AdapterW w;
     std::unique_ptr<Packer> packer;
     Arena arena;
-    ~ctrl_adapter() { if (packer) packer->release_all(); }
+    // frame scatter map: pinned staging + device copy, re-uploaded (on the caller's stream) only when it changes
+    static constexpr int kMaxMap = 1024;
+    int* map_host = nullptr;
+    int* map_dev = nullptr;
+    std::vector<int> map_cur;
+    ~ctrl_adapter() {
+        if (packer) packer->release_all();
+        if (map_host) (void)hipHostFree(map_host);
+        if (map_dev) (void)hipFree(map_dev);
+    }
 };
 
 namespace {
@@ -317,6 +327,7 @@ struct AdapterCall {
     const float* t; int t_count;
     const void* ehs; int ehs_dt; int ehs_batch; int Lk;
     void* const* outs; int out_dt;
+    const int* map_dev; const int32_t* map_host; int N_out;     // frame scatter (null / null / N when off)
 };
 
 size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
@@ -326,6 +337,26 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     const ctrl_adapter_config& c = w.cfg;
     AFwd a;
     a.N = k.N; a.F = k.F; a.B = k.N / k.F; a.t = k.t; a.t_count = k.t_count; a.in_dt = k.in_dt; a.out_dt = k.out_dt;
+    a.out_map = k.map_dev;
+    // frames of the dense output that no input frame lands on (zero-filled per slot below), as [begin, end) runs
+    std::vector<std::pair<int, int>> holes;
+    if (k.map_host) {
+        std::vector<char> hit(k.N_out, 0);
+        for (int j = 0; j < k.N; ++j) hit[k.map_host[j]] = 1;
+        for (int f = 0; f < k.N_out;) {
+            if (hit[f]) { ++f; continue; }
+            int e = f;
+            while (e < k.N_out && !hit[e]) ++e;
+            holes.push_back({f, e});
+            f = e;
+        }
+    }
+    auto fill_holes = [&](void* out, size_t frame_elems) -> int {
+        for (const auto& r : holes)
+            RUN(cx, op_fill_zero((char*)out + (size_t)r.first * frame_elems * dt_size(k.out_dt),
+                                 (size_t)(r.second - r.first) * frame_elems * dt_size(k.out_dt), cx.s));
+        return 0;
+    };
     const int cross = c.cross_attention_dim;
     // encoder hidden states: fp16 copy for the K/V projection GEMM, fp32 copy for the single-key path
     a.e.batch = k.ehs_batch; a.e.Lk = k.Lk; a.e.cross = cross;
@@ -359,17 +390,18 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
         const bool has = bi < w.slot_ids.size() && w.slot_ids[bi] == i;
         if (has) {
             TRY(run_block(cx, w.blocks[bi], c, a, k.ins[i], k.outs[i], h, wd));
+            TRY(fill_holes(k.outs[i], (size_t)slot_c[i] * h * up * wd * up));
             ++bi;
         } else {
             // torch.zeros_like(down_block_res_samples[i])  (ctrl_adapter.py:193): input-sized, not up-sampled
-            RUN(cx, op_fill_zero(k.outs[i], (size_t)k.N * slot_c[i] * h * wd * dt_size(k.out_dt), cx.s));
+            RUN(cx, op_fill_zero(k.outs[i], (size_t)k.N_out * slot_c[i] * h * wd * dt_size(k.out_dt), cx.s));
         }
     }
     if (w.has_mid && k.ins[12] && k.outs[12]) {
         const int h = std::max(k.H0 / 8, 1), wd = std::max(k.W0 / 8, 1);
         TRY(run_block(cx, w.mid, c, a, k.ins[12], k.outs[12], h, wd));
+        TRY(fill_holes(k.outs[12], (size_t)1280 * h * wd));
     }
-    (void)up;
     return 0;
 }
 
@@ -410,9 +442,10 @@ int ctrl_adapter_create(const ctrl_adapter_config* cfg, const ctrl_tensor_ref* t
 
 void ctrl_adapter_destroy(ctrl_adapter* h) { delete h; }
 
-int ctrl_adapter_forward(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
-                         const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
-                         int ehs_batch, int Lk, void* const* outs, int out_dtype, void* stream) {
+static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                                const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
+                                int ehs_batch, int Lk, void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
+                                void* stream) {
     CTRL_CHECK(h && ins && outs && timesteps, "adapter_forward: null argument");
     CTRL_CHECK(N >= 1 && H0 >= 1 && W0 >= 1 && num_frames >= 1 && N % num_frames == 0,
                "adapter_forward: batch must be a multiple of num_frames");
@@ -422,9 +455,33 @@ int ctrl_adapter_forward(ctrl_adapter* h, const void* const* ins, int in_dtype, 
     CTRL_CHECK(!needs_ehs || (encoder_hidden_states && Lk >= 1 && (ehs_batch == 1 || ehs_batch == N)),
                "adapter_forward: encoder_hidden_states batch must be 1 or N");
     for (int i = 0; i < 12; ++i) CTRL_CHECK(ins[i] && outs[i], "adapter_forward: null slot pointer");
-    AdapterCall k = {ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states, ehs_dtype,
-                     ehs_batch, Lk, outs, out_dtype};
     hipStream_t s = (hipStream_t)stream;
+    const int* map_dev = nullptr;
+    if (frame_pos) {
+        CTRL_CHECK(N_out >= N && N_out <= ctrl_adapter::kMaxMap, "adapter_forward_scatter: need N <= N_out <= 1024");
+        std::vector<char> seen(N_out, 0);
+        for (int j = 0; j < N; ++j) {
+            CTRL_CHECK(frame_pos[j] >= 0 && frame_pos[j] < N_out && !seen[frame_pos[j]],
+                       "adapter_forward_scatter: frame positions must be distinct and < N_out");
+            seen[frame_pos[j]] = 1;
+        }
+        if (!h->map_dev) {
+            HIP_TRY(hipHostMalloc((void**)&h->map_host, sizeof(int) * ctrl_adapter::kMaxMap, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void**)&h->map_dev, sizeof(int) * ctrl_adapter::kMaxMap));
+        }
+        if (h->map_cur.size() != (size_t)N || !std::equal(h->map_cur.begin(), h->map_cur.end(), frame_pos)) {
+            // the staging buffer may still be the source of an in-flight copy of the previous map
+            HIP_TRY(hipStreamSynchronize(s));
+            h->map_cur.assign(frame_pos, frame_pos + N);
+            std::copy(frame_pos, frame_pos + N, h->map_host);
+            HIP_TRY(hipMemcpyAsync(h->map_dev, h->map_host, sizeof(int) * N, hipMemcpyHostToDevice, s));
+        }
+        map_dev = h->map_dev;
+    } else {
+        N_out = N;
+    }
+    AdapterCall k = {ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states, ehs_dtype,
+                     ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out};
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
@@ -435,6 +492,22 @@ int ctrl_adapter_forward(ctrl_adapter* h, const void* const* ins, int in_dtype, 
     cx.f32stream = dry.f32stream;
     cx.stats_total = dry.stats_total;
     return adapter_run(cx, h->w, k);
+}
+
+int ctrl_adapter_forward(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                         const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
+                         int ehs_batch, int Lk, void* const* outs, int out_dtype, void* stream) {
+    return adapter_forward_impl(h, ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states,
+                                ehs_dtype, ehs_batch, Lk, outs, out_dtype, nullptr, N, stream);
+}
+
+int ctrl_adapter_forward_scatter(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                                 const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
+                                 int ehs_batch, int Lk, void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
+                                 void* stream) {
+    CTRL_CHECK(frame_pos, "adapter_forward_scatter: null frame_pos");
+    return adapter_forward_impl(h, ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states,
+                                ehs_dtype, ehs_batch, Lk, outs, out_dtype, frame_pos, N_out, stream);
 }
 
 }  // extern "C"

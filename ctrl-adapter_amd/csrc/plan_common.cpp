@@ -63,7 +63,7 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
 
 // ------------------------------------------------------------------------------------------ runners
 int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu) {
-    float* st = cx.stats((size_t)imgs * 32 * 2);
+    float* st = cx.stats(op_gn_stats_floats(imgs, rows, n.C, 32));
     RUN(cx, op_gn_stats(x.p, x.dt, st, imgs, rows, n.C, 32, cx.s));
     RUN(cx, op_gn_apply(x.p, x.dt, st, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s));
     return 0;

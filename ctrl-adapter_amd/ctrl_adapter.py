@@ -67,7 +67,17 @@ class ControlNetAdapter(ParamTreeModule):
 
     @torch.no_grad()
     def forward(self, down_block_res_samples, mid_block_res_sample=None, sparsity_masking=None, num_frames=None,
-                timestep=None, encoder_hidden_states=None):
+                timestep=None, encoder_hidden_states=None, *, scatter_to=None, out_dtype=None, clip_batch=None):
+        """Reference signature (model/ctrl_adapter.py:171) plus three keyword-only extensions that fold the pipelines'
+        residual hand-over into the last epilogue of every adapter block:
+
+        scatter_to=(positions, total_frames): input frame j is written at frame positions[j] of total_frames-frame
+            outputs, all other frames are zero: the sparse -> dense loop of i2vgen_xl/pipelines/...:1052-1071 and
+            svd/pipelines/...:719-741 without the zeros tensor and the per-frame python copies.
+        out_dtype: dtype of the returned tensors (those loops build float32 tensors); default = the input dtype.
+        clip_batch=bs: return `[bs, c, nf, h, w]` tensors, i.e. rearrange(x, "(bs nf) c h w -> bs c nf h w"), as
+            zero-copy views; the UNets' inverse rearrange (i2vgen_xl/models/unets/unet_i2vgen_xl.py:683-684) is then a
+            view of the same memory as well."""
         # sparsity_masking is accepted and ignored, exactly like the reference (SURVEY.md note N7)
         if len(down_block_res_samples) != 12:
             raise ValueError("expected the 12 ControlNet down_block_res_samples")
@@ -95,19 +105,37 @@ class ControlNetAdapter(ParamTreeModule):
                 raise ValueError("encoder_hidden_states must be [1 or N, L, %d]" % self.config.cross_attention_dim)
         ids = self.get_down_block_ids()
         ins = [t.contiguous() for t in down_block_res_samples]
+        odt = out_dtype if out_dtype is not None else dt
+        N_out, pos = N, None
+        if scatter_to is not None:
+            positions, N_out = scatter_to
+            positions = [int(p) for p in positions]
+            N_out = int(N_out)
+            if len(positions) != N or len(set(positions)) != N or min(positions) < 0 or max(positions) >= N_out:
+                raise ValueError("scatter_to: need %d distinct frame positions in [0, %d)" % (N, N_out))
+            pos = (C.c_int32 * N)(*positions)
+        if clip_batch is not None and (int(clip_batch) < 1 or N_out % int(clip_batch)):
+            raise ValueError("clip_batch must divide the number of output frames")
         outs = []
         for i, (c, f) in enumerate(zip(_SLOT_C, _SLOT_F)):
             h, w = max(H0 // f, 1), max(W0 // f, 1)
             s = self._up if i in ids else 1             # zeros_like keeps the input size (ctrl_adapter.py:193)
-            outs.append(torch.empty(N, c, h * s, w * s, dtype=dt, device=x0.device))
+            outs.append(torch.empty(N_out, c, h * s, w * s, dtype=odt, device=x0.device))
         mid_in = mid_out = None
         if mid_block_res_sample is not None and self.add_adapter_location_M:
             mid_in = mid_block_res_sample.contiguous()
-            mid_out = torch.empty(N, 1280, mid_in.shape[2] * self._up, mid_in.shape[3] * self._up, dtype=dt, device=x0.device)
+            mid_out = torch.empty(N_out, 1280, mid_in.shape[2] * self._up, mid_in.shape[3] * self._up, dtype=odt, device=x0.device)
         in_ptrs = (C.c_void_p * 13)(*([t.data_ptr() for t in ins] + [mid_in.data_ptr() if mid_in is not None else None]))
         out_ptrs = (C.c_void_p * 13)(*([t.data_ptr() for t in outs] + [mid_out.data_ptr() if mid_out is not None else None]))
-        L.check(L.lib().ctrl_adapter_forward(
-            plan, in_ptrs, L.dtype_code(dt), N, H0, W0, num_frames, L.ptr(t32), t32.numel(),
-            L.ptr(ehs), L.dtype_code(ehs.dtype) if ehs is not None else 0, eb, Lk,
-            out_ptrs, L.dtype_code(dt), L.cur_stream()))
+        args = (plan, in_ptrs, L.dtype_code(dt), N, H0, W0, num_frames, L.ptr(t32), t32.numel(),
+                L.ptr(ehs), L.dtype_code(ehs.dtype) if ehs is not None else 0, eb, Lk, out_ptrs, L.dtype_code(odt))
+        if pos is None:
+            L.check(L.lib().ctrl_adapter_forward(*args, L.cur_stream()))
+        else:
+            L.check(L.lib().ctrl_adapter_forward_scatter(*args, pos, N_out, L.cur_stream()))
+        if clip_batch is not None:
+            bs = int(clip_batch)
+            as_clips = lambda x: x.view(bs, N_out // bs, *x.shape[1:]).permute(0, 2, 1, 3, 4)
+            outs = [as_clips(x) for x in outs]
+            mid_out = as_clips(mid_out) if mid_out is not None else None
         return outs, mid_out

@@ -129,9 +129,8 @@ def temporal_attn(qkv, Bc, F, HW, heads):
 
 def groupnorm(x, gamma, beta, imgs, rows_per_img, G=32, eps=1e-5, silu=False):
     Cc = x.shape[-1]
-    stats = torch.zeros(imgs, G, 2, dtype=torch.float32, device=x.device)
-    y = torch.empty_like(x)
     lib = L.lib()
+    stats = torch.zeros(lib.ctrl_op_gn_stats_floats(imgs, rows_per_img, Cc, G), dtype=torch.float32, device=x.device)
     y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
     L.check(lib.ctrl_op_gn_stats(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), imgs, rows_per_img, Cc, G, L.cur_stream()))
     L.check(lib.ctrl_op_gn_apply(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(y), imgs, rows_per_img, Cc, G,

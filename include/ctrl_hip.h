@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTRL_ABI_VERSION 1
+#define CTRL_ABI_VERSION 2
 
 /* element types of boundary tensors */
 enum { CTRL_F32 = 0, CTRL_F16 = 1, CTRL_BF16 = 2 };
@@ -52,6 +52,7 @@ typedef struct ctrl_igemm_seg {
     int32_t dtype;      /* CTRL_F32 / CTRL_F16 / CTRL_BF16 */
     int32_t L;          /* tokens per image (TRANSPOSED) */
     int32_t pad_;
+    const int32_t* img_map;   /* TRANSPOSED, optional (device): image m/L is written at image img_map[m/L] (frame scatter) */
 } ctrl_igemm_seg;
 
 typedef struct ctrl_igemm_desc {
@@ -100,7 +101,10 @@ typedef struct ctrl_tattn_desc {
 } ctrl_tattn_desc;
 int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream);
 
-/* x_dtype: CTRL_F16 or CTRL_F32 (fp32 residual stream) */
+/* x_dtype: CTRL_F16 or CTRL_F32 (fp32 residual stream).  GroupNorm statistics are reduced in a fixed order (no
+ * floating-point atomics): `stats` holds ctrl_op_gn_stats_floats(...) floats - [imgs][G][2] (sum, sumsq) results first,
+ * then scratch - and must have been zeroed once; the kernel leaves its scratch tickets zero again. */
+size_t ctrl_op_gn_stats_floats(int imgs, int rows_per_img, int C, int G);
 int ctrl_op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, void* stream);
 int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
@@ -197,6 +201,16 @@ int ctrl_adapter_forward(ctrl_adapter* h,
                          const float* timesteps, int t_count,
                          const void* encoder_hidden_states, int ehs_dtype, int ehs_batch, int Lk,
                          void* const* outs, int out_dtype, void* stream);
+/* The same forward with the pipelines' "sparse frames -> dense frames" scatter folded into the last epilogue of every
+ * block (i2vgen_xl/pipelines/i2vgen_xl_controlnet_adapter_pipeline.py:1052-1071, svd/pipelines/
+ * svd_controlnet_adapter_pipeline.py:719-741: torch.zeros + a python loop of per-frame copies): outs[i] hold N_out
+ * frames, input frame j is written at frame frame_pos[j] (host array of N distinct positions < N_out), every other
+ * frame is zero-filled.  The values are bit-identical to ctrl_adapter_forward's; only their location differs. */
+int ctrl_adapter_forward_scatter(ctrl_adapter* h,
+                                 const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                                 const float* timesteps, int t_count,
+                                 const void* encoder_hidden_states, int ehs_dtype, int ehs_batch, int Lk,
+                                 void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out, void* stream);
 
 /* ---- Router (model/ctrl_router.py) ---- */
 /* weights_out fp32 device [num_routers + (has_mid?1:0)][E]; wg fp32 device same shape (Linear(1,E).weight[:,0]
