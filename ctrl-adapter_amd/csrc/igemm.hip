@@ -279,6 +279,77 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
         // leaves as whole 16-byte pieces of full output rows: residual reads and result writes are coalesced 128-byte+
         // row segments instead of 8-byte fragments scattered over 16 rows.
         __syncthreads();                                   // every wave is done with the ring
+        if (a.seg[0].fmt == SEG_TRANSPOSED) {
+            // One transposed segment (NCHW result / V^T operand): out[(img*ncols + c)*ld + tok].  Everything that is
+            // indexed by (row, column) -- bias, time vector, SiLU, residual, scale -- is applied in the fragment layout;
+            // a 16-channel slab of the wave tile (16 x WM tokens) is then transposed through the wave's LDS area and
+            // leaves as 16-byte pieces of WM-token runs of one channel (256 B contiguous for WM = 128) instead of the
+            // natural orientation's isolated 8-byte stores.
+            constexpr int SLT = WM + 4;                    // 4*SLT = 16 (mod 64 banks): the 4 channel groups of a write hit distinct banks
+            float* stg = (float*)smem_raw + wave * (16 * SLT);
+            const IGemmSeg sg = a.seg[0];
+            const int erow = lane & 15, ecol = (lane >> 4) * 4;
+            const int wrow0 = m0 + wm * WM;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int pcb = n0 + wn * WN + ni * 16;
+                if (pcb < a.Nout) {
+                    const int pcol = pcb + ecol;
+                    f4 b4 = f4{0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) b4 = *(const f4*)(a.bias + pcol);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int row_w = wrow0 + mi * 16 + erow;
+                        f4 x = acc[mi][ni] + b4;
+                        if (row_w < a.M) {
+                            if (a.rowvec) x += *(const f4*)(a.rowvec + (size_t)(row_w / a.rows_per_img) * a.rowvec_ld + pcol);
+                            if (a.act == 1) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
+                            }
+                            if (Rptr) {
+                                if (a.res_f32) {
+                                    x += *(const f4*)((const float*)a.res + (size_t)row_w * a.ldres + pcol);
+                                } else {
+                                    const h4 rr = *(const h4*)(Rptr + (size_t)row_w * a.ldres + pcol);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) x[i] += (float)rr[i];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) stg[(ecol + i) * SLT + mi * 16 + erow] = x[i] * a.scale;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    constexpr int CH8 = WM / 8;
+                    for (int idx = lane; idx < 16 * CH8; idx += 64) {
+                        const int ch = idx / CH8, c8 = idx - ch * CH8;
+                        const int row = wrow0 + c8 * 8;
+                        if (row >= a.M) continue;
+                        int img = row / sg.L;
+                        const int tok = row - img * sg.L;
+                        if (sg.img_map) img = sg.img_map[img];
+                        const size_t o = ((size_t)img * sg.ncols + (pcb - sg.col_begin) + ch) * sg.ld + tok;
+                        const f4 v0 = *(const f4*)(stg + ch * SLT + c8 * 8), v1 = *(const f4*)(stg + ch * SLT + c8 * 8 + 4);
+                        if (sg.dtype == DT_F16) {
+                            h8 pk = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
+                                     (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
+                            *(h8*)((half_t*)sg.out + o) = pk;
+                        } else if (sg.dtype == DT_F32) {
+                            *(f4*)((float*)sg.out + o) = v0;
+                            *(f4*)((float*)sg.out + o + 4) = v1;
+                        } else {
+                            typedef u16 us8 __attribute__((ext_vector_type(8)));
+                            us8 pk = {f32_to_bf16(v0[0]), f32_to_bf16(v0[1]), f32_to_bf16(v0[2]), f32_to_bf16(v0[3]),
+                                      f32_to_bf16(v1[0]), f32_to_bf16(v1[1]), f32_to_bf16(v1[2]), f32_to_bf16(v1[3])};
+                            *(us8*)((u16*)sg.out + o) = pk;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+            return;
+        }
         constexpr int OWMAX = WN;                          // output columns of the wave tile (half of it with GEGLU)
         constexpr int SLD = OWMAX + 4;                     // floats; +16 B keeps the b128 accesses conflict-light
         float* stg = (float*)smem_raw + wave * (16 * SLD);
@@ -510,7 +581,8 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
     constexpr int BNP = (BN + PASSROWS - 1) / PASSROWS * PASSROWS;
     constexpr size_t ring = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
-    constexpr size_t stage_bytes = (size_t)WAVES_M * WAVES_N * 16 * (BN / WAVES_N + 4) * sizeof(float);
+    constexpr int stage_w = (BN / WAVES_N) > (BM / WAVES_M) ? (BN / WAVES_N) : (BM / WAVES_M);     // row / transposed staging
+    constexpr size_t stage_bytes = (size_t)WAVES_M * WAVES_N * 16 * (stage_w + 4) * sizeof(float);
     constexpr size_t smem = ring > stage_bytes ? ring : stage_bytes;
     static bool attr_done = false;
     if (!attr_done) {
@@ -545,13 +617,20 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     return 0;
 }
 
-// Row-major outputs whose operands are 8-byte aligned use the swapped-operand kernel (vector epilogue); anything with a
-// transposed (NCHW / V^T) segment keeps the natural orientation, whose lanes own 4 consecutive tokens of one channel.
+// Aligned row-major outputs and single aligned transposed (NCHW / V^T) outputs use the swapped-operand kernel (LDS-staged
+// vector epilogue); mixed or unaligned segment lists keep the natural orientation and its scalar epilogue.
 bool can_swap(const IGemmArgs& a) {
     bool swap = (a.Nout % 16 == 0);
-    for (int i = 0; i < a.nseg; ++i)
-        swap = swap && a.seg[i].fmt == SEG_ROW && (a.seg[i].ld % 8 == 0) && (((uintptr_t)a.seg[i].out & 15) == 0) &&
-               (a.seg[i].col_begin % 8 == 0);
+    if (a.nseg == 1 && a.seg[0].fmt == SEG_TRANSPOSED) {
+        // single transposed output: LDS-transposed epilogue, 8-token pieces (an image's tokens start 16-byte aligned)
+        const IGemmSeg& g = a.seg[0];
+        swap = swap && !a.geglu && !a.out16 && g.L > 0 && (g.L % 8 == 0) && (g.ld % 8 == 0) && (a.M % 8 == 0) &&
+               (((uintptr_t)g.out & 15) == 0);
+    } else {
+        for (int i = 0; i < a.nseg; ++i)
+            swap = swap && a.seg[i].fmt == SEG_ROW && (a.seg[i].ld % 8 == 0) && (((uintptr_t)a.seg[i].out & 15) == 0) &&
+                   (a.seg[i].col_begin % 8 == 0);
+    }
     if (a.res) swap = swap && (a.ldres % 8 == 0) && (((uintptr_t)a.res & 15) == 0);
     if (a.out16) swap = swap && (a.ld16 % 8 == 0) && (((uintptr_t)a.out16 & 15) == 0);
     if (a.bias) swap = swap && (((uintptr_t)a.bias & 15) == 0);

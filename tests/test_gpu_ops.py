@@ -148,6 +148,29 @@ def test_qkv_segments(ops, gpu):
     report("qkv seg (L=77) v^T", rel_inf(vt2[:, :, :L2], ref2[:, 2 * Cc:].reshape(B2, L2, Cc).permute(0, 2, 1)))
 
 
+@pytest.mark.parametrize("B,Ltok,K,N", [(3, 16384, 512, 320), (2, 64, 1280, 1280), (5, 192, 320, 640), (8, 4096, 512, 640)])
+def test_single_transposed_output_epilogue(ops, gpu, B, Ltok, K, N):
+    """proj_out -> NCHW and the V^T operand: one transposed segment goes through the LDS-transposed epilogue of the
+    swapped-operand kernel; bias, per-image vector, residual (fp32 / fp16, row-major), scale and the three output
+    dtypes; token counts that put two images into one wave tile (64) or leave an M tail (5 x 192)."""
+    M = B * Ltok
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias, rv, res = rnd(N, seed=3), rnd(B, N, seed=4), rnd(M, N, seed=5)
+    wp = ops.pack_linear_w(w.to(gpu))
+    xg = x.half().to(gpu)
+    Lpad = (Ltok + 63) // 64 * 64 + 64
+    base = x.half().float() @ w.half().float().t() + bias + rv.repeat_interleave(Ltok, 0)
+    for res_dt, out_dt in ((torch.float32, torch.float16), (torch.float16, torch.float32), (None, torch.bfloat16)):
+        r = res.to(res_dt).to(gpu) if res_dt is not None else None
+        ref = (base + (r.float().cpu() if r is not None else 0)) * 0.7
+        out = torch.zeros(B, N, Lpad, dtype=out_dt, device=gpu)
+        ops.igemm(xg, K, wp, M, N, K, bias=bias.to(gpu), rowvec=rv.to(gpu), rows_per_img=Ltok, res=r, ldres=N, scale=0.7,
+                  segs=[(out, Lpad, 0, N, ops.SEG_TRANSPOSED, Ltok)])
+        report("transposed out B%d L%d K%d N%d res=%s out=%s" % (B, Ltok, K, N, res_dt, out_dt),
+               rel_inf(out[:, :, :Ltok], ref.reshape(B, Ltok, N).permute(0, 2, 1)), 1e-2 if out_dt == torch.bfloat16 else TOL)
+        assert out[:, :, Ltok:].abs().max().item() == 0.0
+
+
 def test_temporal_conv(ops, gpu):
     b, Fr, HW, Cc = 2, 5, 48, 64
     x = rnd(b, Cc, Fr, HW, 1, seed=1)            # b c f h w
