@@ -7,6 +7,7 @@
 
 typedef _Float16 half_t;
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -66,7 +67,8 @@ __device__ __forceinline__ void store_from_f32(void* p, size_t i, int dt, float 
     else if (dt == DT_F16) ((half_t*)p)[i] = (half_t)v;
     else ((u16*)p)[i] = f32_to_bf16(v);
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division (~10 VALU): SiLU sits in GEMM epilogues and the GroupNorm apply pass
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact (erf) GELU with erf from Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below fp16 resolution):
 // ~12 VALU instead of libm erff's ~50, which dominated the GEGLU GEMM epilogue
 __device__ __forceinline__ float gelu_erf_f(float x) {
