@@ -27,7 +27,9 @@ class IGemmDesc(C.Structure):
                 ("res", C.c_void_p), ("ldres", C.c_int64), ("scale", C.c_float), ("geglu", C.c_int32),
                 ("nseg", C.c_int32), ("act", C.c_int32), ("res_f32", C.c_int32), ("pad3_", C.c_int32),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
-                ("out16", C.c_void_p), ("ld16", C.c_int64), ("seg", IGemmSeg * 3)]
+                ("out16", C.c_void_p), ("ld16", C.c_int64),
+                ("blend_mix", C.c_void_p), ("blend_x", C.c_void_p), ("ld_blend", C.c_int64), ("blend_f32", C.c_int32), ("pad4_", C.c_int32),
+                ("seg", IGemmSeg * 3)]
 
 
 class AttnDesc(C.Structure):

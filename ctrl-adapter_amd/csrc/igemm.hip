@@ -405,6 +405,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] *= a.scale;
+                if (a.blend_mix) {   // AlphaBlender fold: (1-a) * this branch + a * the other branch
+                    const float al = __builtin_amdgcn_rcpf(1.0f + __expf(-a.blend_mix[0]));
+                    float bx[8];
+                    if (a.blend_f32) {
+                        const float* bp = (const float*)a.blend_x + (size_t)row * a.ld_blend + ocol;
+                        const f4 b0 = *(const f4*)bp, b1 = *(const f4*)(bp + 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { bx[i] = b0[i]; bx[4 + i] = b1[i]; }
+                    } else {
+                        const h8 bb = *(const h8*)((const half_t*)a.blend_x + (size_t)row * a.ld_blend + ocol);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) bx[i] = (float)bb[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
+                }
                 if (a.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
                     h8 pk;
 #pragma unroll
@@ -545,6 +561,21 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmArgs a, const f
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] *= a.scale;
+        if (a.blend_mix) {
+            const float al = __builtin_amdgcn_rcpf(1.0f + __expf(-a.blend_mix[0]));
+            float bx[8];
+            if (a.blend_f32) {
+                const float* bp = (const float*)a.blend_x + row * a.ld_blend + col;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bx[j] = bp[j];
+            } else {
+                const h8 bb = *(const h8*)((const half_t*)a.blend_x + row * a.ld_blend + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bx[j] = (float)bb[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = al * bx[j] + (1.0f - al) * x[j];
+        }
         const size_t o = row * sg.ld + col;
         if (sg.dtype == DT_F32) {
             *(f4*)((float*)sg.out + o) = f4{x[0], x[1], x[2], x[3]};
@@ -600,6 +631,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         // partial sums go to fp32 slabs [splitk][M][Nout]; every epilogue term is applied once, by the finish kernel
         IGemmArgs p = a;
         p.bias = nullptr; p.rowvec = nullptr; p.res = nullptr; p.res_f32 = 0; p.act = 0; p.scale = 1.f; p.out16 = nullptr;
+        p.blend_mix = nullptr; p.blend_x = nullptr;
         p.nseg = 1;
         p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
         prof_detail("M%d N%d K%d taps%d tile%dx%dx%d splitk%d", a.M, a.Nout, a.Ktot, a.taps, BM, BN, BK, splitk);
@@ -633,6 +665,7 @@ bool can_swap(const IGemmArgs& a) {
     }
     if (a.res) swap = swap && (a.ldres % 8 == 0) && (((uintptr_t)a.res & 15) == 0);
     if (a.out16) swap = swap && (a.ld16 % 8 == 0) && (((uintptr_t)a.out16 & 15) == 0);
+    if (a.blend_mix) swap = swap && a.blend_x && (a.ld_blend % 8 == 0) && (((uintptr_t)a.blend_x & 15) == 0);
     if (a.bias) swap = swap && (((uintptr_t)a.bias & 15) == 0);
     if (a.rowvec) swap = swap && (a.rowvec_ld % 4 == 0) && (((uintptr_t)a.rowvec & 15) == 0);
     return swap;
@@ -702,6 +735,8 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(a.nseg >= 1 && a.nseg <= 3, "igemm: nseg must be 1..3");
     CTRL_CHECK(!a.geglu || (a.Nout % 32) == 0, "igemm: GEGLU needs Nout % 32 == 0");
     CTRL_CHECK(!a.out16 || (a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a)), "igemm: the fp16 mirror needs a single aligned row-major output");
+    CTRL_CHECK(!a.blend_mix || (a.blend_x && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && !a.geglu && can_swap(a)),
+               "igemm: the blend fold needs a single aligned row-major output and an aligned blend operand");
     for (int i = 0; i < a.nseg; ++i) {
         CTRL_CHECK(a.seg[i].col_begin % 16 == 0, "igemm: segment boundary must be a multiple of 16");
         CTRL_CHECK(a.seg[i].out != nullptr, "igemm: null segment output");

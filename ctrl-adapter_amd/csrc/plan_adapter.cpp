@@ -126,8 +126,10 @@ struct AFwd {
 };
 
 // temporal ResNet on frame-major rows [(b f) hw][C]
+// blend_mix (optional): AlphaBlender fold -- out = a*x + (1-a)*TemporalResnet(x), a = sigmoid(*blend_mix); the spatial
+// branch of the blender IS this block's input (adapter_spatial_temporal.py:226-229), so the last conv's epilogue does it
 int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, const AFwd& a, int HW, int C,
-                        const float* temb /*[N][C]*/) {
+                        const float* temb /*[N][C]*/, const float* blend_mix) {
     const size_t mk = cx.mark();
     const int N = a.N, M = N * HW;
     float* tp = cx.f((size_t)N * C);
@@ -147,13 +149,16 @@ int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, 
     g2.A = n2; g2.W = w.conv2.w; g2.bias = w.conv2.b; g2.rowvec = nullptr;
     set_res(g2, x, C);
     set_out(g2, out, C, C);
+    set_blend(g2, blend_mix, x, C);
     RUN(cx, op_igemm(g2, cx.s));
     cx.release(mk);
     return 0;
 }
 
 // TemporalBasicTransformerBlock on frame-major tokens X [(b f) L][512]; every op but the attention is per token
-int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, const AFwd& a, int L) {
+// blend_mix / blend_other (optional): out = a*blend_other + (1-a)*block(X), folded into the last GEMM's epilogue
+int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, const AFwd& a, int L,
+                    const float* blend_mix, const TV& blend_other) {
     const size_t mk = cx.mark();
     const int M = a.N * L, dim = w.dim, Ci = w.attn1.inner;
     // x = ff_in(norm_in(x)) + x
@@ -172,24 +177,20 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
     ta.QKV = qkv; ta.ld = 3 * Ci; ta.O = o; ta.ldo = Ci; ta.Bc = a.B; ta.F = a.F; ta.HW = L; ta.heads = w.attn1.heads;
     ta.scale = 0.125f;
     RUN(cx, op_temporal_attn(ta, cx.s));
-    TV x1 = stream_alloc(cx, (size_t)M * dim, false);
-    TRY(run_linear(cx, w.attn1.out, o, Ci, x1, dim, M, x0, dim));
-    // x = attn2(norm2(x), first-frame context) + x : one key => query independent (note N5)
+    // x = attn2(norm2(x), first-frame context) + attn1(...) + x : one key => the cross-attention term is one vector
+    // (note N5), added by the out-projection's epilogue.  Rows are (b f p) and the context is the broadcast vector or
+    // the first frame of the only clip: the same vector for every row.
     TV x2 = stream_alloc(cx, (size_t)M * dim, false);
     {
-        const EhsCtx& e = a.e_first;
-        float* v = cx.f((size_t)e.batch * Ci);
-        RUN(cx, op_linear_small(e.f32, e.cross, w.attn2.v.w, nullptr, v, Ci, e.batch, Ci, e.cross, 0, 0, cx.s));
-        float* ov = cx.f((size_t)e.batch * dim);
-        RUN(cx, op_linear_small(v, Ci, w.attn2.out.w, w.attn2.out.b, ov, dim, e.batch, dim, Ci, 0, 0, cx.s));
-        // rows are (b f p); context index = clip b  -> (row / (F*L)) % batch
-        RUN(cx, op_add_rowvec(x1.p, x1.dt, ov, dim, x2.p, x2.dt, (size_t)M, dim, a.F * L, e.batch, cx.s));
+        float* ov = nullptr;
+        TRY(single_key_vector(cx, w.attn2, dim, a.e_first, &ov));
+        TRY(run_linear(cx, w.attn1.out, o, Ci, x2, dim, M, x0, dim, ov, dim, M));
     }
     // x = ff(norm3(x)) + x
     TRY(run_layernorm(cx, w.norm3, x2, xn, M, dim));
     half_t* mid2 = mid;
     TRY(run_linear(cx, w.ff1, xn, dim, tv16(mid2), 4 * dim, M, TV(), 0));
-    TRY(run_linear(cx, w.ff2, mid2, 4 * dim, out, dim, M, x2, dim));
+    TRY(run_linear(cx, w.ff2, mid2, 4 * dim, out, dim, M, x2, dim, nullptr, 0, 0, blend_mix, blend_other));
     cx.release(mk);
     return 0;
 }
@@ -241,16 +242,11 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             CTRL_FAIL("adapter: up-sampling without a spatial resnet (F.interpolate path, :235-237) is not implemented");
         }
         if (tr) {
-            TV yt = stream_alloc(cx, (size_t)N * H * W * C, need16 && !sr);
-            TRY(run_temporal_resnet(cx, Lw.tres, x, yt, a, H * W, C, temb));
-            if (sr) {
-                TV yb = stream_alloc(cx, (size_t)N * H * W * C, false);
-                if (need16) { yb = tv16(cx.h((size_t)N * H * W * C)); }
-                RUN(cx, op_blend(x.p, x.dt, yt.p, yt.dt, Lw.res_mix, yb.p, yb.dt, (size_t)N * H * W * C, cx.s));
-                x = yb;
-            } else {
-                x = yt;
-            }
+            // with a spatial ResNet in front the AlphaBlender (:229) is folded into the temporal block's last conv
+            TV yt = stream_alloc(cx, (size_t)N * H * W * C, false);
+            if (need16) yt = tv16(cx.h((size_t)N * H * W * C));       // only a layout change follows: fp16 is enough
+            TRY(run_temporal_resnet(cx, Lw.tres, x, yt, a, H * W, C, temb, sr ? Lw.res_mix : nullptr));
+            x = yt;
         }
         if (has_tf) {
             const int Lt = H * W, M = N * Lt;
@@ -267,14 +263,15 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             if (tt) {
                 TV t3 = stream_alloc(cx, (size_t)M * INNER, false);
                 RUN(cx, op_add_rowvec(tok.p, tok.dt, femb, INNER, t3.p, t3.dt, (size_t)M, INNER, Lt, a.F, cx.s));
-                TV t4 = stream_alloc(cx, (size_t)M * INNER, !st);
-                TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt));
                 if (st) {
-                    // the blended tokens are consumed only as proj_out's operand: fp16
-                    half_t* t5 = cx.h((size_t)M * INNER);
-                    RUN(cx, op_blend(smix.p, smix.dt, t4.p, t4.dt, Lw.tr_mix, t5, DT_F16, (size_t)M * INNER, cx.s));
-                    tok = tv16(t5);
+                    // AlphaBlender (:282) folded into the temporal block's last GEMM; the blended tokens are consumed
+                    // only as proj_out's operand: fp16
+                    TV t5 = tv16(cx.h((size_t)M * INNER));
+                    TRY(run_temporal_tb(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix));
+                    tok = t5;
                 } else {
+                    TV t4 = stream_alloc(cx, (size_t)M * INNER, true);
+                    TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV()));
                     tok = t4;
                 }
             }

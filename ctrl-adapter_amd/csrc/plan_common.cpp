@@ -96,13 +96,16 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
     return 0;
 }
 
-int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, long ldy, int M, const TV& res, long ldres) {
+int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, long ldy, int M, const TV& res, long ldres,
+               const float* rowvec, int rowvec_ld, int rows_per_vec, const float* blend_mix, const TV& blend_other) {
     IGemmArgs g = {};
     g.A = x; g.lda = ldx; g.mode = IG_ROWS; g.Cin = l.K; g.taps = 1;
     g.W = l.w; g.M = M; g.Nout = l.N; g.Ktot = l.K;
     g.bias = l.b; g.scale = 1.f; g.geglu = l.geglu ? 1 : 0;
+    g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_img = rows_per_vec > 0 ? rows_per_vec : 1;
     set_res(g, res, ldres);
     set_out(g, y, ldy, l.geglu ? l.N / 2 : l.N);
+    set_blend(g, blend_mix, blend_other, ldy);
     RUN(cx, op_igemm(g, cx.s));
     return 0;
 }
@@ -144,7 +147,10 @@ static int run_attention(Ctx& cx, const half_t* Q, long ldq, const half_t* K, lo
 }
 
 // self attention on LN'd tokens; out = attn_out_proj(attn) + bias + resid
-static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, const TV& resid, const TV& out, int B, int L) {
+// `addvec` (optional): a per-image vector added to the block output by the out-projection's epilogue -- the
+// single-key cross-attention that follows the self-attention (note N5) costs no pass of its own
+static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, const TV& resid, const TV& out, int B, int L,
+                         const float* addvec = nullptr, int addvec_rows = 0) {
     const size_t mk = cx.mark();
     const int M = B * L, Ci = w.inner;
     const int Lpad = (L + 63) / 64 * 64;
@@ -166,8 +172,19 @@ static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, con
     RUN(cx, op_igemm(gv, cx.s));
     half_t* o = cx.h((size_t)M * Ci);
     TRY(run_attention(cx, qk, 2 * Ci, qk + Ci, 2 * Ci, vt, Lpad, o, Ci, B, B, w.heads, w.D, L, L));
-    TRY(run_linear(cx, w.out, o, Ci, out, dim, M, resid, dim));
+    TRY(run_linear(cx, w.out, o, Ci, out, dim, M, resid, dim, addvec, dim, addvec_rows));
     cx.release(mk);
+    return 0;
+}
+
+// out-projection of the single value vector of a one-key cross-attention: softmax over one key == 1, so the attention
+// output is to_out(to_v(ctx)) for every query of the image (SURVEY.md note N5): [e.batch][dim] fp32
+int single_key_vector(Ctx& cx, const AttnW& w, int dim, const EhsCtx& e, float** out) {
+    float* v = cx.f((size_t)e.batch * w.inner);
+    RUN(cx, op_linear_small(e.f32, e.cross, w.v.w, nullptr, v, w.inner, e.batch, w.inner, e.cross, 0, 0, cx.s));
+    float* o = cx.f((size_t)e.batch * dim);
+    RUN(cx, op_linear_small(v, w.inner, w.out.w, w.out.b, o, dim, e.batch, dim, w.inner, 0, 0, cx.s));
+    *out = o;
     return 0;
 }
 
@@ -178,10 +195,8 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, 
     const int M = B * L, Ci = w.inner;
     if (e.Lk == 1) {
         // softmax over one key == 1  =>  out = to_out(to_v(ctx)) for every query of the image
-        float* v = cx.f((size_t)e.batch * Ci);
-        RUN(cx, op_linear_small(e.f32, e.cross, w.v.w, nullptr, v, Ci, e.batch, Ci, e.cross, 0, 0, cx.s));
-        float* o = cx.f((size_t)e.batch * dim);
-        RUN(cx, op_linear_small(v, Ci, w.out.w, w.out.b, o, dim, e.batch, dim, Ci, 0, 0, cx.s));
+        float* o = nullptr;
+        TRY(single_key_vector(cx, w, dim, e, &o));
         RUN(cx, op_add_rowvec(x.p, x.dt, o, dim, out.p, out.dt, (size_t)M, dim, L, e.batch, cx.s));
         cx.release(mk);
         return 0;
@@ -230,10 +245,18 @@ int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, 
     const int M = B * L, dim = w.dim;
     half_t* xn = cx.h((size_t)M * dim);
     TRY(run_layernorm(cx, w.norm1, X, xn, M, dim));
-    TV x1 = stream_alloc(cx, (size_t)M * dim, false);
-    TRY(run_self_attn(cx, w.attn1, xn, dim, X, x1, B, L));
     TV x2 = stream_alloc(cx, (size_t)M * dim, false);
-    TRY(run_cross_attn(cx, w.attn2, w.norm2, x1, dim, x2, B, L, e));
+    if (e.Lk == 1) {
+        // x2 = X + attn1(norm1 X) + to_out(to_v(ctx)): the query-independent cross-attention term rides on the self-
+        // attention's out-projection epilogue (per-image vector; one vector for all rows when the context is broadcast)
+        float* ov = nullptr;
+        TRY(single_key_vector(cx, w.attn2, dim, e, &ov));
+        TRY(run_self_attn(cx, w.attn1, xn, dim, X, x2, B, L, ov, e.batch == 1 ? M : L));
+    } else {
+        TV x1 = stream_alloc(cx, (size_t)M * dim, false);
+        TRY(run_self_attn(cx, w.attn1, xn, dim, X, x1, B, L));
+        TRY(run_cross_attn(cx, w.attn2, w.norm2, x1, dim, x2, B, L, e));
+    }
     TRY(run_ff(cx, w.norm3, w.ff1, w.ff2, x2, dim, out, M));
     cx.release(mk);
     return 0;

@@ -299,6 +299,11 @@ inline void set_out(IGemmArgs& g, const TV& out, long ld, int ncols) {
 inline void set_res(IGemmArgs& g, const TV& res, long ld) {
     g.res = res.p; g.ldres = ld; g.res_f32 = (res.ok() && res.dt == DT_F32) ? 1 : 0;
 }
+// AlphaBlender fold: result = (1-a) * (this GEMM's epilogue value) + a * other, a = sigmoid(*mix)  (mix = null: off)
+inline void set_blend(IGemmArgs& g, const float* mix, const TV& other, long ld) {
+    g.blend_mix = mix; g.blend_x = mix ? other.p : nullptr; g.ld_blend = ld;
+    g.blend_f32 = (mix && other.dt == DT_F32) ? 1 : 0;
+}
 
 // ------------------------------------------------------------------------------------------ block runners
 // y = GroupNorm(x) (optional SiLU);  x [imgs*rows][C] fp16 or fp32 stream, y fp16
@@ -311,7 +316,10 @@ struct ConvOpts {
     int act = 0;
 };
 int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int Hin, int Win, const ConvOpts& o);
-int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, long ldy, int M, const TV& res, long ldres);
+// rowvec (optional): fp32 [M / rows_per_vec][rowvec_ld] added to every row of its group by the GEMM epilogue
+int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, long ldy, int M, const TV& res, long ldres,
+               const float* rowvec = nullptr, int rowvec_ld = 0, int rows_per_vec = 0,
+               const float* blend_mix = nullptr, const TV& blend_other = TV());
 // out = ResnetBlock2D(x, temb); temb_proj = rowvec [N][ld] (already time_emb_proj(SiLU(emb)) incl. bias).
 // x.m16 must exist when the block has a shortcut conv (it is that conv's operand).
 int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int H, int W, int up,
@@ -320,4 +328,6 @@ int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int
 struct EhsCtx { const half_t* h16 = nullptr; const float* f32 = nullptr; int batch = 1, Lk = 0, cross = 0; };
 // X [B*L][dim] stream -> out stream (out.m16 is filled when the caller needs a GEMM-operand copy)
 int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e);
+// [e.batch][dim] fp32 output of a one-key cross-attention (query independent, note N5)
+int single_key_vector(Ctx& cx, const AttnW& w, int dim, const EhsCtx& e, float** out);
 int run_layernorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int M, int dim);

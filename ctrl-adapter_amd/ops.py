@@ -47,7 +47,8 @@ def pack_vec(v, geglu=False):
 
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
-          res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None):
+          res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None,
+          blend_mix=None, blend_x=None, ld_blend=0):
     """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
@@ -67,6 +68,10 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.splitk_ws = splitk_ws.data_ptr() if splitk_ws is not None else None
     d.splitk_ws_bytes = splitk_ws.numel() * splitk_ws.element_size() if splitk_ws is not None else 0
     d.ld16 = ld16
+    d.blend_mix = blend_mix.data_ptr() if blend_mix is not None else None
+    d.blend_x = blend_x.data_ptr() if blend_x is not None else None
+    d.ld_blend = ld_blend
+    d.blend_f32 = int(blend_x is not None and blend_x.dtype == torch.float32)
     d.scale = scale; d.geglu = int(geglu)
     d.nseg = len(segs)
     for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):

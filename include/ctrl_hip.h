@@ -78,6 +78,9 @@ typedef struct ctrl_igemm_desc {
     int32_t pad3_;
     void* splitk_ws; int64_t splitk_ws_bytes;   /* optional fp32 scratch: enables split-K for small-M / long-K problems */
     void* out16; int64_t ld16;   /* optional fp16 row-major mirror of the (single, row-major) output: GEMM-operand copy of an fp32 stream */
+    /* optional AlphaBlender fold (diffusers AlphaBlender, model/adapter_spatial_temporal.py:229,282), row-major outputs
+     * only: out = (1-a) * y + a * blend_x[m*ld_blend + n], a = sigmoid(*blend_mix), y = the epilogue result above */
+    const float* blend_mix; const void* blend_x; int64_t ld_blend; int32_t blend_f32; int32_t pad4_;
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
