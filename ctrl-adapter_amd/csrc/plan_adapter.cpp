@@ -310,7 +310,27 @@ struct ctrl_adapter {
     int* map_host = nullptr;
     int* map_dev = nullptr;
     std::vector<int> map_cur;
+    // Lanes: the adapter blocks are independent of each other (ctrl_adapter.py:181-205), so blocks of different
+    // resolutions run on different HIP streams (lane 0 = the caller's stream) and the small low-resolution blocks fill
+    // the CUs the big ones leave idle at their tile-wave tails.  Forked / joined with events: hipGraph-capturable.
+    static constexpr int kLanes = 4;
+    hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[kLanes - 1] = {nullptr, nullptr, nullptr};
+    size_t lane_need[kLanes] = {0, 0, 0, 0};
+    int init_lanes() {
+        for (int i = 0; i < kLanes - 1; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        return 0;
+    }
     ~ctrl_adapter() {
+        for (int i = 0; i < kLanes - 1; ++i) {
+            if (side[i]) (void)hipStreamDestroy(side[i]);
+            if (join_ev[i]) (void)hipEventDestroy(join_ev[i]);
+        }
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
         if (packer) packer->release_all();
         if (map_host) (void)hipHostFree(map_host);
         if (map_dev) (void)hipFree(map_dev);
@@ -325,6 +345,7 @@ struct AdapterCall {
     const void* ehs; int ehs_dt; int ehs_batch; int Lk;
     void* const* outs; int out_dt;
     const int* map_dev; const int32_t* map_host; int N_out;     // frame scatter (null / null / N when off)
+    ctrl_adapter* plan; int nlanes;                             // stream lanes (1 = everything on the caller's stream)
 };
 
 size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
@@ -381,13 +402,41 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     static const int slot_c[12] = {320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280};
     static const int slot_f[12] = {1, 1, 1, 2, 2, 2, 4, 4, 4, 8, 8, 8};
     const int up = c.backbone_sdxl ? 2 : 1;
+    // ---- lanes: one per pyramid level (slot_f = 1, 2, 4, 8 + mid); each lane owns a disjoint workspace region ----
+    const int nl = k.nlanes;
+    ctrl_adapter* P = k.plan;
+    hipStream_t const main_s = cx.s;
+    const size_t common_end = (cx.mark() + 255) & ~(size_t)255;
+    size_t lane_base[ctrl_adapter::kLanes];
+    {
+        size_t off = common_end;
+        for (int l = 0; l < ctrl_adapter::kLanes; ++l) { lane_base[l] = off; off += cx.dry ? 0 : P->lane_need[l]; }
+        if (cx.dry) for (int l = 0; l < ctrl_adapter::kLanes; ++l) P->lane_need[l] = 0;
+    }
+    if (!cx.dry && nl > 1) {
+        HIP_TRY(hipEventRecord(P->fork_ev, main_s));
+        for (int l = 1; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(P->side[l - 1], P->fork_ev, 0));
+    }
+    auto lane_of = [&](int f) { const int l = f == 1 ? 0 : (f == 2 ? 1 : (f == 4 ? 2 : 3)); return l % nl; };
+    auto run_in_lane = [&](int lane, const AdapterBlockW& bw, const void* in, void* out, int h, int wd, size_t frame_elems) -> int {
+        cx.s = lane == 0 ? main_s : P->side[lane - 1];
+        cx.ar->off = lane_base[lane];
+        if (cx.dry) cx.ar->peak = lane_base[lane];
+        TRY(run_block(cx, bw, c, a, in, out, h, wd));
+        TRY(fill_holes(out, frame_elems));
+        if (cx.dry) {
+            const size_t need = (cx.ar->peak - lane_base[lane] + 255) & ~(size_t)255;
+            if (need > P->lane_need[lane]) P->lane_need[lane] = need;
+        }
+        cx.s = main_s;
+        return 0;
+    };
     size_t bi = 0;
     for (int i = 0; i < 12; ++i) {
         const int h = std::max(k.H0 / slot_f[i], 1), wd = std::max(k.W0 / slot_f[i], 1);
         const bool has = bi < w.slot_ids.size() && w.slot_ids[bi] == i;
         if (has) {
-            TRY(run_block(cx, w.blocks[bi], c, a, k.ins[i], k.outs[i], h, wd));
-            TRY(fill_holes(k.outs[i], (size_t)slot_c[i] * h * up * wd * up));
+            TRY(run_in_lane(lane_of(slot_f[i]), w.blocks[bi], k.ins[i], k.outs[i], h, wd, (size_t)slot_c[i] * h * up * wd * up));
             ++bi;
         } else {
             // torch.zeros_like(down_block_res_samples[i])  (ctrl_adapter.py:193): input-sized, not up-sampled
@@ -396,9 +445,20 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     }
     if (w.has_mid && k.ins[12] && k.outs[12]) {
         const int h = std::max(k.H0 / 8, 1), wd = std::max(k.W0 / 8, 1);
-        TRY(run_block(cx, w.mid, c, a, k.ins[12], k.outs[12], h, wd));
-        TRY(fill_holes(k.outs[12], (size_t)1280 * h * wd));
+        TRY(run_in_lane(lane_of(8), w.mid, k.ins[12], k.outs[12], h, wd, (size_t)1280 * h * wd));
     }
+    if (!cx.dry && nl > 1) {
+        for (int l = 1; l < nl; ++l) {
+            HIP_TRY(hipEventRecord(P->join_ev[l - 1], P->side[l - 1]));
+            HIP_TRY(hipStreamWaitEvent(main_s, P->join_ev[l - 1], 0));
+        }
+    }
+    if (cx.dry) {
+        size_t tot = common_end;
+        for (int l = 0; l < ctrl_adapter::kLanes; ++l) tot += P->lane_need[l];
+        cx.ar->peak = tot;
+    }
+    cx.ar->off = common_end;
     return 0;
 }
 
@@ -432,6 +492,7 @@ int ctrl_adapter_create(const ctrl_adapter_config* cfg, const ctrl_tensor_ref* t
     h->packer.reset(new Packer(tensors, n_tensors, (hipStream_t)stream));
     int rc = build_adapter(*h->packer, *cfg, &h->w);
     if (rc) return rc;
+    TRY(h->init_lanes());
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     *out = h.release();
     return 0;
@@ -477,8 +538,11 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     } else {
         N_out = N;
     }
+    // lanes are off while the per-launch profiler is recording (overlapping kernels make per-kernel times meaningless)
+    static const int env_lanes = getenv("CTRL_ADAPTER_LANES") ? atoi(getenv("CTRL_ADAPTER_LANES")) : ctrl_adapter::kLanes;
+    const int nlanes = g_prof_on ? 1 : std::min(std::max(env_lanes, 1), (int)ctrl_adapter::kLanes);
     AdapterCall k = {ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states, ehs_dtype,
-                     ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out};
+                     ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out, h, nlanes};
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
