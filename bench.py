@@ -149,8 +149,10 @@ def main():
         # HBM traffic per launch of that class: PMC FETCH_SIZE/WRITE_SIZE passes of this same command, measured with
         # rocprofv3 (cannot run inside the benchmark), corrected per MI355X_MICROARCH.md, committed under profiles/
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if workload == "sdxl" and n == 8 and os.path.exists(tfile):
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")))      # latest round / version
+        tfile = tfiles[-1] if tfiles else ""
+        if workload == "sdxl" and n == 8 and tfile:
             with open(tfile) as fh:
                 traffic = json.load(fh)["classes"].get(dom, {}).get("hbm_bytes_per_launch_corrected")
         if raw[2] > 0:      # MFMA-bound class (implicit GEMM / flash attention): algorithmic FLOPs / HIP-event time

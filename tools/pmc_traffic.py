@@ -1,0 +1,67 @@
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py into profiles/<round>_pmc_hbm_traffic.json.
+
+  python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_in_run> <out.json>
+
+Each directory holds the *_counter_collection.csv of ONE pass (counters are collected in their own runs, never combined
+with sys/hip/hsa tracing).  Corrections follow MI355X_MICROARCH.md (HBM section): gfx950 reports FETCH_SIZE (KiB) at half
+of the bytes of coalesced 16-B streams -> x2; WRITE_SIZE (KiB) is taken as is.  Kernels are grouped into the same classes
+the library's profiler uses (igemm_rows / igemm_conv / igemm_temporal / flash_attn / ...).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def kernel_class(name):
+    m = re.search(r"igemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)", name)
+    if m:
+        return {"0": "igemm_rows", "1": "igemm_conv", "2": "igemm_temporal"}[m.group(1)]
+    for key in ("splitk_finish", "flash_attn", "temporal_attn", "gn_stats", "gn_apply", "layernorm", "conv3x3_direct",
+                "linear_small", "nchw_to_nhwc", "nhwc_to_nchw", "avgpool", "sincos", "blend", "add_rowvec", "merge"):
+        if key in name:
+            return key
+    return None
+
+
+def collect(directory, counter):
+    tot, launches = {}, {}
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter:
+                    continue
+                cls = kernel_class(row["Kernel_Name"])
+                if cls is None:
+                    continue
+                tot[cls] = tot.get(cls, 0.0) + float(row["Counter_Value"])
+                launches[cls] = launches.get(cls, 0) + 1
+    return tot, launches
+
+
+def main():
+    fetch_dir, write_dir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    f, fl = collect(fetch_dir, "FETCH_SIZE")
+    w, _ = collect(write_dir, "WRITE_SIZE")
+    classes = {}
+    for cls in sorted(f):
+        lps = fl[cls] / steps
+        fkb, wkb = f[cls] / steps, w.get(cls, 0.0) / steps
+        tot = (2.0 * fkb + wkb) * 1024.0
+        classes[cls] = {"launches_per_step": lps, "fetch_kb_per_step": round(fkb), "write_kb_per_step": round(wkb),
+                        "hbm_bytes_per_step_corrected": round(tot), "hbm_bytes_per_launch_corrected": round(tot / lps)}
+    doc = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `CTRL_ADAPTER_LANES=1 python bench.py "
+                    "--no-graph --no-cpu-baseline --steps 2 --warmup 1` (%d steps in total, one stream so that counters "
+                    "attribute to one kernel at a time); FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM (gfx950 "
+                    "reports 1/2 of coalesced 16-B streams); WRITE_SIZE taken as is" % steps,
+           "classes": classes,
+           "total_hbm_bytes_per_step_corrected": sum(c["hbm_bytes_per_step_corrected"] for c in classes.values())}
+    with open(out, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in classes.items()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r01 v4
+# Writes under gpurun_out/final/; copy what should be judged into profiles/.
+set -u
+R=${1:-r01}; V=${2:-v4}
+O=gpurun_out/final; mkdir -p $O
+export TMPDIR=/tmp
+(python -m pytest tests/test_gpu_ops.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_op_parity_${V}.log
+(python -m pytest tests/test_gpu_e2e.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_e2e_parity_${V}.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/${R}_smoke_${V}.log 2>&1
+python bench.py > $O/${R}_bench_${V}.json 2> $O/bench.err
+python bench.py --workload svd16 --steps 10 --warmup 3 > $O/${R}_bench_svd16_${V}.json 2>> $O/bench.err
+timeout 300 python tools/microbench.py > $O/${R}_microbench_${V}.log 2>&1
+# per-kernel time of the same command (its own run: no counters)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/stats.log 2>&1
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/${R}_rocprofv3_kernel_stats_${V}.csv
+# HBM traffic: one counter per pass, nothing but the counter collection; one stream so that counters attribute cleanly
+for c in FETCH_SIZE WRITE_SIZE; do
+  CTRL_ADAPTER_LANES=1 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --no-graph --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_$c.log 2>&1
+done
+# warmup 1 + timed 2 + 3 profiled steps + 2 eager steps before capture are all counted: steps = number of avgpool launches
+STEPS=$(grep -h avgpool $O/pmc_FETCH_SIZE/*/*counter_collection.csv | wc -l)
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $STEPS $O/${R}_pmc_hbm_traffic_${V}.json
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/stats/*/*kernel_trace.csv
+tail -2 $O/${R}_op_parity_${V}.log $O/${R}_e2e_parity_${V}.log $O/${R}_smoke_${V}.log; cat $O/${R}_bench_${V}.json | head -c 600
