@@ -16,7 +16,8 @@ import sys
 
 
 def kernel_class(name):
-    m = re.search(r"igemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)", name)
+    m = re.search(r"igemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)", name) or \
+        re.search(r"igemm_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)      # demangled or mangled
     if m:
         return {"0": "igemm_rows", "1": "igemm_conv", "2": "igemm_temporal"}[m.group(1)]
     for key in ("splitk_finish", "flash_attn", "temporal_attn", "gn_stats", "gn_apply", "layernorm", "conv3x3_direct",
