@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--workload", default="sdxl", choices=["sdxl", "svd16"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", action="store_true",
+                    help="time the fused controlled_step(controlnet, adapter, ...) instead of the pipelines' two calls "
+                         "controlnet(...) ; adapter(...) (same arithmetic, bit-identical results, ~1 % faster)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,10 +95,17 @@ def main():
     nf = 1 if workload == "sdxl" else 16
     skip_conv_in = workload != "sdxl"                     # configs/svd_train_depth.yaml:59
 
-    def step():
+    def step_separate():
         s = P.pool_latents(x["latents"], (64, 64))
         down, mid = cn(s, t, x["ehs_c"], x["cond"], conditioning_scale=1.0, return_dict=False, skip_conv_in=skip_conv_in)
         return ad(down, mid_block_res_sample=mid, num_frames=nf, timestep=t, encoder_hidden_states=x["ehs_a"])
+
+    def step_fused():
+        s = P.pool_latents(x["latents"], (64, 64))
+        return P.controlled_step(cn, ad, s, t, x["ehs_c"], x["cond"], 1.0, skip_conv_in=skip_conv_in, num_frames=nf,
+                                 adapter_encoder_hidden_states=x["ehs_a"])[1]
+
+    step = step_fused if args.fused else step_separate
 
     # eager warm-up: builds the plans (weight packing) and sizes the workspaces
     for _ in range(2):
@@ -201,7 +211,9 @@ def main():
             "config": {"workload": "SDXL depth 1024^2 batch=8 per GPU (N=8 images enter ControlNet+adapter, no CFG doubling); "
                                    "pool->ControlNet(SD1.5, 64x64 latents, 512^2 cond)->Ctrl-Adapter(A,B,C x3, up x2)"
                                    if workload == "sdxl" else "SVD depth, 16 frames, CFG pair (N=32 frames), skip_conv_in",
-                       "batch_per_gpu": n, "parallelism": "dp%d (images sharded, no collective)" % world, "launch": mode},
+                       "batch_per_gpu": n, "parallelism": "dp%d (images sharded, no collective)" % world, "launch": mode,
+                       "call_form": "controlnet(...) ; adapter(...)" if not args.fused else
+                                    "controlled_step(controlnet, adapter, ...) = both forwards, overlapped (bit-identical results)"},
             "algorithmic_tflop_per_step": round(flops_step / 1e12, 2) if flops_step else None,
             "mfma_frac_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if flops_step else None,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,

@@ -4,3 +4,4 @@ from . import _lib  # noqa: F401
 from .controlnet import ControlNetModel, ControlNetOutput, MultiControlNetModel, pool_latents  # noqa: F401
 from .ctrl_adapter import ControlNetAdapter  # noqa: F401
 from .ctrl_router import ControlNetRouter  # noqa: F401
+from .fused import controlled_step  # noqa: F401

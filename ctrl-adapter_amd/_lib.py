@@ -82,6 +82,7 @@ EXPORTS = [
     "ctrl_adapter_param_count", "ctrl_adapter_param_spec", "ctrl_adapter_create", "ctrl_adapter_destroy",
     "ctrl_adapter_forward",
     "ctrl_adapter_forward_scatter",
+    "ctrl_step_forward",
     "ctrl_router_weights", "ctrl_router_merge",
 ]
 

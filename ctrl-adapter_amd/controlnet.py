@@ -84,12 +84,24 @@ class ControlNetModel(ParamTreeModule):
             self._plan = h
         return self._plan
 
-    @torch.no_grad()
-    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0,
-                class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
-                cross_attention_kwargs=None, guess_mode=False, return_dict=True, skip_conv_in=False, skip_time_emb=False):
-        if class_labels is not None or timestep_cond is not None or attention_mask is not None:
-            raise ValueError("class_labels / timestep_cond / attention_mask are not supported by the HIP hot path")
+    def _launch_args(self, sample, timestep, ehs, controlnet_cond, conditioning_scale, guess_mode, skip_conv_in,
+                     skip_time_emb, out_dtype):
+        """Output tensors + the C argument list shared by ctrl_controlnet_forward and ctrl_step_forward
+        (everything between the plan handle and the stream); the third value keeps the marshalled inputs alive."""
+        N, _, Hs, Ws = sample.shape
+        t = timesteps_to_device_f32(timestep, N, sample.device)
+        outs = [torch.empty(N, c, max(Hs // f, 1), max(Ws // f, 1), dtype=out_dtype, device=sample.device)
+                for c, f in zip(self._slot_channels, self._slot_factor)]
+        outs.append(torch.empty(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device))
+        sample_c, ehs_c, cond_c = sample.contiguous(), ehs.contiguous(), controlnet_cond.contiguous()
+        ptrs = (C.c_void_p * 13)(*[o.data_ptr() for o in outs])
+        flags = (1 if skip_conv_in else 0) | (2 if skip_time_emb else 0) | (4 if guess_mode else 0)
+        args = [L.ptr(sample_c), L.dtype_code(sample_c.dtype), N, Hs, Ws, L.ptr(t), t.numel(),
+                L.ptr(ehs_c), L.dtype_code(ehs_c.dtype), ehs_c.shape[1], L.ptr(cond_c), L.dtype_code(cond_c.dtype),
+                C.c_float(float(conditioning_scale)), flags, ptrs, L.dtype_code(out_dtype)]
+        return outs, args, (t, sample_c, ehs_c, cond_c, ptrs)
+
+    def _check_inputs(self, sample, encoder_hidden_states, controlnet_cond):
         if not sample.is_cuda:
             raise RuntimeError("ControlNetModel (libctrlhip) runs on the GPU only; there is no CPU fallback")
         N, _, Hs, Ws = sample.shape
@@ -98,7 +110,17 @@ class ControlNetModel(ParamTreeModule):
         ehs = encoder_hidden_states
         if ehs.dim() != 3 or ehs.shape[0] != N or ehs.shape[2] != self.config.cross_attention_dim:
             raise ValueError("encoder_hidden_states must be [N, L, %d]" % self.config.cross_attention_dim)
-        out_dtype = sample.dtype if sample.dtype in (torch.float16, torch.bfloat16, torch.float32) else self.dtype
+        return sample.dtype if sample.dtype in (torch.float16, torch.bfloat16, torch.float32) else self.dtype
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0,
+                class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
+                cross_attention_kwargs=None, guess_mode=False, return_dict=True, skip_conv_in=False, skip_time_emb=False):
+        if class_labels is not None or timestep_cond is not None or attention_mask is not None:
+            raise ValueError("class_labels / timestep_cond / attention_mask are not supported by the HIP hot path")
+        out_dtype = self._check_inputs(sample, encoder_hidden_states, controlnet_cond)
+        N, _, Hs, Ws = sample.shape
+        ehs = encoder_hidden_states
         if isinstance(conditioning_scale, (int, float)) and conditioning_scale == 0:
             # control switched off for this step (controlnet_keep == 0, sdxl pipeline :1262-1266): every output of the
             # reference is `conv(x) * 0`; return the zeros without running the network (SURVEY.md note N8)
@@ -106,18 +128,9 @@ class ControlNetModel(ParamTreeModule):
                     for c, f in zip(self._slot_channels, self._slot_factor)]
             mid = torch.zeros(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device)
             return ControlNetOutput(down, mid) if return_dict else (down, mid)
-        plan = self._ensure_plan()
-        t = timesteps_to_device_f32(timestep, N, sample.device)
-        outs = [torch.empty(N, c, max(Hs // f, 1), max(Ws // f, 1), dtype=out_dtype, device=sample.device)
-                for c, f in zip(self._slot_channels, self._slot_factor)]
-        outs.append(torch.empty(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device))
-        sample_c, ehs_c, cond_c = sample.contiguous(), ehs.contiguous(), controlnet_cond.contiguous()
-        ptrs = (C.c_void_p * 13)(*[o.data_ptr() for o in outs])
-        flags = (1 if skip_conv_in else 0) | (2 if skip_time_emb else 0) | (4 if guess_mode else 0)
-        L.check(L.lib().ctrl_controlnet_forward(
-            plan, L.ptr(sample_c), L.dtype_code(sample_c.dtype), N, Hs, Ws, L.ptr(t), t.numel(),
-            L.ptr(ehs_c), L.dtype_code(ehs_c.dtype), ehs_c.shape[1], L.ptr(cond_c), L.dtype_code(cond_c.dtype),
-            C.c_float(float(conditioning_scale)), flags, ptrs, L.dtype_code(out_dtype), L.cur_stream()))
+        outs, args, _keep = self._launch_args(sample, timestep, ehs, controlnet_cond, conditioning_scale, guess_mode,
+                                              skip_conv_in, skip_time_emb, out_dtype)
+        L.check(L.lib().ctrl_controlnet_forward(self._ensure_plan(), *args, L.cur_stream()))
         down, mid = outs[:12], outs[12]
         if not return_dict:
             return (down, mid)

@@ -346,6 +346,7 @@ struct AdapterCall {
     void* const* outs; int out_dt;
     const int* map_dev; const int32_t* map_host; int N_out;     // frame scatter (null / null / N when off)
     ctrl_adapter* plan; int nlanes;                             // stream lanes (1 = everything on the caller's stream)
+    const hipEvent_t* in_ev;                                    // optional [13]: input slot i is ready when in_ev[i] fires
 };
 
 size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
@@ -418,8 +419,9 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
         for (int l = 1; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(P->side[l - 1], P->fork_ev, 0));
     }
     auto lane_of = [&](int f) { const int l = f == 1 ? 0 : (f == 2 ? 1 : (f == 4 ? 2 : 3)); return l % nl; };
-    auto run_in_lane = [&](int lane, const AdapterBlockW& bw, const void* in, void* out, int h, int wd, size_t frame_elems) -> int {
+    auto run_in_lane = [&](int lane, int slot, const AdapterBlockW& bw, const void* in, void* out, int h, int wd, size_t frame_elems) -> int {
         cx.s = lane == 0 ? main_s : P->side[lane - 1];
+        if (!cx.dry && k.in_ev) HIP_TRY(hipStreamWaitEvent(cx.s, k.in_ev[slot], 0));     // fused step: producer still running
         cx.ar->off = lane_base[lane];
         if (cx.dry) cx.ar->peak = lane_base[lane];
         TRY(run_block(cx, bw, c, a, in, out, h, wd));
@@ -436,7 +438,7 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
         const int h = std::max(k.H0 / slot_f[i], 1), wd = std::max(k.W0 / slot_f[i], 1);
         const bool has = bi < w.slot_ids.size() && w.slot_ids[bi] == i;
         if (has) {
-            TRY(run_in_lane(lane_of(slot_f[i]), w.blocks[bi], k.ins[i], k.outs[i], h, wd, (size_t)slot_c[i] * h * up * wd * up));
+            TRY(run_in_lane(lane_of(slot_f[i]), i, w.blocks[bi], k.ins[i], k.outs[i], h, wd, (size_t)slot_c[i] * h * up * wd * up));
             ++bi;
         } else {
             // torch.zeros_like(down_block_res_samples[i])  (ctrl_adapter.py:193): input-sized, not up-sampled
@@ -445,7 +447,7 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     }
     if (w.has_mid && k.ins[12] && k.outs[12]) {
         const int h = std::max(k.H0 / 8, 1), wd = std::max(k.W0 / 8, 1);
-        TRY(run_in_lane(lane_of(8), w.mid, k.ins[12], k.outs[12], h, wd, (size_t)1280 * h * wd));
+        TRY(run_in_lane(lane_of(8), 12, w.mid, k.ins[12], k.outs[12], h, wd, (size_t)1280 * h * wd));
     }
     if (!cx.dry && nl > 1) {
         for (int l = 1; l < nl; ++l) {
@@ -503,7 +505,7 @@ void ctrl_adapter_destroy(ctrl_adapter* h) { delete h; }
 static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
                                 const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
                                 int ehs_batch, int Lk, void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
-                                void* stream) {
+                                void* stream, const hipEvent_t* in_ev = nullptr) {
     CTRL_CHECK(h && ins && outs && timesteps, "adapter_forward: null argument");
     CTRL_CHECK(N >= 1 && H0 >= 1 && W0 >= 1 && num_frames >= 1 && N % num_frames == 0,
                "adapter_forward: batch must be a multiple of num_frames");
@@ -542,7 +544,7 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     static const int env_lanes = getenv("CTRL_ADAPTER_LANES") ? atoi(getenv("CTRL_ADAPTER_LANES")) : ctrl_adapter::kLanes;
     const int nlanes = g_prof_on ? 1 : std::min(std::max(env_lanes, 1), (int)ctrl_adapter::kLanes);
     AdapterCall k = {ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states, ehs_dtype,
-                     ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out, h, nlanes};
+                     ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out, h, nlanes, in_ev};
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
@@ -572,3 +574,13 @@ int ctrl_adapter_forward_scatter(ctrl_adapter* h, const void* const* ins, int in
 }
 
 }  // extern "C"
+
+// Fused-step half (plan_fused.cpp): like ctrl_adapter_forward[_scatter], but input slot i may still be in production on
+// another stream -- the block that consumes it waits for in_ev[i] on its lane (in_ev = null: inputs are ready)
+int adapter_forward_events(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                           const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
+                           int ehs_batch, int Lk, void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
+                           void* stream, const hipEvent_t* in_ev) {
+    return adapter_forward_impl(h, ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states,
+                                ehs_dtype, ehs_batch, Lk, outs, out_dtype, frame_pos, frame_pos ? N_out : N, stream, in_ev);
+}

@@ -146,7 +146,23 @@ struct ctrl_controlnet {
     ControlNetW w;
     std::unique_ptr<Packer> packer;
     Arena arena;
-    ~ctrl_controlnet() { if (packer) packer->release_all(); }
+    // fused step (ctrl_step_forward): the network runs on its own stream and signals every output with an event
+    hipStream_t side = nullptr;
+    hipEvent_t fork_ev = nullptr, done_ev = nullptr, out_ev[13] = {};
+    int init_async() {
+        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&done_ev, hipEventDisableTiming));
+        for (int i = 0; i < 13; ++i) HIP_TRY(hipEventCreateWithFlags(&out_ev[i], hipEventDisableTiming));
+        return 0;
+    }
+    ~ctrl_controlnet() {
+        if (packer) packer->release_all();
+        if (side) (void)hipStreamDestroy(side);
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
+        if (done_ev) (void)hipEventDestroy(done_ev);
+        for (int i = 0; i < 13; ++i) if (out_ev[i]) (void)hipEventDestroy(out_ev[i]);
+    }
 };
 
 namespace {
@@ -158,6 +174,7 @@ struct FwdArgs {
     const void* cond; int cond_dt;
     float scale; int flags;
     void* const* outs; int out_dt;
+    hipEvent_t* out_ev;     // optional [13]: recorded on the launch stream right after output i has been enqueued
 };
 
 int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& pout, const BasicTBW& tb, const TV& x,
@@ -235,9 +252,30 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         cx.release(mk);
     }
 
+    // ---- 5./6. zero convs (:850-858) with the conditioning scale fused (:861-868), NCHW outputs.  Each one is enqueued
+    //      as soon as its residual exists (the reference applies them after the mid block; they only read the residual),
+    //      so a consumer of output i -- the adapter block of slot i in the fused step -- can start while the rest of the
+    //      network is still running ----
+    const size_t nout = w.zero_convs.size();
+    size_t n_emitted = 0;
+    auto emit = [&](const TV& r, int hh, int ww) -> int {
+        const size_t i = n_emitted++;
+        CTRL_CHECK(i < nout, "controlnet: residual/zero-conv count mismatch");
+        float sc = a.scale;
+        if (a.flags & CTRL_GUESS_MODE) sc *= powf(10.f, -1.f + (float)i / (float)(nout - 1));   // torch.logspace(-1, 0, n) * scale
+        const ConvW& z = w.zero_convs[i];
+        const int HW = hh * ww;
+        IGemmArgs g = {};
+        g.A = r.m16; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1;
+        g.W = z.w; g.M = N * HW; g.Nout = z.Cout; g.Ktot = z.Cin; g.bias = z.b; g.scale = sc;
+        g.nseg = 1;
+        g.seg[0] = IGemmSeg{a.outs[i], HW, 0, z.Cout, SEG_TRANSPOSED, a.out_dt, HW, 0};
+        RUN(cx, op_igemm(g, cx.s));
+        if (!cx.dry && a.out_ev) HIP_TRY(hipEventRecord(a.out_ev[i], cx.s));
+        return 0;
+    };
     // ---- 3. down blocks (:820-833) ----
-    std::vector<TV> res; std::vector<int> res_c, res_h, res_w;
-    res.push_back(x); res_c.push_back(c0); res_h.push_back(H); res_w.push_back(W);
+    TRY(emit(x, H, W));
     int h = H, wd = W;
     TV cur = x;
     for (int i = 0; i < 4; ++i) {
@@ -251,7 +289,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
                 TRY(run_transformer2d(cx, d.tnorm[j], d.proj_in[j], d.proj_out[j], d.tb[j], cur, t, N, h, wd, e));
                 cur = t;
             }
-            res.push_back(cur); res_c.push_back(d.Cout); res_h.push_back(h); res_w.push_back(wd);
+            TRY(emit(cur, h, wd));
         }
         if (d.has_down) {
             const int ho = (h - 1) / 2 + 1, wo = (wd - 1) / 2 + 1;
@@ -259,7 +297,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
             ConvOpts o; o.stride = 2;
             TRY(run_conv(cx, d.down, cur.m16, y, N, h, wd, o));
             cur = y; h = ho; wd = wo;
-            res.push_back(cur); res_c.push_back(d.Cout); res_h.push_back(h); res_w.push_back(wd);
+            TRY(emit(cur, h, wd));
         }
     }
     // ---- 4. mid block (:836-846) ----
@@ -271,25 +309,9 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         TRY(run_transformer2d(cx, w.mid_tnorm, w.mid_pin, w.mid_pout, w.mid_tb, m0, m1, N, h, wd, e));
         TV m2 = stream_alloc(cx, (size_t)N * h * wd * C, true);
         TRY(run_resnet(cx, w.mid_r1, m1, m2, N, h, wd, 1, tproj + w.mid_r1.temb_off, w.temb_total, c.norm_eps));
-        res.push_back(m2); res_c.push_back(C); res_h.push_back(h); res_w.push_back(wd);
+        TRY(emit(m2, h, wd));
     }
-    // ---- 5./6. zero convs (:850-858) with the conditioning scale fused (:861-868), NCHW outputs ----
-    const size_t nout = res.size();
-    CTRL_CHECK(nout == w.zero_convs.size(), "controlnet: residual/zero-conv count mismatch");
-    for (size_t i = 0; i < nout; ++i) {
-        float sc = a.scale;
-        if (a.flags & CTRL_GUESS_MODE) {   // torch.logspace(-1, 0, n) * conditioning_scale
-            sc *= powf(10.f, -1.f + (float)i / (float)(nout - 1));
-        }
-        const ConvW& z = w.zero_convs[i];
-        const int HW = res_h[i] * res_w[i];
-        IGemmArgs g = {};
-        g.A = res[i].m16; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1;
-        g.W = z.w; g.M = N * HW; g.Nout = z.Cout; g.Ktot = z.Cin; g.bias = z.b; g.scale = sc;
-        g.nseg = 1;
-        g.seg[0] = IGemmSeg{a.outs[i], HW, 0, z.Cout, SEG_TRANSPOSED, a.out_dt, HW, 0};
-        RUN(cx, op_igemm(g, cx.s));
-    }
+    CTRL_CHECK(n_emitted == nout, "controlnet: residual/zero-conv count mismatch");
     return 0;
 }
 
@@ -323,6 +345,7 @@ int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_
     h->packer.reset(new Packer(tensors, n_tensors, (hipStream_t)stream));
     int rc = build_controlnet(*h->packer, *cfg, &h->w);
     if (rc) return rc;     // ~ctrl_controlnet frees what was packed so far
+    TRY(h->init_async());
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // packed copies are complete; source tensors may be freed
     *out = h.release();
     return 0;
@@ -330,18 +353,17 @@ int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_
 
 void ctrl_controlnet_destroy(ctrl_controlnet* h) { delete h; }
 
-int ctrl_controlnet_forward(ctrl_controlnet* h, const void* sample, int sample_dtype, int N, int Hs, int Ws,
-                            const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype, int Lk,
-                            const void* controlnet_cond, int cond_dtype, float conditioning_scale, int flags,
-                            void* const* outs, int out_dtype, void* stream) {
+static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int sample_dtype, int N, int Hs, int Ws,
+                                   const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype, int Lk,
+                                   const void* controlnet_cond, int cond_dtype, float conditioning_scale, int flags,
+                                   void* const* outs, int out_dtype, hipStream_t s, hipEvent_t* out_ev) {
     CTRL_CHECK(h && sample && timesteps && encoder_hidden_states && controlnet_cond && outs, "controlnet_forward: null argument");
     CTRL_CHECK(N >= 1 && N <= 4096 && Hs >= 1 && Ws >= 1 && Lk >= 1, "controlnet_forward: bad sizes");
     CTRL_CHECK(Hs % 8 == 0 && Ws % 8 == 0, "controlnet_forward: latent height/width must be multiples of 8 (3 stride-2 stages)");
     CTRL_CHECK(t_count == 1 || t_count == N, "controlnet_forward: need 1 or N timesteps");
     for (int i = 0; i < 13; ++i) CTRL_CHECK(outs[i] != nullptr, "controlnet_forward: null output pointer");
     FwdArgs a = {sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
-                 controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype};
-    hipStream_t s = (hipStream_t)stream;
+                 controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, out_ev};
     // sizing pass (no launches) -> workspace; then the real pass
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
@@ -355,4 +377,35 @@ int ctrl_controlnet_forward(ctrl_controlnet* h, const void* sample, int sample_d
     return controlnet_run(cx, h->w, a);
 }
 
+int ctrl_controlnet_forward(ctrl_controlnet* h, const void* sample, int sample_dtype, int N, int Hs, int Ws,
+                            const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype, int Lk,
+                            const void* controlnet_cond, int cond_dtype, float conditioning_scale, int flags,
+                            void* const* outs, int out_dtype, void* stream) {
+    return controlnet_forward_impl(h, sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
+                                   controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, (hipStream_t)stream, nullptr);
+}
+
 }  // extern "C"
+
+// Fused-step half (plan_fused.cpp): the whole network on the plan's own stream, forked from `main_s`; *out_events gets the
+// 13 per-output events and *done the event that marks the end of the network.  With `async` false (profiler recording)
+// everything runs on main_s and no events are produced.
+int controlnet_forward_async(ctrl_controlnet* h, const void* sample, int sample_dtype, int N, int Hs, int Ws,
+                             const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype, int Lk,
+                             const void* controlnet_cond, int cond_dtype, float conditioning_scale, int flags,
+                             void* const* outs, int out_dtype, hipStream_t main_s, bool async,
+                             hipEvent_t** out_events, hipEvent_t* done) {
+    CTRL_CHECK(h, "controlnet_forward: null plan");
+    if (!async) {
+        *out_events = nullptr; *done = nullptr;
+        return controlnet_forward_impl(h, sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
+                                       controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, main_s, nullptr);
+    }
+    HIP_TRY(hipEventRecord(h->fork_ev, main_s));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->fork_ev, 0));
+    TRY(controlnet_forward_impl(h, sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
+                                controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, h->side, h->out_ev));
+    HIP_TRY(hipEventRecord(h->done_ev, h->side));
+    *out_events = h->out_ev; *done = h->done_ev;
+    return 0;
+}

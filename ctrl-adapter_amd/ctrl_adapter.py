@@ -79,6 +79,20 @@ class ControlNetAdapter(ParamTreeModule):
             zero-copy views; the UNets' inverse rearrange (i2vgen_xl/models/unets/unet_i2vgen_xl.py:683-684) is then a
             view of the same memory as well."""
         # sparsity_masking is accepted and ignored, exactly like the reference (SURVEY.md note N7)
+        outs, mid_out, args, tail, finish, _keep = self._launch_args(
+            down_block_res_samples, mid_block_res_sample, num_frames, timestep, encoder_hidden_states, scatter_to, out_dtype, clip_batch)
+        in_ptrs, in_dt = _keep[0], _keep[1]
+        if tail is None:
+            L.check(L.lib().ctrl_adapter_forward(self._ensure_plan(), in_ptrs, in_dt, *args, L.cur_stream()))
+        else:
+            L.check(L.lib().ctrl_adapter_forward_scatter(self._ensure_plan(), in_ptrs, in_dt, *args, *tail, L.cur_stream()))
+        return finish(outs, mid_out)
+
+    def _launch_args(self, down_block_res_samples, mid_block_res_sample, num_frames, timestep, encoder_hidden_states,
+                     scatter_to, out_dtype, clip_batch):
+        """Validation + output tensors + the C argument list shared by ctrl_adapter_forward[_scatter] and
+        ctrl_step_forward: args = (N, H0, W0, num_frames, t, t_count, ehs, ehs_dtype, ehs_batch, Lk, out_ptrs, out_dtype),
+        tail = (frame_pos, N_out) or None, finish = the clip_batch view step."""
         if len(down_block_res_samples) != 12:
             raise ValueError("expected the 12 ControlNet down_block_res_samples")
         x0 = down_block_res_samples[0]
@@ -90,7 +104,6 @@ class ControlNetAdapter(ParamTreeModule):
             if tuple(t.shape) != (N, c, max(H0 // f, 1), max(W0 // f, 1)) or t.dtype != dt:
                 raise ValueError("down_block_res_samples[%d] has shape %s, expected the SD-1.5 ControlNet pyramid" % (i, tuple(t.shape)))
         num_frames = int(num_frames) if num_frames is not None else 1
-        plan = self._ensure_plan()
         t32 = timesteps_to_device_f32(timestep, N, x0.device)
         needs_ehs = self.config.add_spatial_transformer or self.config.add_temporal_transformer
         ehs = None
@@ -127,15 +140,15 @@ class ControlNetAdapter(ParamTreeModule):
             mid_out = torch.empty(N_out, 1280, mid_in.shape[2] * self._up, mid_in.shape[3] * self._up, dtype=odt, device=x0.device)
         in_ptrs = (C.c_void_p * 13)(*([t.data_ptr() for t in ins] + [mid_in.data_ptr() if mid_in is not None else None]))
         out_ptrs = (C.c_void_p * 13)(*([t.data_ptr() for t in outs] + [mid_out.data_ptr() if mid_out is not None else None]))
-        args = (plan, in_ptrs, L.dtype_code(dt), N, H0, W0, num_frames, L.ptr(t32), t32.numel(),
-                L.ptr(ehs), L.dtype_code(ehs.dtype) if ehs is not None else 0, eb, Lk, out_ptrs, L.dtype_code(odt))
-        if pos is None:
-            L.check(L.lib().ctrl_adapter_forward(*args, L.cur_stream()))
-        else:
-            L.check(L.lib().ctrl_adapter_forward_scatter(*args, pos, N_out, L.cur_stream()))
-        if clip_batch is not None:
-            bs = int(clip_batch)
-            as_clips = lambda x: x.view(bs, N_out // bs, *x.shape[1:]).permute(0, 2, 1, 3, 4)
-            outs = [as_clips(x) for x in outs]
-            mid_out = as_clips(mid_out) if mid_out is not None else None
-        return outs, mid_out
+        args = [N, H0, W0, num_frames, L.ptr(t32), t32.numel(),
+                L.ptr(ehs), L.dtype_code(ehs.dtype) if ehs is not None else 0, eb, Lk, out_ptrs, L.dtype_code(odt)]
+        tail = None if pos is None else [pos, N_out]
+
+        def finish(outs, mid_out):
+            if clip_batch is not None:
+                bs = int(clip_batch)
+                as_clips = lambda x: x.view(bs, N_out // bs, *x.shape[1:]).permute(0, 2, 1, 3, 4)
+                outs = [as_clips(x) for x in outs]
+                mid_out = as_clips(mid_out) if mid_out is not None else None
+            return outs, mid_out
+        return outs, mid_out, args, tail, finish, (in_ptrs, L.dtype_code(dt), ins, mid_in, t32, ehs, out_ptrs, pos)

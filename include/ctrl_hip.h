@@ -215,6 +215,22 @@ int ctrl_adapter_forward_scatter(ctrl_adapter* h,
                                  const void* encoder_hidden_states, int ehs_dtype, int ehs_batch, int Lk,
                                  void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out, void* stream);
 
+/* ---- Fused step: ctrl_controlnet_forward + ctrl_adapter_forward[_scatter] of one denoise step as one call (the two
+ * back-to-back calls of the pipelines, sdxl/pipelines/sdxl_controlnet_adapter_pipeline.py:1323,1338 and
+ * svd/...:684,709, i2vgen_xl/...:957,1042).  Same arguments as the two calls (the ControlNet outputs cn_outs[13] are
+ * the adapter inputs; use_mid = pass cn_outs[12] as mid_block_res_sample; frame_pos may be NULL = no scatter); same
+ * results bit for bit; the ControlNet runs on a plan-owned stream and every adapter block starts as soon as ITS input
+ * is ready.  CTRL_STEP_OVERLAP=0 runs the two halves back to back. */
+int ctrl_step_forward(ctrl_controlnet* cn, ctrl_adapter* ad,
+                      const void* sample, int sample_dtype, int N, int Hs, int Ws,
+                      const float* cn_timesteps, int cn_t_count,
+                      const void* cn_encoder_hidden_states, int cn_ehs_dtype, int cn_Lk,
+                      const void* controlnet_cond, int cond_dtype, float conditioning_scale, int flags,
+                      void* const* cn_outs, int cn_out_dtype,
+                      int num_frames, const float* ad_timesteps, int ad_t_count,
+                      const void* ad_encoder_hidden_states, int ad_ehs_dtype, int ad_ehs_batch, int ad_Lk,
+                      int use_mid, void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out, void* stream);
+
 /* ---- Router (model/ctrl_router.py) ---- */
 /* weights_out fp32 device [num_routers + (has_mid?1:0)][E]; wg fp32 device same shape (Linear(1,E).weight[:,0]
  * per router; ignored for equal_weights); mask host int[E] (NULL = all ones). */

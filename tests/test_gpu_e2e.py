@@ -296,3 +296,37 @@ def test_sparse_to_dense_scatter_and_clip_layout(P, gpu):
     d_r, dm_r = ad_r(ins, **kw, scatter_to=(double_sparse, bs * nf), clip_batch=bs)
     for a, b in zip(list(d_r) + [dm_r], list(o_r) + [m_r]):
         assert torch.equal(a, pipeline_dense(b, torch.float16))
+
+
+def test_controlled_step_equals_separate_calls(P, controlnet, gpu):
+    """The fused step (ControlNet on its own stream, per-output events, adapter blocks start when their input exists) must
+    return exactly what the pipelines' two back-to-back calls return: SDXL shapes of the goldens, the video adapter with
+    mid block + frame scatter, and the zero-scale shortcut."""
+    torch.set_grad_enabled(False)
+    inp = cases.controlnet_inputs(N=2, hs=8, seed=300)
+    sample, ehs_c, cond = inp["sample"].half().to(gpu), inp["encoder_hidden_states"].half().to(gpu), inp["controlnet_cond"].half().to(gpu)
+    t = torch.tensor(749.0)
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+    ehs_a = seeded_tensor((2, 77, 2048), 301).half().to(gpu)
+    d, m = controlnet(sample, t, ehs_c, cond, conditioning_scale=0.8, return_dict=False)
+    o, om = ad(d, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+    for _ in range(2):      # twice: the second call re-uses streams / events / workspaces
+        (fd, fm), (fo, fom) = P.controlled_step(controlnet, ad, sample, t, ehs_c, cond, 0.8, adapter_encoder_hidden_states=ehs_a, num_frames=1)
+        assert fom is None and om is None
+        assert all(torch.equal(a, b) for a, b in zip(list(fd) + [fm] + list(fo), list(d) + [m] + list(o)))
+    # video adapter: mid block, skip_conv_in, sparse frames scattered into the dense clip grid
+    adv = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_VIDEO), seed=33).to(gpu)
+    inp = cases.controlnet_inputs(N=4, hs=8, seed=310)
+    sample, ehs_c, cond = inp["sample"].half().to(gpu), inp["encoder_hidden_states"].half().to(gpu), inp["controlnet_cond"].half().to(gpu)
+    e_img = seeded_tensor((1, 1, 1024), 311).half().to(gpu)
+    kw = dict(num_frames=2, scatter_to=([0, 3, 4, 7], 8), clip_batch=2, out_dtype=torch.float32)
+    d, m = controlnet(sample, t, ehs_c, cond, return_dict=False, skip_conv_in=True)
+    o, om = adv(d, mid_block_res_sample=m, timestep=t, encoder_hidden_states=e_img, **kw)
+    (fd, fm), (fo, fom) = P.controlled_step(controlnet, adv, sample, t, ehs_c, cond, skip_conv_in=True,
+                                            adapter_encoder_hidden_states=e_img, **kw)
+    assert all(torch.equal(a, b) for a, b in zip(list(fd) + [fm] + list(fo) + [fom], list(d) + [m] + list(o) + [om]))
+    # control switched off: zeros from the ControlNet, the adapter still runs on them
+    (zd, zm), (zo, _) = P.controlled_step(controlnet, ad, sample[:2], t, ehs_c[:2], cond[:2], 0, adapter_encoder_hidden_states=ehs_a, num_frames=1)
+    assert all(x.abs().max().item() == 0.0 for x in list(zd) + [zm])
+    o0, _ = ad(zd, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+    assert all(torch.equal(a, b) for a, b in zip(zo, o0))
