@@ -33,6 +33,10 @@ class ControlNetModel(ParamTreeModule):
                  global_pool_conditions=False, addition_embed_type_num_heads=64):
         super().__init__()
         self.config = Config({k: v for k, v in locals().items() if k not in ("self", "__class__")})
+        # opt-in step-invariant cache of the conditioning embedder: with the same `controlnet_cond`
+        # tensor object, unmodified, on consecutive forwards only the embedder's last conv runs.  Bit-identical results.
+        self.cache_condition = False
+        self._cond_ref, self._cond_version, self._cond_key = None, -1, None
         # the hot path only reaches this configuration family (SD-1.5 ControlNets); anything else fails loudly
         unsupported = []
         if not flip_sin_to_cos or freq_shift != 0: unsupported.append("time_proj variant")
@@ -84,6 +88,10 @@ class ControlNetModel(ParamTreeModule):
             self._plan = h
         return self._plan
 
+    def _drop_plan(self):
+        self._cond_ref, self._cond_version, self._cond_key = None, -1, None      # the cache lives in the plan
+        super()._drop_plan()
+
     def _launch_args(self, sample, timestep, ehs, controlnet_cond, conditioning_scale, guess_mode, skip_conv_in,
                      skip_time_emb, out_dtype):
         """Output tensors + the C argument list shared by ctrl_controlnet_forward and ctrl_step_forward
@@ -96,6 +104,13 @@ class ControlNetModel(ParamTreeModule):
         sample_c, ehs_c, cond_c = sample.contiguous(), ehs.contiguous(), controlnet_cond.contiguous()
         ptrs = (C.c_void_p * 13)(*[o.data_ptr() for o in outs])
         flags = (1 if skip_conv_in else 0) | (2 if skip_time_emb else 0) | (4 if guess_mode else 0)
+        if self.cache_condition:
+            # same tensor object, not written to since the forward that cached it (and same plan): the embedder's hidden
+            # map is still valid.  The reference recomputes it on each of the ~50 steps.
+            key = (tuple(controlnet_cond.shape), controlnet_cond.dtype, tuple(sample.shape))
+            same = (self._cond_ref is controlnet_cond and self._cond_version == controlnet_cond._version and self._cond_key == key)
+            flags |= 16 if same else 8
+            self._cond_ref, self._cond_version, self._cond_key = controlnet_cond, controlnet_cond._version, key
         args = [L.ptr(sample_c), L.dtype_code(sample_c.dtype), N, Hs, Ws, L.ptr(t), t.numel(),
                 L.ptr(ehs_c), L.dtype_code(ehs_c.dtype), ehs_c.shape[1], L.ptr(cond_c), L.dtype_code(cond_c.dtype),
                 C.c_float(float(conditioning_scale)), flags, ptrs, L.dtype_code(out_dtype)]

@@ -149,6 +149,10 @@ struct ctrl_controlnet {
     // fused step (ctrl_step_forward): the network runs on its own stream and signals every output with an event
     hipStream_t side = nullptr;
     hipEvent_t fork_ev = nullptr, done_ev = nullptr, out_ev[13] = {};
+    // step-invariant cache of the conditioning embedder's last hidden map (CTRL_COND_KEEP / CTRL_COND_REUSE)
+    half_t* cond_cache = nullptr;
+    size_t cond_cache_elems = 0;        // capacity
+    int cond_N = 0, cond_H = 0, cond_W = 0;   // what the cache holds (0 = nothing)
     int init_async() {
         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
@@ -158,6 +162,7 @@ struct ctrl_controlnet {
     }
     ~ctrl_controlnet() {
         if (packer) packer->release_all();
+        if (cond_cache) (void)hipFree(cond_cache);
         if (side) (void)hipStreamDestroy(side);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
         if (done_ev) (void)hipEventDestroy(done_ev);
@@ -175,6 +180,8 @@ struct FwdArgs {
     float scale; int flags;
     void* const* outs; int out_dt;
     hipEvent_t* out_ev;     // optional [13]: recorded on the launch stream right after output i has been enqueued
+    half_t* cond_cache;     // plan-owned [N][H][W][c_last_hidden] or null
+    bool cond_reuse;        // start the conditioning embedder from cond_cache
 };
 
 int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& pout, const BasicTBW& tb, const TV& x,
@@ -237,8 +244,13 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
             const int co = w.ce_chain_c[i], st = w.ce_chain_stride[i];
             const int ho = (hh - 1) / st + 1, wo = (ww - 1) / st + 1;
             const bool last = (i + 1 == nl);
-            half_t* y16 = last ? nullptr : cx.h((size_t)N * ho * wo * co);
-            if ((int)i < w.n_direct) {
+            // the layer in front of the last one writes the step-invariant map: into the plan's cache when there is one
+            const bool cached_layer = (i + 2 == nl) && a.cond_cache;
+            half_t* y16 = last ? nullptr : (cached_layer ? a.cond_cache : cx.h((size_t)N * ho * wo * co));
+            if (a.cond_reuse && !last) {
+                // unchanged condition image: skip everything up to the cached map
+                if ((int)i >= w.n_direct) ++gi;
+            } else if ((int)i < w.n_direct) {
                 CTRL_CHECK(!last, "controlnet: the conditioning embedder must end with an implicit-GEMM layer");
                 RUN(cx, op_conv3x3_direct(cur, cur_dt, nchw, w.ce_direct[i].w, w.ce_direct[i].b, y16, N, ch, co, hh, ww, st, 1, cx.s));
             } else {
@@ -362,8 +374,27 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     CTRL_CHECK(Hs % 8 == 0 && Ws % 8 == 0, "controlnet_forward: latent height/width must be multiples of 8 (3 stride-2 stages)");
     CTRL_CHECK(t_count == 1 || t_count == N, "controlnet_forward: need 1 or N timesteps");
     for (int i = 0; i < 13; ++i) CTRL_CHECK(outs[i] != nullptr, "controlnet_forward: null output pointer");
+    // step-invariant conditioning-embedder cache
+    const bool keep = (flags & CTRL_COND_KEEP) != 0, reuse = (flags & CTRL_COND_REUSE) != 0;
+    half_t* cache = nullptr;
+    if (keep || reuse) {
+        const size_t nl = h->w.ce_chain_c.size();
+        CTRL_CHECK(nl >= 2, "controlnet: conditioning embedder too short to cache");
+        const size_t need = (size_t)N * Hs * Ws * h->w.ce_chain_c[nl - 2];
+        if (reuse) {
+            CTRL_CHECK(h->cond_cache && h->cond_N == N && h->cond_H == Hs && h->cond_W == Ws,
+                       "controlnet_forward: CTRL_COND_REUSE without a matching CTRL_COND_KEEP forward");
+        } else if (need > h->cond_cache_elems) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h->cond_cache) HIP_TRY(hipFree(h->cond_cache));
+            h->cond_cache = nullptr; h->cond_cache_elems = 0; h->cond_N = 0;
+            HIP_TRY(hipMalloc((void**)&h->cond_cache, need * sizeof(half_t)));
+            h->cond_cache_elems = need;
+        }
+        cache = h->cond_cache;
+    }
     FwdArgs a = {sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
-                 controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, out_ev};
+                 controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, out_ev, cache, reuse};
     // sizing pass (no launches) -> workspace; then the real pass
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
@@ -374,7 +405,9 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     Ctx cx{&h->arena, s, false};
     cx.f32stream = dry.f32stream;
     cx.stats_total = dry.stats_total;
-    return controlnet_run(cx, h->w, a);
+    TRY(controlnet_run(cx, h->w, a));
+    if (keep && !reuse) { h->cond_N = N; h->cond_H = Hs; h->cond_W = Ws; }
+    return 0;
 }
 
 int ctrl_controlnet_forward(ctrl_controlnet* h, const void* sample, int sample_dtype, int N, int Hs, int Ws,

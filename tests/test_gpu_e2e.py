@@ -330,3 +330,26 @@ def test_controlled_step_equals_separate_calls(P, controlnet, gpu):
     assert all(x.abs().max().item() == 0.0 for x in list(zd) + [zm])
     o0, _ = ad(zd, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
     assert all(torch.equal(a, b) for a, b in zip(zo, o0))
+
+
+def test_condition_cache_is_bit_identical(P, controlnet, gpu):
+    """with `cache_condition` the conditioning embedder's hidden map is kept in the plan and re-used
+    while the same, unmodified `controlnet_cond` tensor comes back; an in-place write or another tensor recomputes."""
+    torch.set_grad_enabled(False)
+    inp = cases.controlnet_inputs(N=2, hs=8, seed=400)
+    sample, ehs, cond = inp["sample"].half().to(gpu), inp["encoder_hidden_states"].half().to(gpu), inp["controlnet_cond"].half().to(gpu)
+    ts = [torch.tensor(999.0), torch.tensor(749.0), torch.tensor(499.0)]
+    ref = [controlnet(sample, t, ehs, cond, return_dict=False) for t in ts]
+    controlnet.cache_condition = True
+    try:
+        for t, (rd, rm) in zip(ts, ref):                     # KEEP, then REUSE twice
+            d, m = controlnet(sample, t, ehs, cond, return_dict=False)
+            assert all(torch.equal(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm]))
+        cond.mul_(0.5)                                       # in-place change: the version counter invalidates the cache
+        d, m = controlnet(sample, ts[0], ehs, cond, return_dict=False)
+        controlnet.cache_condition = False
+        rd, rm = controlnet(sample, ts[0], ehs, cond, return_dict=False)
+        assert all(torch.equal(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm]))
+        assert not torch.equal(d[0], ref[0][0][0])
+    finally:
+        controlnet.cache_condition = False
