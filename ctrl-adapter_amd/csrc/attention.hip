@@ -38,7 +38,7 @@ __device__ __forceinline__ int tile_swz(int row) {
 template <int D, int NW, bool BATCH>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(AttnArgs a, const half_t* zeros) {
     constexpr int DP = (D + 31) / 32 * 32;      // padded head dim (zero filled): 64, 64, 96, 160
-    constexpr int KS = DP / 16;                 // k-steps of the 32x32x16 MFMA for QK^T
+    constexpr int KS = (D + 15) / 16;           // k-steps of the 32x32x16 MFMA for QK^T (40 -> 3, 80 -> 5: no all-zero steps)
     constexpr int DB = DP / 32;                 // 32-row output blocks of O^T
     constexpr int KCPR = DP / 8;                // 16-B chunks per K-tile row
     constexpr int PASSES = DP / (8 * NW);       // staging passes per tile: NW KiB each (K tile = V^T tile = 64*DP halfs)

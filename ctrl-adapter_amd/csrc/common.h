@@ -69,15 +69,17 @@ __device__ __forceinline__ void store_from_f32(void* p, size_t i, int dt, float 
 }
 // v_rcp_f32 (1 ulp) instead of an IEEE division (~10 VALU): SiLU sits in GEMM epilogues and the GroupNorm apply pass
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// exact (erf) GELU with erf from Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below fp16 resolution):
-// ~12 VALU instead of libm erff's ~50, which dominated the GEGLU GEMM epilogue
+// exact (erf) GELU with erf from Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below fp16 resolution).
+//   gelu(x) = x/2 * (1 + erf(x/sqrt2)),  erf(z) = sign(z) * (1 - P(t) e^{-z^2}),  t = 1/(1 + p|z|)
+//           = max(x, 0) - |x| * (P(t)/2) * e^{-x^2/2}            (x/2 + |x|/2 = max(x,0): no sign select, no 1 +/- erf)
+// ~11 VALU issues instead of libm erff's ~50, which dominated the GEGLU GEMM epilogue
 __device__ __forceinline__ float gelu_erf_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.0f + erf);
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+    const float hp = t * (0.5f * 0.254829592f + t * (0.5f * -0.284496736f + t * (0.5f * 1.421413741f +
+                     t * (0.5f * -1.453152027f + t * (0.5f * 1.061405429f)))));
+    return fmaf(-ax * hp, e, fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
