@@ -34,3 +34,32 @@ def pyramid_inputs(N, h0, seed, with_mid):
     downs = [seeded_tensor((N, c, max(h0 // f, 1), max(h0 // f, 1)), seed + i) for i, (c, f) in enumerate(SD15_PYRAMID)]
     mid = seeded_tensor((N, 1280, max(h0 // 8, 1), max(h0 // 8, 1)), seed + 50) if with_mid else None
     return downs, mid
+
+
+# ---- configuration variants the reference supports beyond the shipped YAMLs (model/ctrl_adapter.py:17-116) ----
+def _variant(base, **kw):
+    d = dict(base)
+    d.update(kw)
+    return d
+
+
+ADAPTER_VARIANTS = {
+    # two adapters per location (selection_map[2] = first and last slot of a location), ResNet-only blocks: the
+    # result leaves through the layout kernel instead of a GEMM epilogue
+    "sdxl_resnet_only_AC_x2": (_variant(ADAPTER_SDXL, num_adapters_per_location=2, add_adapter_location_B=False,
+                                        add_spatial_transformer=False), dict(N=2, frames=1, mid=False, ehs=(2, 77, 2048))),
+    # two stacked (ResNet, transformer) layers per block: the inter-layer path (fp16 mirror feeding the next shortcut conv)
+    "sdxl_two_blocks_C_x1": (_variant(ADAPTER_SDXL, num_blocks=2, num_adapters_per_location=1, add_adapter_location_A=False,
+                                      add_adapter_location_B=False), dict(N=2, frames=1, mid=False, ehs=(2, 77, 2048))),
+    # temporal modules only (no spatial ResNet / transformer), locations B and M, 2 clips x 3 frames
+    "video_temporal_only_BM": (_variant(ADAPTER_VIDEO, add_spatial_resnet=False, add_spatial_transformer=False,
+                                        add_adapter_location_A=False, add_adapter_location_C=False,
+                                        add_adapter_location_D=False, num_frames=3), dict(N=6, frames=3, mid=True, ehs=(1, 1, 1024))),
+}
+
+
+def variant_inputs(tag, seed=500):
+    cfg, io = ADAPTER_VARIANTS[tag]
+    downs, mid = pyramid_inputs(N=io["N"], h0=8, seed=seed, with_mid=io["mid"])
+    ehs = seeded_tensor(io["ehs"], seed + 90)
+    return cfg, io, downs, mid, ehs

@@ -76,6 +76,19 @@ def main():
     print("adapter video: %.1f M params" % (sum(p.numel() for p in ad.parameters()) / 1e6))
     del ad
 
+    # ---- G3b: configuration variants outside the shipped YAMLs (tests/golden/cases.py:ADAPTER_VARIANTS) ----
+    gv = {}
+    for tag in cases.ADAPTER_VARIANTS:
+        cfg, io, downs, midin, ehs = cases.variant_inputs(tag)
+        ad = seeded_init(ControlNetAdapter(**cfg).eval(), seed=77)
+        out, mid = ad(downs, mid_block_res_sample=midin, sparsity_masking=None, num_frames=io["frames"],
+                      timestep=torch.tensor(333.0), encoder_hidden_states=ehs)
+        gv[tag] = {"keys": sorted(ad.state_dict().keys()), "n_params": sum(p.numel() for p in ad.parameters()),
+                   "out": [digest(o) for o in out] + ([digest(mid)] if mid is not None else [])}
+        del ad
+    torch.save(gv, os.path.join(out_dir, "adapter_variants.pt"))
+    print("adapter variants: %s" % ", ".join(gv))
+
     # ---- G4: router ----
     r = seeded_init(ControlNetRouter(num_experts=3, router_type="simple_weights", num_routers=12).eval(), seed=44)
     g4 = {"keys": sorted(r.state_dict().keys()), "runs": {}}

@@ -353,3 +353,20 @@ def test_condition_cache_is_bit_identical(P, controlnet, gpu):
         assert not torch.equal(d[0], ref[0][0][0])
     finally:
         controlnet.cache_condition = False
+
+
+@pytest.mark.parametrize("tag", sorted(cases.ADAPTER_VARIANTS))
+def test_adapter_variants_golden(P, gpu, tag):
+    """configurations the reference supports beyond its shipped YAMLs, against goldens made by the reference's own files:
+    two adapters per location with ResNet-only blocks (layout-kernel exit), num_blocks = 2 (inter-layer path), temporal
+    modules only with a mid block (2 clips x 3 frames)"""
+    torch.set_grad_enabled(False)
+    g = load_golden("adapter_variants.pt")[tag]
+    cfg, io, downs, mid, ehs = cases.variant_inputs(tag)
+    ad = seeded_init(P.ControlNetAdapter(**cfg), seed=77).to(gpu)
+    assert sorted(ad.state_dict().keys()) == g["keys"]
+    out, m = ad([d.half().to(gpu) for d in downs], mid_block_res_sample=mid.half().to(gpu) if mid is not None else None,
+                num_frames=io["frames"], timestep=torch.tensor(333.0), encoder_hidden_states=ehs.half().to(gpu))
+    errs = [check_digest(t, d, TOL_ADAPTER, "%s out %d" % (tag, i))
+            for i, (t, d) in enumerate(zip(list(out) + ([m] if m is not None else []), g["out"]))]
+    print("PARITY adapter variant %-24s rel_inf: %s" % (tag, " ".join("%.2e" % e for e in errs)))

@@ -90,3 +90,16 @@ def test_merge_semantics():
     assert torch.allclose(mm, mw[0] * sum(mids), atol=1e-6)
     td, tm = merge_training(downs, mids, dw, mw, [1, 1, 1])
     assert torch.allclose(td[3], sum(dw[3][e] * downs[e][3] for e in range(E)), atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", sorted(cases.ADAPTER_VARIANTS))
+def test_adapter_variant_golden(tag):
+    """configurations outside the shipped YAMLs: 2 adapters per location / ResNet-only, num_blocks = 2, temporal-only"""
+    torch.set_grad_enabled(False)
+    g = load_golden("adapter_variants.pt")[tag]
+    cfg, io, downs, mid, ehs = cases.variant_inputs(tag)
+    ad = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=77)
+    assert sorted(ad.state_dict().keys()) == g["keys"] and sum(p.numel() for p in ad.parameters()) == g["n_params"]
+    out, m = ad(downs, mid_block_res_sample=mid, num_frames=io["frames"], timestep=torch.tensor(333.0), encoder_hidden_states=ehs)
+    for i, (t, d) in enumerate(zip(list(out) + ([m] if m is not None else []), g["out"])):
+        check_digest(t, d, TOL, "%s out %d" % (tag, i))
