@@ -55,6 +55,9 @@ ADAPTER_VARIANTS = {
     "video_temporal_only_BM": (_variant(ADAPTER_VIDEO, add_spatial_resnet=False, add_spatial_transformer=False,
                                         add_adapter_location_A=False, add_adapter_location_C=False,
                                         add_adapter_location_D=False, num_frames=3), dict(N=6, frames=3, mid=True, ehs=(1, 1, 1024))),
+    # 2-D encoder_hidden_states (adapter_spatial_temporal.py:240-241 -> one key per image: the query-independent
+    # cross-attention with a PER-IMAGE vector) and per-sample timesteps
+    "sdxl_ehs2d_per_sample_t": (dict(ADAPTER_SDXL), dict(N=2, frames=1, mid=False, ehs=(2, 2048), t=[749.0, 249.0])),
 }
 
 
@@ -63,3 +66,7 @@ def variant_inputs(tag, seed=500):
     downs, mid = pyramid_inputs(N=io["N"], h0=8, seed=seed, with_mid=io["mid"])
     ehs = seeded_tensor(io["ehs"], seed + 90)
     return cfg, io, downs, mid, ehs
+
+
+def variant_timestep(io):
+    return torch.tensor(io["t"]) if "t" in io else torch.tensor(333.0)

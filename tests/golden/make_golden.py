@@ -82,7 +82,7 @@ def main():
         cfg, io, downs, midin, ehs = cases.variant_inputs(tag)
         ad = seeded_init(ControlNetAdapter(**cfg).eval(), seed=77)
         out, mid = ad(downs, mid_block_res_sample=midin, sparsity_masking=None, num_frames=io["frames"],
-                      timestep=torch.tensor(333.0), encoder_hidden_states=ehs)
+                      timestep=cases.variant_timestep(io), encoder_hidden_states=ehs)
         gv[tag] = {"keys": sorted(ad.state_dict().keys()), "n_params": sum(p.numel() for p in ad.parameters()),
                    "out": [digest(o) for o in out] + ([digest(mid)] if mid is not None else [])}
         del ad

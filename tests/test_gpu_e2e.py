@@ -366,7 +366,7 @@ def test_adapter_variants_golden(P, gpu, tag):
     ad = seeded_init(P.ControlNetAdapter(**cfg), seed=77).to(gpu)
     assert sorted(ad.state_dict().keys()) == g["keys"]
     out, m = ad([d.half().to(gpu) for d in downs], mid_block_res_sample=mid.half().to(gpu) if mid is not None else None,
-                num_frames=io["frames"], timestep=torch.tensor(333.0), encoder_hidden_states=ehs.half().to(gpu))
+                num_frames=io["frames"], timestep=cases.variant_timestep(io), encoder_hidden_states=ehs.half().to(gpu))
     errs = [check_digest(t, d, TOL_ADAPTER, "%s out %d" % (tag, i))
             for i, (t, d) in enumerate(zip(list(out) + ([m] if m is not None else []), g["out"]))]
     print("PARITY adapter variant %-24s rel_inf: %s" % (tag, " ".join("%.2e" % e for e in errs)))

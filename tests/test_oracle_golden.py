@@ -100,6 +100,6 @@ def test_adapter_variant_golden(tag):
     cfg, io, downs, mid, ehs = cases.variant_inputs(tag)
     ad = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=77)
     assert sorted(ad.state_dict().keys()) == g["keys"] and sum(p.numel() for p in ad.parameters()) == g["n_params"]
-    out, m = ad(downs, mid_block_res_sample=mid, num_frames=io["frames"], timestep=torch.tensor(333.0), encoder_hidden_states=ehs)
+    out, m = ad(downs, mid_block_res_sample=mid, num_frames=io["frames"], timestep=cases.variant_timestep(io), encoder_hidden_states=ehs)
     for i, (t, d) in enumerate(zip(list(out) + ([m] if m is not None else []), g["out"])):
         check_digest(t, d, TOL, "%s out %d" % (tag, i))
