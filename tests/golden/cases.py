@@ -30,6 +30,16 @@ def controlnet_inputs(N=2, hs=8, seed=100):
     )
 
 
+def controlnet_inputs_nonsquare(seed=150):
+    """one image, 8 x 16 latents (64 x 128 condition image), 0-d timestep: the reference accepts any multiple of 8"""
+    return dict(
+        sample=seeded_tensor((1, 4, 8, 16), seed + 1),
+        timestep=torch.tensor(499.0),
+        encoder_hidden_states=seeded_tensor((1, 77, 768), seed + 2),
+        controlnet_cond=seeded_tensor((1, 3, 64, 128), seed + 3, kind="uniform"),
+    )
+
+
 def pyramid_inputs(N, h0, seed, with_mid):
     downs = [seeded_tensor((N, c, max(h0 // f, 1), max(h0 // f, 1)), seed + i) for i, (c, f) in enumerate(SD15_PYRAMID)]
     mid = seeded_tensor((N, 1280, max(h0 // 8, 1), max(h0 // 8, 1)), seed + 50) if with_mid else None

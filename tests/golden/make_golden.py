@@ -50,6 +50,10 @@ def main():
         down, mid = net(inp["sample"], inp["timestep"], encoder_hidden_states=inp["encoder_hidden_states"],
                         controlnet_cond=inp["controlnet_cond"], return_dict=False, **kw)
         g1["runs"][tag] = [digest(d) for d in down] + [digest(mid)]
+    inp = cases.controlnet_inputs_nonsquare()
+    down, mid = net(inp["sample"], inp["timestep"], encoder_hidden_states=inp["encoder_hidden_states"],
+                    controlnet_cond=inp["controlnet_cond"], return_dict=False)
+    g1["nonsquare_n1"] = [digest(d) for d in down] + [digest(mid)]
     torch.save(g1, os.path.join(out_dir, "controlnet_sd15.pt"))
     print("controlnet: %d params (%.1f M), %d keys" % (nparams, nparams / 1e6, len(keys)))
     del net

@@ -370,3 +370,13 @@ def test_adapter_variants_golden(P, gpu, tag):
     errs = [check_digest(t, d, TOL_ADAPTER, "%s out %d" % (tag, i))
             for i, (t, d) in enumerate(zip(list(out) + ([m] if m is not None else []), g["out"]))]
     print("PARITY adapter variant %-24s rel_inf: %s" % (tag, " ".join("%.2e" % e for e in errs)))
+
+
+def test_controlnet_nonsquare_single_image_golden(controlnet, gpu):
+    """one image, 8 x 16 latents, 0-d timestep (token counts 128 / 32 / 8 / 2: every attention tail path)"""
+    g = load_golden("controlnet_sd15.pt")["nonsquare_n1"]
+    inp = cases.controlnet_inputs_nonsquare()
+    down, mid = controlnet(inp["sample"].half().to(gpu), inp["timestep"], inp["encoder_hidden_states"].half().to(gpu),
+                           inp["controlnet_cond"].half().to(gpu), return_dict=False)
+    errs = [check_digest(t, d, TOL, "controlnet[nonsquare] out %d" % i) for i, (t, d) in enumerate(zip(list(down) + [mid], g))]
+    print("PARITY controlnet golden nonsquare 8x16 N=1 max rel_inf=%.3e" % max(errs))

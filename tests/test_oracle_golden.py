@@ -103,3 +103,11 @@ def test_adapter_variant_golden(tag):
     out, m = ad(downs, mid_block_res_sample=mid, num_frames=io["frames"], timestep=cases.variant_timestep(io), encoder_hidden_states=ehs)
     for i, (t, d) in enumerate(zip(list(out) + ([m] if m is not None else []), g["out"])):
         check_digest(t, d, TOL, "%s out %d" % (tag, i))
+
+
+def test_controlnet_nonsquare_single_image_golden(controlnet):
+    g = load_golden("controlnet_sd15.pt")["nonsquare_n1"]
+    inp = cases.controlnet_inputs_nonsquare()
+    down, mid = controlnet(inp["sample"], inp["timestep"], inp["encoder_hidden_states"], inp["controlnet_cond"])
+    for i, (t, d) in enumerate(zip(list(down) + [mid], g)):
+        check_digest(t, d, TOL, "controlnet[nonsquare] out %d" % i)
