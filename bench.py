@@ -207,7 +207,8 @@ def main():
                       else "denoise-steps/s (ControlNet+adapter fwd) SVD 16-frame clip (CFG pair, 32 frames)",
             "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp16 storage / fp32 accumulate", "data": "synthetic latents, prompts, condition images; seeded random weights",
+            "dtype": "f16",    # MFMA operands fp16; fp32 accumulate / statistics / softmax / residual streams
+            "data": "synthetic latents, prompts, condition images; seeded random weights",
             "config": {"workload": "SDXL depth 1024^2 batch=8 per GPU (N=8 images enter ControlNet+adapter, no CFG doubling); "
                                    "pool->ControlNet(SD1.5, 64x64 latents, 512^2 cond)->Ctrl-Adapter(A,B,C x3, up x2)"
                                    if workload == "sdxl" else "SVD depth, 16 frames, CFG pair (N=32 frames), skip_conv_in",
