@@ -25,7 +25,79 @@ def c_spec(count_fn, spec_fn, cfg):
     return out
 
 
-class ParamTreeModule(nn.Module):
+class PretrainedMixin:
+    """diffusers-layout persistence shared by every mirror (ControlNetModel, ControlNetAdapter, ControlNetRouter):
+    `config.json` + `diffusion_pytorch_model.safetensors`, as the reference's call sites expect
+    (inference.py:217-254,324-345: `Cls.from_pretrained(repo_or_dir, subfolder=..., torch_dtype=...)`)."""
+
+    _WEIGHT_STEMS = ("diffusion_pytorch_model", "model", "pytorch_model")
+
+    def save_pretrained(self, path, safe_serialization=True, variant=None, **unused):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as fh:
+            json.dump(dict(self.config_dict(), _class_name=type(self).__name__), fh, indent=2)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        stem = "diffusion_pytorch_model" + (".%s" % variant if variant else "")
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(path, stem + ".safetensors"))
+        else:
+            torch.save(sd, os.path.join(path, stem + ".bin"))
+
+    @staticmethod
+    def _resolve_dir(path, subfolder, **hub_kw):
+        """local directory, or a hub id resolved through huggingface_hub (snapshot of the sub-folder only)"""
+        if os.path.isdir(path):
+            return os.path.join(path, subfolder) if subfolder else path
+        try:
+            from huggingface_hub import snapshot_download
+        except ImportError as e:       # pragma: no cover
+            raise FileNotFoundError("%r is not a directory and huggingface_hub is not installed" % path) from e
+        kw = {k: hub_kw[k] for k in ("cache_dir", "revision", "token", "local_files_only", "proxies") if hub_kw.get(k) is not None}
+        pats = [(subfolder + "/*") if subfolder else "*"]
+        root = snapshot_download(repo_id=path, allow_patterns=pats, **kw)
+        return os.path.join(root, subfolder) if subfolder else root
+
+    @classmethod
+    def _find_weights(cls, d, variant):
+        tried = []
+        for stem in cls._WEIGHT_STEMS:
+            for var in ([variant] if variant else []) + [None]:
+                for ext in (".safetensors", ".bin"):
+                    f = os.path.join(d, stem + (".%s" % var if var else "") + ext)
+                    tried.append(os.path.basename(f))
+                    if os.path.exists(f):
+                        return f
+        raise FileNotFoundError("no weights file in %s (looked for %s)" % (d, ", ".join(tried)))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, torch_dtype=None, variant=None, **kwargs):
+        import inspect
+        d = cls._resolve_dir(str(pretrained_model_name_or_path), subfolder, **kwargs)
+        with open(os.path.join(d, "config.json")) as fh:
+            raw = json.load(fh)
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        cfg = {k: v for k, v in raw.items() if not k.startswith("_") and k in accepted}
+        wfile = cls._find_weights(d, variant)
+        if wfile.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(wfile)
+        else:
+            sd = torch.load(wfile, map_location="cpu", weights_only=True)
+        m = cls(**cfg)
+        # build the module in the CHECKPOINT's dtype before loading: the packers convert to the MFMA operand format
+        # themselves (with an fp16 range check), and the fp32-side parameters (norms, biases, mix factors, router
+        # weights) must not take a detour through fp16
+        fl = [v.dtype for v in sd.values() if v.is_floating_point()]
+        if fl and any(p.dtype != fl[0] for p in m.parameters()):
+            m = m.to(fl[0])
+        m.load_state_dict(sd)
+        if torch_dtype is not None:
+            m = m.to(torch_dtype)
+        return m
+
+
+class ParamTreeModule(PretrainedMixin, nn.Module):
     """nn.Module whose parameters are registered under dotted names (nested plain containers), so that
     state_dict() keys equal the reference module tree's keys."""
 
@@ -92,30 +164,6 @@ class ParamTreeModule(nn.Module):
     @property
     def device(self):
         return next(self.parameters()).device
-
-    # -- diffusers-layout persistence --
-    def save_pretrained(self, path):
-        from safetensors.torch import save_file
-        os.makedirs(path, exist_ok=True)
-        with open(os.path.join(path, "config.json"), "w") as fh:
-            json.dump(dict(self.config_dict(), _class_name=type(self).__name__), fh, indent=2)
-        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
-                  os.path.join(path, "diffusion_pytorch_model.safetensors"))
-
-    @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **unused):
-        from safetensors.torch import load_file
-        if subfolder:
-            path = os.path.join(path, subfolder)
-        with open(os.path.join(path, "config.json")) as fh:
-            cfg = {k: v for k, v in json.load(fh).items() if not k.startswith("_")}
-        m = cls(**cfg)
-        m.load_state_dict(load_file(os.path.join(path, "diffusion_pytorch_model.safetensors")))
-        if torch_dtype is not None:
-            m = m.to(torch_dtype)
-        return m
-
-
 class Config(dict):
     """attribute-style access like diffusers' FrozenDict (pipelines read e.g. controlnet.config.global_pool_conditions)"""
 

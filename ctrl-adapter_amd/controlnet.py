@@ -145,7 +145,8 @@ class ControlNetModel(ParamTreeModule):
             return ControlNetOutput(down, mid) if return_dict else (down, mid)
         outs, args, _keep = self._launch_args(sample, timestep, ehs, controlnet_cond, conditioning_scale, guess_mode,
                                               skip_conv_in, skip_time_emb, out_dtype)
-        L.check(L.lib().ctrl_controlnet_forward(self._ensure_plan(), *args, L.cur_stream()))
+        with torch.cuda.device(sample.device):      # plan, stream and launches follow the tensors' device, not the current one
+            L.check(L.lib().ctrl_controlnet_forward(self._ensure_plan(), *args, L.cur_stream()))
         down, mid = outs[:12], outs[12]
         if not return_dict:
             return (down, mid)

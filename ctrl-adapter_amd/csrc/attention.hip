@@ -274,23 +274,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
     }
 }
 
-const half_t* attn_zero_page() {
-    static half_t* z = nullptr;
-    if (!z) {
-        if (hipMalloc((void**)&z, 4096) != hipSuccess) return nullptr;
-        hipMemset(z, 0, 4096);
-    }
-    return z;
-}
+const half_t* attn_zero_page() { return (const half_t*)device_zero_page(); }
 
 template <int D, int NW, bool BATCH>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr size_t smem = (size_t)3 * 2 * 64 * DP * sizeof(half_t);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[kMaxDevices] = {};
+    const int dev = cur_device();
+    if (!attr_done[dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D, NW, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     const half_t* zeros = attn_zero_page();
     CTRL_CHECK(zeros != nullptr, "flash_attn: could not allocate the zero page");

@@ -32,6 +32,12 @@ void ctrl_set_error(const std::string& s);
     } while (0)
 #define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
+// ---- per-device singletons (one rank per GPU is the norm, but a process may drive several devices) ----
+constexpr int kMaxDevices = 16;
+inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kMaxDevices) ? d : 0; }
+// 4 KiB of zeros on the current device: source of the LDS-DMA loads that implement zero padding
+const void* device_zero_page();
+
 // ---- per-kernel-class event profiler (used by bench.py's roofline leg) ----
 void prof_before(const char* tag, hipStream_t s);
 void prof_after(hipStream_t s);

@@ -218,14 +218,19 @@ __global__ void router_softmax_kernel(const float* __restrict__ wg, RouterMask m
 }
 
 // ---------------- weight packers (run once at plan build) ----------------
-__global__ void pack_conv_w_kernel(const void* __restrict__ w, int dt, half_t* __restrict__ out, int Cout, int Cin, int taps) {
+// fp16 range guard of the GEMM-weight packers: bf16 / fp32 checkpoints may hold values fp16 cannot (|w| > 65504)
+__device__ __forceinline__ half_t to_h_checked(float v, int* ovf) {
+    if (ovf && !(fabsf(v) <= 65504.f)) *ovf = 1;      // also catches inf / nan; benign race (all writers store 1)
+    return (half_t)v;
+}
+__global__ void pack_conv_w_kernel(const void* __restrict__ w, int dt, half_t* __restrict__ out, int Cout, int Cin, int taps, int* ovf) {
     const size_t total = (size_t)Cout * taps * Cin;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int ci = (int)(i % Cin);
         const size_t r = i / Cin;
         const int tp = (int)(r % taps);
         const size_t co = r / taps;
-        out[i] = (half_t)load_as_f32(w, (co * Cin + ci) * taps + tp, dt);
+        out[i] = to_h_checked(load_as_f32(w, (co * Cin + ci) * taps + tp, dt), ovf);
     }
 }
 __global__ void pack_conv_w_direct_kernel(const void* __restrict__ w, int dt, float* __restrict__ out, int Cout, int Cin) {
@@ -244,13 +249,13 @@ __device__ __forceinline__ int geglu_src_row(int p, int N) {
     const int blk = p >> 5, wi = p & 31;
     return wi < 16 ? blk * 16 + wi : N / 2 + blk * 16 + (wi - 16);
 }
-__global__ void pack_linear_w_kernel(const void* __restrict__ w, int dt, half_t* __restrict__ out, int N, int K, int geglu) {
+__global__ void pack_linear_w_kernel(const void* __restrict__ w, int dt, half_t* __restrict__ out, int N, int K, int geglu, int* ovf) {
     const size_t total = (size_t)N * K;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int k = (int)(i % K);
         const int p = (int)(i / K);
         const int srow = geglu ? geglu_src_row(p, N) : p;
-        out[i] = (half_t)load_as_f32(w, (size_t)srow * K + k, dt);
+        out[i] = to_h_checked(load_as_f32(w, (size_t)srow * K + k, dt), ovf);
     }
 }
 __global__ void pack_vec_kernel(const void* __restrict__ v, int dt, float* __restrict__ out, int N, int geglu) {
@@ -336,17 +341,17 @@ int op_router_softmax(const float* wg, const int* mask, float* out, int R, int E
     LAUNCH("router", router_softmax_kernel, dim3((R + 63) / 64), dim3(64), 0, s, wg, rm, out, R, E, equal_weights);
     return 0;
 }
-int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s) {
-    LAUNCH("pack", pack_conv_w_kernel, dim3(grid_for((size_t)Cout * Cin * taps)), dim3(256), 0, s, w, dtype, out, Cout, Cin, taps);
+int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s, int* ovf) {
+    LAUNCH("pack", pack_conv_w_kernel, dim3(grid_for((size_t)Cout * Cin * taps)), dim3(256), 0, s, w, dtype, out, Cout, Cin, taps, ovf);
     return 0;
 }
 int op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, hipStream_t s) {
     LAUNCH("pack", pack_conv_w_direct_kernel, dim3(grid_for((size_t)Cout * Cin * 9)), dim3(256), 0, s, w, dtype, out, Cout, Cin);
     return 0;
 }
-int op_pack_linear_w(const void* w, int dtype, half_t* out, int N, int K, int geglu, hipStream_t s) {
+int op_pack_linear_w(const void* w, int dtype, half_t* out, int N, int K, int geglu, hipStream_t s, int* ovf) {
     CTRL_CHECK(!geglu || N % 32 == 0, "pack_linear_w: GEGLU needs N % 32 == 0");
-    LAUNCH("pack", pack_linear_w_kernel, dim3(grid_for((size_t)N * K)), dim3(256), 0, s, w, dtype, out, N, K, geglu);
+    LAUNCH("pack", pack_linear_w_kernel, dim3(grid_for((size_t)N * K)), dim3(256), 0, s, w, dtype, out, N, K, geglu, ovf);
     return 0;
 }
 int op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, hipStream_t s) {

@@ -598,14 +598,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmArgs a, const f
     }
 }
 
-const half_t* zero_page() {
-    static half_t* z = nullptr;
-    if (!z) {
-        if (hipMalloc((void**)&z, 4096) != hipSuccess) return nullptr;
-        hipMemset(z, 0, 4096);
-    }
-    return z;
-}
+const half_t* zero_page() { return (const half_t*)device_zero_page(); }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
 int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
@@ -615,11 +608,12 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     constexpr int stage_w = (BN / WAVES_N) > (BM / WAVES_M) ? (BN / WAVES_N) : (BM / WAVES_M);     // row / transposed staging
     constexpr size_t stage_bytes = (size_t)WAVES_M * WAVES_N * 16 * (stage_w + 4) * sizeof(float);
     constexpr size_t smem = ring > stage_bytes ? ring : stage_bytes;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[kMaxDevices] = {};       // function attributes are per device
+    const int dev = cur_device();
+    if (!attr_done[dev]) {
         HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     const half_t* zeros = zero_page();
     CTRL_CHECK(zeros != nullptr, "igemm: could not allocate the zero page");

@@ -87,10 +87,11 @@ int op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w,
 
 // weight packing (load time)
 // conv weight [Cout][Cin][kh][kw] (any dtype) -> fp16 [Cout][kh*kw][Cin]   (taps-major K)
-int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s);
+int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s, int* ovf = nullptr);
+//   ovf (optional, device): set to 1 when a value does not fit fp16 (|w| > 65504, inf, nan)
 // conv weight [Cout][Cin][3][3] -> fp32 [9][Cin][Cout] for the direct kernel
 int op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, hipStream_t s);
 // linear weight [N][K] -> fp16 [N][K]; optional GEGLU interleave of rows (N = 2*inner)
-int op_pack_linear_w(const void* w, int dtype, half_t* out, int N, int K, int geglu, hipStream_t s);
+int op_pack_linear_w(const void* w, int dtype, half_t* out, int N, int K, int geglu, hipStream_t s, int* ovf = nullptr);
 // vector -> fp32 (optional GEGLU interleave)
 int op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, hipStream_t s);

@@ -301,7 +301,7 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
 
 }  // namespace
 
-struct ctrl_adapter {
+struct ctrl_adapter : PlanBase {
     AdapterW w;
     std::unique_ptr<Packer> packer;
     Arena arena;
@@ -447,7 +447,7 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     }
     if (w.has_mid && k.ins[12] && k.outs[12]) {
         const int h = std::max(k.H0 / 8, 1), wd = std::max(k.W0 / 8, 1);
-        TRY(run_in_lane(lane_of(8), 12, w.mid, k.ins[12], k.outs[12], h, wd, (size_t)1280 * h * wd));
+        TRY(run_in_lane(lane_of(8), 12, w.mid, k.ins[12], k.outs[12], h, wd, (size_t)1280 * h * up * wd * up));
     }
     if (!cx.dry && nl > 1) {
         for (int l = 1; l < nl; ++l) {
@@ -491,11 +491,13 @@ int ctrl_adapter_create(const ctrl_adapter_config* cfg, const ctrl_tensor_ref* t
                         ctrl_adapter** out) {
     CTRL_CHECK(cfg && tensors && out, "adapter_create: null argument");
     std::unique_ptr<ctrl_adapter> h(new ctrl_adapter());
+    TRY(h->init_base(n_tensors > 0 ? tensors[0].data : nullptr));
+    DeviceGuard dg(h->device);
     h->packer.reset(new Packer(tensors, n_tensors, (hipStream_t)stream));
     int rc = build_adapter(*h->packer, *cfg, &h->w);
     if (rc) return rc;
     TRY(h->init_lanes());
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    TRY(h->packer->finish());
     *out = h.release();
     return 0;
 }
@@ -516,6 +518,9 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
                "adapter_forward: encoder_hidden_states batch must be 1 or N");
     for (int i = 0; i < 12; ++i) CTRL_CHECK(ins[i] && outs[i], "adapter_forward: null slot pointer");
     hipStream_t s = (hipStream_t)stream;
+    DeviceGuard dg(h->device);
+    bool capturing = false;
+    TRY(h->enter(s, &capturing));
     const int* map_dev = nullptr;
     if (frame_pos) {
         CTRL_CHECK(N_out >= N && N_out <= ctrl_adapter::kMaxMap, "adapter_forward_scatter: need N <= N_out <= 1024");
@@ -549,12 +554,13 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
     TRY(adapter_run(dry, h->w, k));
-    TRY(h->arena.ensure(workspace_bytes(dry), s));
+    TRY(h->arena.ensure(workspace_bytes(dry)));
     h->arena.off = 0;
     Ctx cx{&h->arena, s, false};
     cx.f32stream = dry.f32stream;
     cx.stats_total = dry.stats_total;
-    return adapter_run(cx, h->w, k);
+    TRY(adapter_run(cx, h->w, k));
+    return h->leave(s, capturing);
 }
 
 int ctrl_adapter_forward(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,

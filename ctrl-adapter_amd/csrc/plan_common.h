@@ -76,10 +76,27 @@ struct Packer : ParamSink {
     std::vector<void*> allocs;
     size_t bytes = 0;
     hipStream_t s;
+    int* ovf = nullptr;          // device flag: set by a packer kernel that met a weight outside the fp16 range
     Packer(const ctrl_tensor_ref* t, int n, hipStream_t stream) : s(stream) {
         for (int i = 0; i < n; ++i) map[t[i].name] = &t[i];
     }
-    void release_all() { for (void* p : allocs) hipFree(p); allocs.clear(); }
+    void release_all() { for (void* p : allocs) hipFree(p); allocs.clear(); if (ovf) hipFree(ovf); ovf = nullptr; }
+    int* ovf_flag() {
+        if (!ovf && hipMalloc((void**)&ovf, sizeof(int)) == hipSuccess) (void)hipMemsetAsync(ovf, 0, sizeof(int), s);
+        return ovf;
+    }
+    // end of packing: wait for the packed copies (the source tensors may be freed afterwards) and refuse checkpoints
+    // whose GEMM weights do not fit the fp16 MFMA operand format (bf16 / fp32 values beyond +-65504, inf, nan)
+    int finish() {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ovf) {
+            int h = 0;
+            HIP_TRY(hipMemcpy(&h, ovf, sizeof(int), hipMemcpyDeviceToHost));
+            CTRL_CHECK(h == 0, "a weight tensor holds values outside the fp16 range (|w| > 65504, inf or nan): the MFMA "
+                               "operand format of this library cannot represent this checkpoint");
+        }
+        return 0;
+    }
     int dalloc(size_t nbytes, void** out) {
         HIP_TRY(hipMalloc(out, nbytes ? nbytes : 16));
         allocs.push_back(*out);
@@ -109,7 +126,7 @@ struct Packer : ParamSink {
         const ctrl_tensor_ref* t;
         TRY(get(name + ".weight", {N, K}, &t));
         TRY(dalloc((size_t)N * K * sizeof(half_t), (void**)&out->w));
-        TRY(op_pack_linear_w(t->data, t->dtype, out->w, N, K, geglu ? 1 : 0, s));
+        TRY(op_pack_linear_w(t->data, t->dtype, out->w, N, K, geglu ? 1 : 0, s, ovf_flag()));
         out->b = nullptr;
         if (bias) {
             TRY(dalloc((size_t)N * sizeof(float), (void**)&out->b));
@@ -128,7 +145,7 @@ struct Packer : ParamSink {
         for (size_t i = 0; i < names.size(); ++i) {
             const ctrl_tensor_ref* t;
             TRY(get(names[i] + ".weight", {Ns[i], K}, &t));
-            TRY(op_pack_linear_w(t->data, t->dtype, out->w + (size_t)off * K, Ns[i], K, 0, s));
+            TRY(op_pack_linear_w(t->data, t->dtype, out->w + (size_t)off * K, Ns[i], K, 0, s, ovf_flag()));
             if (bias) TRY(vec(names[i] + ".bias", Ns[i], false, out->b + off));
             off += Ns[i];
         }
@@ -141,7 +158,7 @@ struct Packer : ParamSink {
         if (temporal) TRY(get(name + ".weight", {Cout, Cin, 3, 1, 1}, &t));
         else TRY(get(name + ".weight", {Cout, Cin, k, k}, &t));
         TRY(dalloc((size_t)Cout * Cin * taps * sizeof(half_t), (void**)&out->w));
-        TRY(op_pack_conv_w(t->data, t->dtype, out->w, Cout, Cin, taps, s));
+        TRY(op_pack_conv_w(t->data, t->dtype, out->w, Cout, Cin, taps, s, ovf_flag()));
         TRY(dalloc((size_t)Cout * sizeof(float), (void**)&out->b));
         TRY(vec(name + ".bias", Cout, false, out->b));
         out->Cout = Cout; out->Cin = Cin; out->taps = taps;
@@ -183,16 +200,62 @@ struct Packer : ParamSink {
 struct Arena {
     char* base = nullptr;
     size_t cap = 0, off = 0, peak = 0;
-    ~Arena() { if (base) hipFree(base); }
-    int ensure(size_t need, hipStream_t s) {
+    std::vector<void*> retired;      // outgrown blocks: kept until the plan is destroyed (see ensure)
+    ~Arena() {
+        if (base) hipFree(base);
+        for (void* p : retired) hipFree(p);
+    }
+    // Grows by allocating a NEW block; the old one is retired, not freed: launches already queued on any stream and
+    // hipGraphs captured with the old addresses baked in (bench.py, per-shape graphs of a server) keep reading and
+    // writing valid memory.  The cost is the retained bytes of the smaller shapes seen before the largest one.
+    int ensure(size_t need) {
         if (need <= cap) return 0;
-        HIP_TRY(hipStreamSynchronize(s));     // the old buffer may still be in use by queued work
-        if (base) HIP_TRY(hipFree(base));
-        base = nullptr; cap = 0;
-        HIP_TRY(hipMalloc((void**)&base, need));
-        cap = need;
+        char* nb = nullptr;
+        HIP_TRY(hipMalloc((void**)&nb, need));
+        if (base) retired.push_back(base);
+        base = nb; cap = need;
         return 0;
     }
+};
+
+// State every plan carries besides its weights: the device it lives on and the stream that used its workspace last.
+struct PlanBase {
+    int device = 0;
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
+    hipEvent_t last_done = nullptr;
+    int init_base(const void* any_param) {
+        hipPointerAttribute_t at;
+        if (any_param && hipPointerGetAttributes(&at, any_param) == hipSuccess) device = at.device;
+        else HIP_TRY(hipGetDevice(&device));
+        return 0;
+    }
+    ~PlanBase() { if (last_done) (void)hipEventDestroy(last_done); }
+    // Two forwards on different streams share one workspace: the later one waits for the earlier one's last launch.
+    // (Inside a stream capture nothing is recorded or waited for: a graph replay is ordered by its launch stream.)
+    int enter(hipStream_t s, bool* capturing) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cs);
+        *capturing = (cs == hipStreamCaptureStatusActive);
+        if (!*capturing && last_valid && last_stream != s) HIP_TRY(hipStreamWaitEvent(s, last_done, 0));
+        return 0;
+    }
+    int leave(hipStream_t s, bool capturing) {
+        if (capturing) return 0;
+        if (!last_done) HIP_TRY(hipEventCreateWithFlags(&last_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(last_done, s));
+        last_stream = s; last_valid = true;
+        return 0;
+    }
+};
+// RAII: run a plan call on the plan's device (model.to('cuda:1') without torch.cuda.set_device), restore afterwards
+struct DeviceGuard {
+    int prev = -1, want;
+    explicit DeviceGuard(int dev) : want(dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
 };
 
 // Execution context: `dry` = sizing pass (allocations only advance the offset, nothing is launched).

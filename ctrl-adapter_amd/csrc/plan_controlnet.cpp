@@ -142,7 +142,7 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
 
 }  // namespace
 
-struct ctrl_controlnet {
+struct ctrl_controlnet : PlanBase {
     ControlNetW w;
     std::unique_ptr<Packer> packer;
     Arena arena;
@@ -151,6 +151,7 @@ struct ctrl_controlnet {
     hipEvent_t fork_ev = nullptr, done_ev = nullptr, out_ev[13] = {};
     // step-invariant cache of the conditioning embedder's last hidden map (CTRL_COND_KEEP / CTRL_COND_REUSE)
     half_t* cond_cache = nullptr;
+    std::vector<void*> cond_retired;    // outgrown caches stay alive (captured graphs may still address them)
     size_t cond_cache_elems = 0;        // capacity
     int cond_N = 0, cond_H = 0, cond_W = 0;   // what the cache holds (0 = nothing)
     int init_async() {
@@ -163,6 +164,7 @@ struct ctrl_controlnet {
     ~ctrl_controlnet() {
         if (packer) packer->release_all();
         if (cond_cache) (void)hipFree(cond_cache);
+        for (void* p : cond_retired) (void)hipFree(p);
         if (side) (void)hipStreamDestroy(side);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
         if (done_ev) (void)hipEventDestroy(done_ev);
@@ -354,11 +356,13 @@ int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_
                            ctrl_controlnet** out) {
     CTRL_CHECK(cfg && tensors && out, "controlnet_create: null argument");
     std::unique_ptr<ctrl_controlnet> h(new ctrl_controlnet());
+    TRY(h->init_base(n_tensors > 0 ? tensors[0].data : nullptr));
+    DeviceGuard dg(h->device);           // the plan lives on the parameters' device, whatever the current device is
     h->packer.reset(new Packer(tensors, n_tensors, (hipStream_t)stream));
     int rc = build_controlnet(*h->packer, *cfg, &h->w);
     if (rc) return rc;     // ~ctrl_controlnet frees what was packed so far
     TRY(h->init_async());
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // packed copies are complete; source tensors may be freed
+    TRY(h->packer->finish());            // sync: packed copies are complete (source tensors may be freed); fp16 range check
     *out = h.release();
     return 0;
 }
@@ -370,6 +374,9 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
                                    const void* controlnet_cond, int cond_dtype, float conditioning_scale, int flags,
                                    void* const* outs, int out_dtype, hipStream_t s, hipEvent_t* out_ev) {
     CTRL_CHECK(h && sample && timesteps && encoder_hidden_states && controlnet_cond && outs, "controlnet_forward: null argument");
+    DeviceGuard dg(h->device);
+    bool capturing = false;
+    TRY(h->enter(s, &capturing));
     CTRL_CHECK(N >= 1 && N <= 4096 && Hs >= 1 && Ws >= 1 && Lk >= 1, "controlnet_forward: bad sizes");
     CTRL_CHECK(Hs % 8 == 0 && Ws % 8 == 0, "controlnet_forward: latent height/width must be multiples of 8 (3 stride-2 stages)");
     CTRL_CHECK(t_count == 1 || t_count == N, "controlnet_forward: need 1 or N timesteps");
@@ -385,8 +392,7 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
             CTRL_CHECK(h->cond_cache && h->cond_N == N && h->cond_H == Hs && h->cond_W == Ws,
                        "controlnet_forward: CTRL_COND_REUSE without a matching CTRL_COND_KEEP forward");
         } else if (need > h->cond_cache_elems) {
-            HIP_TRY(hipStreamSynchronize(s));
-            if (h->cond_cache) HIP_TRY(hipFree(h->cond_cache));
+            if (h->cond_cache) h->cond_retired.push_back(h->cond_cache);
             h->cond_cache = nullptr; h->cond_cache_elems = 0; h->cond_N = 0;
             HIP_TRY(hipMalloc((void**)&h->cond_cache, need * sizeof(half_t)));
             h->cond_cache_elems = need;
@@ -400,14 +406,14 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
     TRY(controlnet_run(dry, h->w, a));
-    TRY(h->arena.ensure(workspace_bytes(dry), s));
+    TRY(h->arena.ensure(workspace_bytes(dry)));
     h->arena.off = 0;
     Ctx cx{&h->arena, s, false};
     cx.f32stream = dry.f32stream;
     cx.stats_total = dry.stats_total;
     TRY(controlnet_run(cx, h->w, a));
     if (keep && !reuse) { h->cond_N = N; h->cond_H = Hs; h->cond_W = Ws; }
-    return 0;
+    return h->leave(s, capturing);
 }
 
 int ctrl_controlnet_forward(ctrl_controlnet* h, const void* sample, int sample_dtype, int N, int Hs, int Ws,

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "../../include/ctrl_hip.h"
 #include <map>
+#include <mutex>
 #include <vector>
 #include <cstring>
 #include <cstdarg>
@@ -11,6 +12,18 @@
 
 static thread_local std::string g_err;
 void ctrl_set_error(const std::string& s) { g_err = s; }
+
+const void* device_zero_page() {
+    static void* z[kMaxDevices] = {};
+    static std::mutex mu;
+    const int d = cur_device();
+    std::lock_guard<std::mutex> lk(mu);
+    if (!z[d]) {
+        if (hipMalloc(&z[d], 4096) != hipSuccess) return nullptr;
+        if (hipMemset(z[d], 0, 4096) != hipSuccess) return nullptr;
+    }
+    return z[d];
+}
 
 bool g_prof_on = false;
 double g_prof_flops = 0, g_prof_bytes = 0;

@@ -82,10 +82,11 @@ class ControlNetAdapter(ParamTreeModule):
         outs, mid_out, args, tail, finish, _keep = self._launch_args(
             down_block_res_samples, mid_block_res_sample, num_frames, timestep, encoder_hidden_states, scatter_to, out_dtype, clip_batch)
         in_ptrs, in_dt = _keep[0], _keep[1]
-        if tail is None:
-            L.check(L.lib().ctrl_adapter_forward(self._ensure_plan(), in_ptrs, in_dt, *args, L.cur_stream()))
-        else:
-            L.check(L.lib().ctrl_adapter_forward_scatter(self._ensure_plan(), in_ptrs, in_dt, *args, *tail, L.cur_stream()))
+        with torch.cuda.device(down_block_res_samples[0].device):
+            if tail is None:
+                L.check(L.lib().ctrl_adapter_forward(self._ensure_plan(), in_ptrs, in_dt, *args, L.cur_stream()))
+            else:
+                L.check(L.lib().ctrl_adapter_forward_scatter(self._ensure_plan(), in_ptrs, in_dt, *args, *tail, L.cur_stream()))
         return finish(outs, mid_out)
 
     def _launch_args(self, down_block_res_samples, mid_block_res_sample, num_frames, timestep, encoder_hidden_states,

@@ -4,10 +4,10 @@ import torch
 from torch import nn
 
 from . import ops
-from ._plan import Config
+from ._plan import Config, PretrainedMixin
 
 
-class ControlNetRouter(nn.Module):
+class ControlNetRouter(PretrainedMixin, nn.Module):
     def __init__(self, num_experts=2, backbone_model_name=None, router_type="simple_weights", embedding_dim=None,
                  num_routers=12, add_mid_block_router=True, use_sparsemax=False):
         super().__init__()
@@ -20,6 +20,9 @@ class ControlNetRouter(nn.Module):
         if router_type == "simple_weights":
             self.down_blocks_router = nn.ModuleList([self._wg(num_experts) for _ in range(num_routers)])
             self.mid_block_router = self._wg(num_experts) if add_mid_block_router else None
+
+    def config_dict(self):
+        return dict(self.config)
 
     @staticmethod
     def _wg(e):
@@ -41,8 +44,8 @@ class ControlNetRouter(nn.Module):
                 rows.append(self.mid_block_router.wg.weight[:, 0])
             wg = torch.stack(rows).float().contiguous()
         else:
-            dev = "cuda"
-            wg = torch.zeros(R, self.num_experts, device=dev)
+            # no parameters to take the device from (equal weights): the caller's current device, like every op here
+            wg = torch.zeros(R, self.num_experts, device=torch.device("cuda", torch.cuda.current_device()))
         if not wg.is_cuda:
             raise RuntimeError("ControlNetRouter (libctrlhip) runs on the GPU only")
         mask = [int(m) for m in sparse_mask] if sparse_mask is not None else None
@@ -59,6 +62,9 @@ class ControlNetRouter(nn.Module):
         inference_quirk=False applies train.py's formula w[k][idx] (idx = position among the active experts)."""
         E = len(expert_masks)
         act = [e for e in range(E) if expert_masks[e]]
+        if inference_quirk and (num_frames is None or int(num_frames) < 1):
+            raise ValueError("merge(inference_quirk=True) needs num_frames (the pipeline indexes "
+                             "w.repeat_interleave(num_frames)); pass inference_quirk=False for train.py's formula")
 
         def widx(e, k):
             if inference_quirk:

@@ -41,7 +41,9 @@ def controlled_step(controlnet, adapter, sample, timestep, encoder_hidden_states
         adapter_encoder_hidden_states, scatter_to, out_dtype, clip_batch)
     N, H0, W0 = ad_args[0], ad_args[1], ad_args[2]
     frame_pos, n_out = (tail[0], tail[1]) if tail is not None else (None, N)
-    L.check(L.lib().ctrl_step_forward(
-        controlnet._ensure_plan(), adapter._ensure_plan(), *cn_args,
-        ad_args[3], *ad_args[4:10], int(use_m and mid_out is not None), ad_args[10], ad_args[11], frame_pos, n_out, L.cur_stream()))
+    import torch
+    with torch.cuda.device(sample.device):
+        L.check(L.lib().ctrl_step_forward(
+            controlnet._ensure_plan(), adapter._ensure_plan(), *cn_args,
+            ad_args[3], *ad_args[4:10], int(use_m and mid_out is not None), ad_args[10], ad_args[11], frame_pos, n_out, L.cur_stream()))
     return (down, mid), finish(outs, mid_out)
