@@ -1,28 +1,35 @@
 """Benchmark of the Ctrl-Adapter denoising hot path on MI355X (BASELINE.json metric).
 
-One "step" = what the reference's SDXL pipeline does per denoising step around the UNet call
-(sdxl/pipelines/sdxl_controlnet_adapter_pipeline.py:1306-1343): pool the latents to 64x64, ControlNetModel.forward,
-ControlNetAdapter.forward -- for a batch of 8 images at 1024^2 (BASELINE.json configs[1]), synthetic latents / prompts /
-condition images already resident in HBM, seeded random weights of the real architecture (361 M + 184 M parameters).
+One "step" = what the reference's pipelines do per denoising step around the UNet call
+(sdxl/pipelines/sdxl_controlnet_adapter_pipeline.py:1306-1343; svd/pipelines/...:684-747; i2vgen_xl/pipelines/...:957-1082):
+pool the latents to 64x64, ControlNetModel.forward (K of them + router + merge in the multi-condition config),
+ControlNetAdapter.forward -- on synthetic latents / prompts / condition images already resident in HBM and seeded random
+weights of the real architectures (361 M + 184 M / 587 M parameters).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sdxl|svd16|i2vgen16|multi3]
+
+`--gpus N` with N > 1 launches the N ranks itself (re-executes under `python -m torch.distributed.run`, one rank per
+GPU over RCCL, 127.0.0.1 rendezvous); started under a launcher already (RANK / WORLD_SIZE in the environment) it joins it.
 
 Prints ONE JSON line (rank 0).  Besides the driver contract it carries:
-  roofline      the dominant kernel class (flash attention), algorithmic FLOPs / HIP-event time, vs the dense fp16 MFMA peak
-  cpu_baseline  the pure-PyTorch fp32 oracle on the host cores, on a bounded sample (1 image of the batch)
-  kernels       per-kernel-class time of one profiled step (HIP events around every launch on the launch stream)
+  roofline      ONE kernel (symbol with template arguments + shape): algorithmic FLOPs per launch / HIP-event time per
+                launch on the launch stream, vs the dense fp16 MFMA peak; `traffic` = PMC HBM bytes per launch of that
+                kernel from the committed rocprofv3 passes (profiles/, tools/profile_round.sh)
+  per_kernel    the same for every (template instantiation, shape) of the step, sorted by time
+  kernels       per kernel class (what the library's profiler tags)
+  cpu_baseline  the pure-PyTorch fp32 oracle on the host cores: the whole step of this workload, 1 warm-up + 3 repetitions
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "golden")]
-
-import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
@@ -37,25 +44,86 @@ VIDEO_ADAPTER = dict(backbone_model_name="svd", num_blocks=1, num_frames=16, num
                      add_adapter_location_A=True, add_adapter_location_B=True, add_adapter_location_C=True,
                      add_adapter_location_D=True, add_adapter_location_M=True)
 
+# BASELINE.json configs -> workloads.  flops: SURVEY.md section 8d (ControlNet 0.2835 TFLOP / frame, SDXL adapter 2.258 /
+# image, video adapter 0.659 / frame)
+WORKLOADS = {
+    "sdxl": dict(config=2, video=False, n_cn=1, skip_conv_in=False, adapter=SDXL_ADAPTER,
+                 metric="denoise-steps/s (ControlNet+adapter fwd) SDXL 1024^2 b=8",
+                 what="SDXL depth 1024^2 batch=%d per GPU (N=%d images enter ControlNet+adapter, no CFG doubling); "
+                      "pool->ControlNet(SD1.5, 64x64 latents, 512^2 cond)->Ctrl-Adapter(A,B,C x3, up x2)"),
+    "svd16": dict(config=3, video=True, n_cn=1, skip_conv_in=True, adapter=VIDEO_ADAPTER,
+                  metric="denoise-steps/s (ControlNet+adapter fwd) SVD 16-frame clip (CFG pair, 32 frames)",
+                  what="SVD depth 576x1024, 16 frames, CFG pair (N=32 frames enter ControlNet+adapter), skip_conv_in; "
+                       "ControlNet(64x64 latents)->Ctrl-Adapter(A-D+M, spatial+temporal ResNets and transformers)"),
+    "i2vgen16": dict(config=4, video=True, n_cn=1, skip_conv_in=False, adapter=dict(VIDEO_ADAPTER, backbone_model_name="i2vgen-xl"),
+                     metric="denoise-steps/s (ControlNet+adapter fwd) I2VGen-XL 16-frame clip per GPU (CFG pair, 32 frames)",
+                     what="I2VGen-XL depth, one 16-frame clip per GPU (CFG pair, N=32 frames; 8 clips on 8 GPUs = BASELINE config 4), "
+                          "whole clips sharded across ranks: no data-path collective"),
+    "multi3": dict(config=5, video=True, n_cn=3, skip_conv_in=False, adapter=dict(VIDEO_ADAPTER, backbone_model_name="i2vgen-xl"),
+                   metric="denoise-steps/s (3 ControlNets + router + merge + adapter fwd) I2VGen-XL 16-frame clip per GPU",
+                   what="I2VGen-XL multi-condition (depth+canny+softedge): K=3 ControlNets -> ctrl_router weights -> expert merge -> "
+                        "Ctrl-Adapter, one 16-frame clip per GPU (CFG pair, N=32 frames)"),
+}
 
-def build_models(dev, workload):
+
+def step_flops(w, n):
+    if not w["video"]:
+        return (0.2835 + 2.258) * 1e12 * n
+    return (w["n_cn"] * 0.2835 + 0.659) * 1e12 * n
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and relay their output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def build_models(dev, w):
     import ctrl_adapter_amd as P
-    from oracle.init import seeded_init      # seeded random weights (shared with the parity tests)
-    cn = seeded_init(P.ControlNetModel(cross_attention_dim=768), seed=11).to(dev)
-    ad = seeded_init(P.ControlNetAdapter(**(SDXL_ADAPTER if workload == "sdxl" else VIDEO_ADAPTER)), seed=22).to(dev)
-    return P, cn, ad
+    from ctrl_adapter_amd.synthetic import seeded_init      # seeded random weights (no checkpoints offline)
+    cns = [seeded_init(P.ControlNetModel(cross_attention_dim=768), seed=11 + 100 * k).to(dev) for k in range(w["n_cn"])]
+    ad = seeded_init(P.ControlNetAdapter(**w["adapter"]), seed=22).to(dev)
+    router = None
+    if w["n_cn"] > 1:
+        router = seeded_init(P.ControlNetRouter(num_experts=w["n_cn"], router_type="simple_weights", num_routers=12), seed=44).to(dev)
+    return P, cns, ad, router
 
 
-def make_inputs(dev, workload, n, seed):
+def make_inputs(dev, w, n, seed):
+    import torch
     g = torch.Generator().manual_seed(seed)
-    if workload == "sdxl":
+    if not w["video"]:
         lat = torch.randn(n, 4, 128, 128, generator=g)
         ehs_a = torch.randn(n, 77, 2048, generator=g)
     else:
         lat = torch.randn(n, 4, 64, 64, generator=g)
         ehs_a = torch.randn(1, 1, 1024, generator=g)
-    d = dict(latents=lat, ehs_c=torch.randn(n, 77, 768, generator=g), cond=torch.rand(n, 3, 512, 512, generator=g), ehs_a=ehs_a)
+    d = dict(latents=lat, ehs_c=torch.randn(n, 77, 768, generator=g), ehs_a=ehs_a)
+    for k in range(w["n_cn"]):
+        d["cond%d" % k] = torch.rand(n, 3, 512, 512, generator=g)
     return {k: v.half().to(dev) for k, v in d.items()}
+
+
+def pmc_traffic_for(kernel_row):
+    """HBM bytes per launch of one (symbol, grid) from the committed rocprofv3 PMC passes (cannot run inside the bench)"""
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")))
+    for tfile in reversed(tfiles):
+        try:
+            with open(tfile) as fh:
+                doc = json.load(fh)
+        except Exception:
+            continue
+        ent = doc.get("kernels", {}).get("%s|%d" % (kernel_row["symbol"], kernel_row["grid"]))
+        if ent:
+            return ent.get("hbm_bytes_per_launch_corrected"), os.path.basename(tfile)
+    return None, None
 
 
 def main():
@@ -63,57 +131,72 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU entering the hot path (BASELINE: 8)")
-    ap.add_argument("--workload", default="sdxl", choices=["sdxl", "svd16"])
+    ap.add_argument("--batch", type=int, default=8, help="sdxl: images per GPU entering the hot path (BASELINE: 8)")
+    ap.add_argument("--workload", default="sdxl", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused", action="store_true",
                     help="time the fused controlled_step(controlnet, adapter, ...) instead of the pipelines' two calls "
-                         "controlnet(...) ; adapter(...) (same arithmetic, bit-identical results, ~1 % faster)")
+                         "controlnet(...) ; adapter(...) (same arithmetic, bit-identical results)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert args.gpus == world, "--gpus must equal the number of launched ranks"
+    import ctrl_adapter_amd.dp as dp
+    dp.init("nccl")
     torch.set_grad_enabled(False)
 
-    workload = "sdxl" if args.workload == "sdxl" else "video"
-    n = args.batch if workload == "sdxl" else 32          # svd16: one CFG pair of 16-frame clips
-    P, cn, ad = build_models(dev, workload)
-    x = make_inputs(dev, workload, n, seed=1234 + rank)   # every rank owns different images (data parallel, no collective)
+    w = WORKLOADS[args.workload]
+    n = args.batch if not w["video"] else 32          # video: one CFG pair of a 16-frame clip per GPU
+    nf = 1 if not w["video"] else 16
+    P, cns, ad, router = build_models(dev, w)
+    x = make_inputs(dev, w, n, seed=1234 + rank)       # every rank owns different images / clips (no collective)
     t = torch.tensor([499.0], device=dev)
-    nf = 1 if workload == "sdxl" else 16
-    skip_conv_in = workload != "sdxl"                     # configs/svd_train_depth.yaml:59
+    masks = [1] * w["n_cn"]
+
+    def controlnets(s):
+        if w["n_cn"] == 1:
+            return cns[0](s, t, x["ehs_c"], x["cond0"], conditioning_scale=1.0, return_dict=False, skip_conv_in=w["skip_conv_in"])
+        downs, mids = [], []
+        for k, cn in enumerate(cns):                  # MultiControlNetModel.forward (controlnet/multicontrolnet.py:45-99)
+            d, m = cn(s, t, x["ehs_c"], x["cond%d" % k], conditioning_scale=1.0, return_dict=False, skip_conv_in=w["skip_conv_in"])
+            downs.append(d)
+            mids.append(m)
+        dw, mw = router(sparse_mask=masks)            # model/ctrl_router.py:85-112, then the pipeline's merge (:1000-1022)
+        return router.merge(downs, mids, dw, mw, masks, num_frames=nf, inference_quirk=True)
 
     def step_separate():
         s = P.pool_latents(x["latents"], (64, 64))
-        down, mid = cn(s, t, x["ehs_c"], x["cond"], conditioning_scale=1.0, return_dict=False, skip_conv_in=skip_conv_in)
+        down, mid = controlnets(s)
         return ad(down, mid_block_res_sample=mid, num_frames=nf, timestep=t, encoder_hidden_states=x["ehs_a"])
 
     def step_fused():
         s = P.pool_latents(x["latents"], (64, 64))
-        return P.controlled_step(cn, ad, s, t, x["ehs_c"], x["cond"], 1.0, skip_conv_in=skip_conv_in, num_frames=nf,
+        return P.controlled_step(cns[0], ad, s, t, x["ehs_c"], x["cond0"], 1.0, skip_conv_in=w["skip_conv_in"], num_frames=nf,
                                  adapter_encoder_hidden_states=x["ehs_a"])[1]
 
+    if args.fused and w["n_cn"] != 1:
+        raise SystemExit("--fused covers one ControlNet")
     step = step_fused if args.fused else step_separate
 
-    # eager warm-up: builds the plans (weight packing) and sizes the workspaces
-    for _ in range(2):
+    for _ in range(2):          # eager warm-up: builds the plans (weight packing) and sizes the workspaces
         step()
     torch.cuda.synchronize()
 
-    run = step
-    mode = "eager"
+    run, mode = step, "eager"
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -123,9 +206,8 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_out = step()
-            run = graph.replay
-            mode = "hipgraph"
+                static_out = step()      # noqa: F841  (keeps the captured outputs alive)
+            run, mode = graph.replay, "hipgraph"
         except Exception as e:   # capture is an optimisation only
             print("bench: hipGraph capture failed (%s); running eager" % str(e).split("\n")[0], file=sys.stderr)
             torch.cuda.synchronize()
@@ -134,93 +216,107 @@ def main():
     for _ in range(args.warmup):
         run()
 
-    import ctrl_adapter_amd.dp as dp
     elapsed = dp.timed_region(run, args.steps, device=dev)        # barrier + sync on both sides, MAX over ranks
     ms_per_step = elapsed / args.steps * 1e3
-    value = dp.aggregate_throughput(1, args.steps, elapsed, world)   # whole-job denoise-steps/s (each rank: batch of 8)
+    value = dp.aggregate_throughput(1, args.steps, elapsed, world)   # whole-job denoise-steps/s (each rank: its own batch / clip)
 
-    # ---- roofline leg: one eager step with HIP events around every launch (on the launch stream) ----
-    from ctrl_adapter_amd import ops
-    kernels = {}
-    roof = None
+    # ---- roofline leg: eager steps with HIP events around every launch, on the launch stream (lanes off) ----
+    kernels, per_kernel, roof = {}, [], None
     if rank == 0:
+        from ctrl_adapter_amd import ops
         reps = 3
         with ops.Profiler() as prof:
             for _ in range(reps):
                 step()
-        kernels = {}
         for k, v in prof.rows.items():
             ms = v[0] / reps
             kernels[k] = {"ms_per_step": round(ms, 4), "launches_per_step": v[1] // reps,
                           "tflops": round(v[2] / reps / (ms * 1e-3) / 1e12, 1) if v[2] else None,
                           "gbs": round(v[3] / reps / (ms * 1e-3) / 1e9, 1) if v[3] else None}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        kd, raw = kernels[dom], prof.rows[dom]
-        # HBM traffic per launch of that class: PMC FETCH_SIZE/WRITE_SIZE passes of this same command, measured with
-        # rocprofv3 (cannot run inside the benchmark), corrected per MI355X_MICROARCH.md, committed under profiles/
-        traffic = None
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")))      # latest round / version
-        tfile = tfiles[-1] if tfiles else ""
-        if workload == "sdxl" and n == 8 and tfile:
-            with open(tfile) as fh:
-                traffic = json.load(fh)["classes"].get(dom, {}).get("hbm_bytes_per_launch_corrected")
-        if raw[2] > 0:      # MFMA-bound class (implicit GEMM / flash attention): algorithmic FLOPs / HIP-event time
-            roof = {"kernel": dom, "bound": "mfma", "achieved": kd["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(kd["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "flops_per_launch": raw[2] / raw[1], "avg_launch_ms": raw[0] / raw[1], "launches_per_step": kd["launches_per_step"]}
-        else:
-            roof = {"kernel": dom, "bound": "hbm", "achieved": kd["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kd["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": raw[3] / raw[1], "avg_launch_ms": raw[0] / raw[1], "launches_per_step": kd["launches_per_step"]}
+        rows = prof.per_kernel(reps)
+        order = sorted(rows, key=lambda k: -rows[k]["ms_per_step"])
+        for k in order:
+            r = rows[k]
+            if r["tflops"]:      # MFMA kernels: algorithmic FLOPs / HIP-event time vs the dense MFMA peak
+                bound, ach, peak = "mfma", r["tflops"], MFMA_PEAK_TFLOPS
+            elif r["gbs"]:       # streaming kernels: algorithmic bytes / time vs the HBM peak
+                bound, ach, peak = "hbm", r["gbs"], HBM_PEAK_GBS
+            else:
+                bound, ach, peak = None, None, None
+            per_kernel.append({"kernel": k, "class": r["tag"], "launches_per_step": round(r["launches_per_step"], 2),
+                               "ms_per_step": round(r["ms_per_step"], 4), "avg_launch_ms": round(r["avg_launch_ms"], 5),
+                               "bound": bound, "achieved": round(ach, 1) if ach else None,
+                               "frac": round(ach / peak, 4) if ach else None, "grid": r["grid"]})
+        dom = next((k for k in order if rows[k]["tflops"] or rows[k]["gbs"]), None)
+        if dom is not None:
+            r = rows[dom]
+            traffic, tsrc = pmc_traffic_for(r)
+            if r["tflops"]:
+                roof = {"kernel": dom, "bound": "mfma", "achieved": round(r["tflops"], 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(r["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "flops_per_launch": r["flops_per_launch"], "algorithmic_bytes_per_launch": r["bytes_per_launch"],
+                        "avg_launch_ms": r["avg_launch_ms"], "launches_per_step": r["launches_per_step"],
+                        "ms_per_step": round(r["ms_per_step"], 4)}
+            else:
+                roof = {"kernel": dom, "bound": "hbm", "achieved": round(r["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(r["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "bytes_per_launch": r["bytes_per_launch"], "avg_launch_ms": r["avg_launch_ms"],
+                        "launches_per_step": r["launches_per_step"], "ms_per_step": round(r["ms_per_step"], 4)}
 
-    # ---- cpu_baseline leg: the fp32 oracle on the host cores, bounded sample (rank 0, N=1 only) ----
+    # ---- cpu_baseline leg: the fp32 oracle on the host cores, the whole step of this workload (rank 0, N=1 only) ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and workload == "sdxl":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import cases  # noqa: F401
         from oracle.init import seeded_init
         from oracle.controlnet import ControlNetOracle
         from oracle.adapter import ControlNetAdapterOracle
+        from oracle.router import RouterOracle, merge_inference
         cores = min(os.cpu_count() or 1, 32)        # more threads than this slow the fp32 oracle down (NUMA / oversubscription)
         torch.set_num_threads(cores)
-        oc = seeded_init(ControlNetOracle(cross_attention_dim=768).eval(), seed=11)
-        oa = seeded_init(ControlNetAdapterOracle(**SDXL_ADAPTER).eval(), seed=22)
-        xc = {k: v[:1].float().cpu() for k, v in x.items()}
+        ocs = [seeded_init(ControlNetOracle(cross_attention_dim=768).eval(), seed=11 + 100 * k) for k in range(w["n_cn"])]
+        oa = seeded_init(ControlNetAdapterOracle(**w["adapter"]).eval(), seed=22)
+        orr = seeded_init(RouterOracle(num_experts=w["n_cn"], router_type="simple_weights", num_routers=12).eval(), seed=44) if w["n_cn"] > 1 else None
+        xc = {k: v.float().cpu() for k, v in x.items()}
+        tc = torch.tensor(499.0)
 
         def cpu_step():
             s = torch.nn.functional.adaptive_avg_pool2d(xc["latents"], (64, 64))
-            d, m = oc(s, torch.tensor(499.0), xc["ehs_c"], xc["cond"])
-            return oa(d, num_frames=1, timestep=torch.tensor(499.0), encoder_hidden_states=xc["ehs_a"])
+            outs = [oc(s, tc, xc["ehs_c"], xc["cond%d" % k], skip_conv_in=w["skip_conv_in"]) for k, oc in enumerate(ocs)]
+            if orr is None:
+                d, m = outs[0]
+            else:
+                dw, mw = orr(sparse_mask=masks)
+                d, m = merge_inference([o[0] for o in outs], [o[1] for o in outs], dw, mw, masks, nf)
+            return oa(d, mid_block_res_sample=m if w["video"] else None, num_frames=nf, timestep=tc, encoder_hidden_states=xc["ehs_a"])
+        cpu_step()                                  # warm-up
+        reps = 3
         c0 = time.perf_counter()
-        reps = 4                                    # bounded sample: one image of the batch, ~10-15 s of CPU work
         for _ in range(reps):
             cpu_step()
-        per_img = (time.perf_counter() - c0) / reps
-        cpu = {"value": round(1.0 / (per_img * n), 5), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-               "sample": "1 image of the batch of %d (1/%d step) x %d reps, fp32 PyTorch oracle; value = 1/(%d x %.2f s)"
-                         % (n, n, reps, n, per_img)}
+        per_step = (time.perf_counter() - c0) / reps
+        cpu = {"value": round(1.0 / per_step, 5), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+               "sample": "the whole step of this workload (N=%d), 1 warm-up + %d repetitions, fp32 PyTorch oracle on %d threads: "
+                         "%.2f s per step" % (n, reps, cores, per_step)}
 
     if rank == 0:
-        flops_step = (0.2835 + 2.258) * 1e12 * n if workload == "sdxl" else None
+        flops_step = step_flops(w, n)
         line = {
-            "metric": "denoise-steps/s (ControlNet+adapter fwd) SDXL 1024^2 b=8" if workload == "sdxl"
-                      else "denoise-steps/s (ControlNet+adapter fwd) SVD 16-frame clip (CFG pair, 32 frames)",
-            "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": w["metric"], "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
             "dtype": "f16",    # MFMA operands fp16; fp32 accumulate / statistics / softmax / residual streams
             "data": "synthetic latents, prompts, condition images; seeded random weights",
-            "config": {"workload": "SDXL depth 1024^2 batch=8 per GPU (N=8 images enter ControlNet+adapter, no CFG doubling); "
-                                   "pool->ControlNet(SD1.5, 64x64 latents, 512^2 cond)->Ctrl-Adapter(A,B,C x3, up x2)"
-                                   if workload == "sdxl" else "SVD depth, 16 frames, CFG pair (N=32 frames), skip_conv_in",
-                       "batch_per_gpu": n, "parallelism": "dp%d (images sharded, no collective)" % world, "launch": mode,
+            "config": {"workload": (w["what"] % (n, n)) if "%d" in w["what"] else w["what"], "baseline_config": w["config"],
+                       "batch_per_gpu": n, "parallelism": "dp%d (images / whole clips sharded, no collective)" % world, "launch": mode,
                        "call_form": "controlnet(...) ; adapter(...)" if not args.fused else
                                     "controlled_step(controlnet, adapter, ...) = both forwards, overlapped (bit-identical results)"},
-            "algorithmic_tflop_per_step": round(flops_step / 1e12, 2) if flops_step else None,
-            "mfma_frac_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if flops_step else None,
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
+            "mfma_frac_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "per_kernel": per_kernel,
         }
         print(json.dumps(line))
-    if dist is not None:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -69,9 +69,10 @@ class AdapterConfig(C.Structure):
 
 
 # every symbol include/ctrl_hip.h declares (tests check the library exports all of them)
-ABI_VERSION = 2       # CTRL_ABI_VERSION of include/ctrl_hip.h
+ABI_VERSION = 3       # CTRL_ABI_VERSION of include/ctrl_hip.h
 EXPORTS = [
     "ctrl_abi_version", "ctrl_last_error", "ctrl_prof_begin", "ctrl_prof_end", "ctrl_prof_count", "ctrl_prof_get",
+    "ctrl_prof_launch_count", "ctrl_prof_launch_get",
     "ctrl_op_igemm", "ctrl_op_flash_attn", "ctrl_op_temporal_attn", "ctrl_op_gn_stats_floats", "ctrl_op_gn_stats", "ctrl_op_gn_apply",
     "ctrl_op_layernorm", "ctrl_op_nchw_to_nhwc", "ctrl_op_nhwc_to_nchw", "ctrl_avgpool_nchw",
     "ctrl_op_timestep_sincos", "ctrl_op_linear_small", "ctrl_op_blend", "ctrl_op_add_rowvec",

@@ -291,7 +291,8 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32), pairs = a.B * a.heads;
     dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
     PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
-    prof_detail("B%d h%d D%d Lq%d Lk%d nw%d", a.B, a.heads, a.D, a.Lq, a.Lk, NW);
+    prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
+    prof_symbol("flash_attn_kernel<%d, %d, %s>", D, NW, BATCH ? "true" : "false");
     LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH>), grid, dim3(NW * 64), smem, s, a, zeros);
     return 0;
 }
@@ -415,6 +416,7 @@ int op_temporal_attn(const TAttnArgs& a, hipStream_t s) {
     CTRL_CHECK(nitems > 0, "temporal_attn: empty problem");
     dim3 grid((unsigned)((nitems + 3) / 4));
     PROF_WORK(4.0 * nitems * a.F * a.F * 64, 2.0 * 4.0 * nitems * a.F * 64);
+    prof_detail("clips%d F%d HW%d heads%d", a.Bc, a.F, a.HW, a.heads);
     if (a.F <= 16) LAUNCH("temporal_attn", temporal_attn_kernel<16>, grid, dim3(256), 0, s, a);
     else LAUNCH("temporal_attn", temporal_attn_kernel<32>, grid, dim3(256), 0, s, a);
     return 0;

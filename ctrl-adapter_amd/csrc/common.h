@@ -39,16 +39,18 @@ inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d
 const void* device_zero_page();
 
 // ---- per-kernel-class event profiler (used by bench.py's roofline leg) ----
-void prof_before(const char* tag, hipStream_t s);
+void prof_before(const char* tag, const char* kern_expr, long grid_threads, hipStream_t s);
 void prof_after(hipStream_t s);
 extern bool g_prof_on;
 extern double g_prof_flops, g_prof_bytes;     // algorithmic work of the NEXT launch (set by the op, consumed by prof_before)
 #define PROF_WORK(flops, bytes) do { if (g_prof_on) { g_prof_flops = (double)(flops); g_prof_bytes = (double)(bytes); } } while (0)
 void prof_detail(const char* fmt, ...);       // optional per-launch shape note (dumped when CTRL_PROF_DUMP=<file> is set)
+void prof_symbol(const char* fmt, ...);       // kernel symbol with its template arguments, as rocprofv3 prints it (default: the launch expression)
 
 #define LAUNCH(tag, kern, grid, block, shmem, stream, ...)                        \
     do {                                                                          \
-        if (g_prof_on) prof_before(tag, stream);                                  \
+        if (g_prof_on) { const dim3 g_ = (grid), b_ = (block);                    \
+            prof_before(tag, #kern, (long)g_.x * g_.y * g_.z * b_.x * b_.y * b_.z, stream); } \
         hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);        \
         if (g_prof_on) prof_after(stream);                                        \
         hipError_t le_ = hipGetLastError();                                       \

@@ -621,6 +621,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     PROF_WORK(2.0 * a.M * a.Nout * a.Ktot, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     prof_detail("M%d N%d K%d taps%d tile%dx%dx%d swap%d geglu%d", a.M, a.Nout, a.Ktot, a.taps, BM, BN, BK, (int)SWAP, a.geglu);
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
+    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
     if (splitk > 1) {
         // partial sums go to fp32 slabs [splitk][M][Nout]; every epilogue term is applied once, by the finish kernel
         IGemmArgs p = a;
@@ -629,15 +630,18 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         p.nseg = 1;
         p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
         prof_detail("M%d N%d K%d taps%d tile%dx%dx%d splitk%d", a.M, a.Nout, a.Ktot, a.taps, BM, BN, BK, splitk);
+        sym();
         LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn * splitk),
                dim3(WAVES_M * WAVES_N * 64), smem, s, p, ntm, ntn, zeros, splitk);
         const size_t total = (size_t)a.M * (a.Nout / 8);
         size_t blocks = (total + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         PROF_WORK(0, 4.0 * splitk * a.M * a.Nout);
+        prof_detail("M%d N%d splitk%d", a.M, a.Nout, splitk);
         LAUNCH("splitk_finish", splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)a.splitk_ws, splitk);
         return 0;
     }
+    sym();
     LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
            a, ntm, ntn, zeros, 1);
     return 0;

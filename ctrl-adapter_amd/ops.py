@@ -250,4 +250,29 @@ class Profiler:
         for i in range(lib.ctrl_prof_count()):
             L.check(lib.ctrl_prof_get(i, name, 64, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
             self.rows[name.value.decode()] = (ms.value, n.value, fl.value, by.value)
+        # per-launch records, in launch order: (class tag, kernel symbol, shape note, ms, flops, bytes, grid work-items)
+        self.launches = []
+        tag, sym, det = C.create_string_buffer(64), C.create_string_buffer(256), C.create_string_buffer(256)
+        grid = C.c_int64()
+        for i in range(lib.ctrl_prof_launch_count()):
+            L.check(lib.ctrl_prof_launch_get(i, tag, 64, sym, 256, det, 256, C.byref(ms), C.byref(fl), C.byref(by), C.byref(grid)))
+            self.launches.append((tag.value.decode(), sym.value.decode(), det.value.decode(), ms.value, fl.value, by.value, grid.value))
         return False
+
+    def per_kernel(self, reps=1):
+        """launches grouped by (kernel symbol, shape): {key: dict(tag, symbol, shape, launches_per_step, ms_per_step,
+        avg_launch_ms, flops_per_launch, bytes_per_launch, tflops, gbs, grid)} -- one row per template instantiation x shape"""
+        acc = {}
+        for tag, sym, det, ms, fl, by, grid in self.launches:
+            k = (sym, det)
+            a = acc.setdefault(k, dict(tag=tag, symbol=sym, shape=det, n=0, ms=0.0, flops=0.0, bytes=0.0, grid=grid))
+            a["n"] += 1; a["ms"] += ms; a["flops"] += fl; a["bytes"] += by
+        out = {}
+        for (sym, det), a in acc.items():
+            n, ms = a["n"], a["ms"]
+            out[(sym + " " + det).strip()] = dict(
+                tag=a["tag"], symbol=sym, shape=det, launches_per_step=n / reps, ms_per_step=ms / reps, avg_launch_ms=ms / n,
+                flops_per_launch=a["flops"] / n, bytes_per_launch=a["bytes"] / n, grid=a["grid"],
+                tflops=(a["flops"] / (ms * 1e-3) / 1e12) if a["flops"] and ms > 0 else None,
+                gbs=(a["bytes"] / (ms * 1e-3) / 1e9) if a["bytes"] and ms > 0 else None)
+        return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTRL_ABI_VERSION 2
+#define CTRL_ABI_VERSION 3
 
 /* element types of boundary tensors */
 enum { CTRL_F32 = 0, CTRL_F16 = 1, CTRL_BF16 = 2 };
@@ -41,6 +41,12 @@ int ctrl_prof_end(void);
 int ctrl_prof_count(void);
 /* flops / bytes: ALGORITHMIC work summed over the class's launches (2*M*N*K, 4*B*h*Lq*Lk*D, one read + one write, ...) */
 int ctrl_prof_get(int i, char* name, int name_len, double* total_ms, int* launches, double* flops, double* bytes);
+/* per-launch records of the last finished profile, in launch order: kernel class tag, kernel symbol with template
+   arguments (as rocprofv3 prints it), shape note, HIP-event time on the launch stream, algorithmic work, grid size in
+   work-items (= rocprofv3's Grid_Size, which tells the shapes of one symbol apart) */
+int ctrl_prof_launch_count(void);
+int ctrl_prof_launch_get(int i, char* tag, int tag_len, char* symbol, int symbol_len, char* detail, int detail_len,
+                         double* ms, double* flops, double* bytes, int64_t* grid_threads);
 
 /* ---------------------------------------------------------------- op level */
 typedef struct ctrl_igemm_seg {

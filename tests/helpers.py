@@ -27,4 +27,9 @@ def check_digest(t, d, tol, what=""):
     # whole-tensor check through the abs-sum (catches errors outside the sampled positions)
     rel_sum = abs(float(flat.double().abs().sum()) - d["abssum"]) / max(d["abssum"], 1e-12)
     assert rel_sum <= max(tol, 1e-6) * 2, "%s: abs-sum differs by %.3e" % (what, rel_sum)
+    if "full" in d:
+        # the whole tensor is stored: element-by-element rel-inf (supersedes the strided samples)
+        full = d["full"].float()
+        err = max(err, ((t - full).abs().max().item()) / max(full.abs().max().item(), 1e-12))
+        assert err <= tol, "%s: rel_inf over the full tensor %.3e > %.1e" % (what, err, tol)
     return err

@@ -18,6 +18,7 @@ from oracle.init import seeded_init, seeded_tensor
 pytestmark = pytest.mark.gpu
 TOL = 1.5e-3          # ControlNet outputs (13 tensors, ~60 layers deep)
 TOL_ADAPTER = 1e-3    # the north-star bound on the adapter residuals (BASELINE.json)
+TOL_CHAIN = 1e-3      # ... also when the adapter is fed by the HIP ControlNet (the pipelines' own output)
 
 
 @pytest.fixture(scope="module")
@@ -380,3 +381,48 @@ def test_controlnet_nonsquare_single_image_golden(controlnet, gpu):
                            inp["controlnet_cond"].half().to(gpu), return_dict=False)
     errs = [check_digest(t, d, TOL, "controlnet[nonsquare] out %d" % i) for i, (t, d) in enumerate(zip(list(down) + [mid], g))]
     print("PARITY controlnet golden nonsquare 8x16 N=1 max rel_inf=%.3e" % max(errs))
+
+
+def test_video_chain_at_benched_shapes_vs_oracle(P, gpu):
+    """BASELINE.json configs 3 / 4 at the shapes bench.py times (`--workload svd16`): one CFG pair of a 16-frame clip,
+    N = 32 frames, 64x64 latents, 512x512 condition images, skip_conv_in (configs/svd_train_depth.yaml:59), video adapter
+    A-D + M with all four sub-modules, broadcast [1, 1, 1024] context -- against the fp32 CPU oracle.
+    Covers at size what the 8x8 goldens cannot: the 256x320-tile Conv3d (IG_TEMPORAL), the clip-wide GroupNorm over
+    65 536 rows (multi-chunk ticketed statistics), the AlphaBlender fold in the swapped epilogue at M = 131 072 and the
+    frame-axis attention at HW = 4096 (model/adapter_spatial_temporal.py:223-231,278-282)."""
+    from oracle.controlnet import ControlNetOracle
+    from oracle.adapter import ControlNetAdapterOracle
+    torch.set_grad_enabled(False)
+    F_, N = 16, 32
+    cfg = dict(cases.ADAPTER_VIDEO, backbone_model_name="svd", num_frames=F_)
+    lat = seeded_tensor((N, 4, 64, 64), 2001)
+    ehs_c = seeded_tensor((N, 77, 768), 2002)
+    cond = seeded_tensor((N, 3, 512, 512), 2003, kind="uniform")
+    e_img = seeded_tensor((1, 1, 1024), 2004)
+    t = torch.tensor(961.0)
+    cn = seeded_init(P.ControlNetModel(**cases.CONTROLNET_KW), seed=11).to(gpu)
+    ad = seeded_init(P.ControlNetAdapter(**cfg), seed=33).to(gpu)
+    d, m = cn(lat.half().to(gpu), t, ehs_c.half().to(gpu), cond.half().to(gpu), return_dict=False, skip_conv_in=True)
+    o, om = ad(d, mid_block_res_sample=m, num_frames=F_, timestep=t, encoder_hidden_states=e_img.half().to(gpu))
+    torch.cuda.synchronize()
+    oc = seeded_init(ControlNetOracle(**cases.CONTROLNET_KW).eval(), seed=11)
+    oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=33)
+    rd, rm = oc(lat, t, ehs_c, cond, skip_conv_in=True)
+    e_cn = [rel_inf(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm])]
+    print("PARITY svd16-shape controlnet (N=32, skip_conv_in) rel_inf: " + " ".join("%.2e" % e for e in e_cn))
+    # the adapter on IDENTICAL inputs (the north-star bound): both sides get the oracle's features, rounded to the fp16
+    # the pipelines hand over (svd/pipelines/svd_controlnet_adapter_pipeline.py:709)
+    rd16, rm16 = [x.half() for x in rd], rm.half()
+    o_same, om_same = ad([x.to(gpu) for x in rd16], mid_block_res_sample=rm16.to(gpu), num_frames=F_, timestep=t,
+                         encoder_hidden_states=e_img.half().to(gpu))
+    ro_same, rom_same = oa([x.float() for x in rd16], mid_block_res_sample=rm16.float(), num_frames=F_, timestep=t,
+                           encoder_hidden_states=e_img)
+    e_ad = [rel_inf(a, b) for a, b in zip(list(o_same) + [om_same], list(ro_same) + [rom_same])]
+    print("PARITY svd16-shape video adapter (same inputs) rel_inf: " + " ".join("%.2e" % e for e in e_ad))
+    del ro_same, rom_same, o_same, om_same
+    ro, rom = oa(rd, mid_block_res_sample=rm, num_frames=F_, timestep=t, encoder_hidden_states=e_img)
+    e_chain = [rel_inf(a, b) for a, b in zip(list(o) + [om], list(ro) + [rom])]
+    print("PARITY svd16-shape chain (HIP ControlNet -> HIP adapter vs oracle -> oracle) rel_inf: " + " ".join("%.2e" % e for e in e_chain))
+    assert o[0].shape == (N, 320, 64, 64) and om.shape == (N, 1280, 8, 8)
+    assert max(e_ad) <= TOL_ADAPTER
+    assert max(e_cn) <= TOL and max(e_chain) <= TOL_CHAIN

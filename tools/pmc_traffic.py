@@ -27,6 +27,36 @@ def kernel_class(name):
     return None
 
 
+def symbol_of(name):
+    """rocprofv3 kernel name (mangled or demangled) -> the symbol spelling the library's profiler / bench.py uses"""
+    m = re.search(r"igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
+    if m:
+        g = m.groups()
+        return "igemm_kernel<%s, %s, %s, %s, %s, %s, %s, %s>" % (g[:7] + ("true" if g[7] == "1" else "false",))
+    m = re.search(r"flash_attn_kernelILi(\d+)ELi(\d+)ELb([01])E", name)
+    if m:
+        return "flash_attn_kernel<%s, %s, %s>" % (m.group(1), m.group(2), "true" if m.group(3) == "1" else "false")
+    m = re.search(r"((?:igemm|flash_attn)_kernel<[^>]*>)", name)
+    if m:
+        return re.sub(r",\s*", ", ", m.group(1))
+    m = re.search(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+_kernel)", name) or re.search(r"([a-z0-9_]+_kernel)", name)
+    return m.group(1) if m else name
+
+
+def collect_kernels(directory, counter):
+    """per (symbol, grid size): grid size tells the shapes of one template instantiation apart"""
+    tot, launches = {}, {}
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter or kernel_class(row["Kernel_Name"]) is None:
+                    continue
+                k = "%s|%s" % (symbol_of(row["Kernel_Name"]), row["Grid_Size"])
+                tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"])
+                launches[k] = launches.get(k, 0) + 1
+    return tot, launches
+
+
 def collect(directory, counter):
     tot, launches = {}, {}
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
@@ -53,11 +83,20 @@ def main():
         tot = (2.0 * fkb + wkb) * 1024.0
         classes[cls] = {"launches_per_step": lps, "fetch_kb_per_step": round(fkb), "write_kb_per_step": round(wkb),
                         "hbm_bytes_per_step_corrected": round(tot), "hbm_bytes_per_launch_corrected": round(tot / lps)}
+    fk, fkl = collect_kernels(fetch_dir, "FETCH_SIZE")
+    wk, _ = collect_kernels(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(fk):
+        n = fkl[k]
+        tot = (2.0 * fk[k] + wk.get(k, 0.0)) * 1024.0
+        kernels[k] = {"launches_per_step": n / steps, "fetch_kb_per_launch": round(fk[k] / n), "write_kb_per_launch": round(wk.get(k, 0.0) / n),
+                      "hbm_bytes_per_launch_corrected": round(tot / n)}
     doc = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `CTRL_ADAPTER_LANES=1 python bench.py "
                     "--no-graph --no-cpu-baseline --steps 2 --warmup 1` (%d steps in total, one stream so that counters "
                     "attribute to one kernel at a time); FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM (gfx950 "
                     "reports 1/2 of coalesced 16-B streams); WRITE_SIZE taken as is" % steps,
            "classes": classes,
+           "kernels": kernels,       # key = "<symbol>|<grid size in work-items>" (bench.py's per_kernel rows carry both)
            "total_hbm_bytes_per_step_corrected": sum(c["hbm_bytes_per_step_corrected"] for c in classes.values())}
     with open(out, "w") as fh:
         json.dump(doc, fh, indent=1)
