@@ -26,6 +26,10 @@ int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream) {
     return op_gn_apply(x, x_dtype, stats, gamma, beta, H(y), imgs, rows_per_img, C, G, eps, silu, S(stream));
 }
+int ctrl_op_gn_apply_split(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
+                           int64_t ldy, int lo_off, int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream) {
+    return op_gn_apply(x, x_dtype, stats, gamma, beta, H(y), imgs, rows_per_img, C, G, eps, silu, S(stream), (long)ldy, lo_off);
+}
 int ctrl_op_layernorm(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                       int M, int C, float eps, void* stream) {
     return op_layernorm(x, x_dtype, ldx, gamma, beta, H(y), ldy, M, C, eps, S(stream));
@@ -58,6 +62,9 @@ int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const floa
 }
 int ctrl_op_pack_conv_w(const void* w, int dtype, void* out, int Cout, int Cin, int taps, void* stream) {
     return op_pack_conv_w(w, dtype, H(out), Cout, Cin, taps, S(stream));
+}
+int ctrl_op_pack_conv_w_dup(const void* w, int dtype, void* out, int Cout, int Cin, int taps, void* stream) {
+    return op_pack_conv_w_dup(w, dtype, H(out), Cout, Cin, taps, S(stream));
 }
 int ctrl_op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, void* stream) {
     return op_pack_conv_w_direct(w, dtype, out, Cout, Cin, S(stream));

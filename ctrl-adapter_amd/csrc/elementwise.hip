@@ -233,6 +233,18 @@ __global__ void pack_conv_w_kernel(const void* __restrict__ w, int dt, half_t* _
         out[i] = to_h_checked(load_as_f32(w, (co * Cin + ci) * taps + tp, dt), ovf);
     }
 }
+// split-operand convolution: [Cout][taps][2*Cin], out[co][tp][h*Cin + ci] = w[co][ci][tp] for h = 0, 1
+__global__ void pack_conv_w_dup_kernel(const void* __restrict__ w, int dt, half_t* __restrict__ out, int Cout, int Cin, int taps, int* ovf) {
+    const size_t total = (size_t)Cout * taps * 2 * Cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c2 = (int)(i % (2 * Cin));
+        const int ci = c2 >= Cin ? c2 - Cin : c2;
+        const size_t r = i / (2 * Cin);
+        const int tp = (int)(r % taps);
+        const size_t co = r / taps;
+        out[i] = to_h_checked(load_as_f32(w, (co * Cin + ci) * taps + tp, dt), ovf);
+    }
+}
 __global__ void pack_conv_w_direct_kernel(const void* __restrict__ w, int dt, float* __restrict__ out, int Cout, int Cin) {
     const size_t total = (size_t)9 * Cin * Cout;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -343,6 +355,10 @@ int op_router_softmax(const float* wg, const int* mask, float* out, int R, int E
 }
 int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s, int* ovf) {
     LAUNCH("pack", pack_conv_w_kernel, dim3(grid_for((size_t)Cout * Cin * taps)), dim3(256), 0, s, w, dtype, out, Cout, Cin, taps, ovf);
+    return 0;
+}
+int op_pack_conv_w_dup(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s, int* ovf) {
+    LAUNCH("pack", pack_conv_w_dup_kernel, dim3(grid_for((size_t)Cout * Cin * taps * 2)), dim3(256), 0, s, w, dtype, out, Cout, Cin, taps, ovf);
     return 0;
 }
 int op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, hipStream_t s) {

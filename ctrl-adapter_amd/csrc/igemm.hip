@@ -426,6 +426,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
 #pragma unroll
                     for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
                     *(h8*)((half_t*)a.out16 + (size_t)row * a.ld16 + ocol) = pk;
+                    if (a.out16_lo_off) {      // split operand: the rounding residual rides along (hi + lo == x to ~2^-22)
+                        h8 lo;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) lo[i] = (half_t)(x[i] - (float)pk[i]);
+                        *(h8*)((half_t*)a.out16 + (size_t)row * a.ld16 + a.out16_lo_off + ocol) = lo;
+                    }
                 }
                 int si = 0;
 #pragma unroll
@@ -594,6 +600,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmArgs a, const f
 #pragma unroll
             for (int j = 0; j < 8; ++j) pk[j] = (half_t)x[j];
             *(h8*)((half_t*)a.out16 + row * a.ld16 + col) = pk;
+            if (a.out16_lo_off) {
+                h8 lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) lo[j] = (half_t)(x[j] - (float)pk[j]);
+                *(h8*)((half_t*)a.out16 + row * a.ld16 + a.out16_lo_off + col) = lo;
+            }
         }
     }
 }
@@ -618,8 +630,10 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     const half_t* zeros = zero_page();
     CTRL_CHECK(zeros != nullptr, "igemm: could not allocate the zero page");
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
-    PROF_WORK(2.0 * a.M * a.Nout * a.Ktot, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
-    prof_detail("M%d N%d K%d taps%d tile%dx%dx%d swap%d geglu%d", a.M, a.Nout, a.Ktot, a.taps, BM, BN, BK, (int)SWAP, a.geglu);
+    // algorithmic work = the reference op's: a split operand doubles the K the kernel walks, not the FLOPs that count
+    const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
+    PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
+    prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
     const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
     if (splitk > 1) {
@@ -629,7 +643,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         p.blend_mix = nullptr; p.blend_x = nullptr;
         p.nseg = 1;
         p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
-        prof_detail("M%d N%d K%d taps%d tile%dx%dx%d splitk%d", a.M, a.Nout, a.Ktot, a.taps, BM, BN, BK, splitk);
+        prof_detail("M%d N%d K%d taps%d%s splitk%d", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
         sym();
         LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn * splitk),
                dim3(WAVES_M * WAVES_N * 64), smem, s, p, ntm, ntn, zeros, splitk);
@@ -662,7 +676,7 @@ bool can_swap(const IGemmArgs& a) {
                    (a.seg[i].col_begin % 8 == 0);
     }
     if (a.res) swap = swap && (a.ldres % 8 == 0) && (((uintptr_t)a.res & 15) == 0);
-    if (a.out16) swap = swap && (a.ld16 % 8 == 0) && (((uintptr_t)a.out16 & 15) == 0);
+    if (a.out16) swap = swap && (a.ld16 % 8 == 0) && (((uintptr_t)a.out16 & 15) == 0) && (a.out16_lo_off % 8 == 0);
     if (a.blend_mix) swap = swap && a.blend_x && (a.ld_blend % 8 == 0) && (((uintptr_t)a.blend_x & 15) == 0);
     if (a.bias) swap = swap && (((uintptr_t)a.bias & 15) == 0);
     if (a.rowvec) swap = swap && (a.rowvec_ld % 4 == 0) && (((uintptr_t)a.rowvec & 15) == 0);

@@ -131,7 +131,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        half_t* __restrict__ y, int rows, int C, int G, float eps,
-                                                       int silu, int rows_per_block) {
+                                                       int silu, int rows_per_block, long ldy, int lo_off) {
     const int tid = threadIdx.x;
     const int lpr = C >> 3;
     const int rpi = 256 / lpr;
@@ -154,18 +154,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         sc[j] = rstd * gamma[c];
         sf[j] = beta[c] - mean * sc[j];
     }
-    const size_t base = ((size_t)img * rows) * C + tc * 8;
-    const T* xp = x + base;
-    half_t* yp = y + base;
-    auto xform = [&](const float (&v)[8]) {
-        h8 o;
+    const T* xp = x + ((size_t)img * rows) * C + tc * 8;
+    half_t* yp = y + ((size_t)img * rows) * ldy + tc * 8;
+    // split operand (lo_off > 0): the row also carries lo = fp16(f - hi), so that hi + lo == f to ~2^-22
+    auto emit = [&](const float (&v)[8], half_t* dst) {
+        h8 o, l;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float f = v[j] * sc[j] + sf[j];
             if (silu) f = silu_f(f);
             o[j] = (half_t)f;
+            l[j] = (half_t)(f - (float)o[j]);
         }
-        return o;
+        *(h8*)dst = o;
+        if (lo_off) *(h8*)(dst + lo_off) = l;
     };
     int r = r0 + tr;
     for (; r + 3 * rpi < r1; r += 4 * rpi) {
@@ -173,12 +175,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) load8<T>(xp + (size_t)(r + u * rpi) * C, v[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *(h8*)(yp + (size_t)(r + u * rpi) * C) = xform(v[u]);
+        for (int u = 0; u < 4; ++u) emit(v[u], yp + (size_t)(r + u * rpi) * ldy);
     }
     for (; r < r1; r += rpi) {
         float v[8];
         load8<T>(xp + (size_t)r * C, v);
-        *(h8*)(yp + (size_t)r * C) = xform(v);
+        emit(v, yp + (size_t)r * ldy);
     }
 }
 
@@ -267,18 +269,20 @@ int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per
 }
 
 int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
-                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s) {
+                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s, long ldy, int lo_off) {
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_apply: C must be a multiple of 8 and of G, <= 2048");
+    if (ldy == 0) ldy = C;
+    CTRL_CHECK(ldy % 8 == 0 && lo_off % 8 == 0 && (lo_off == 0 || (lo_off >= C && lo_off + C <= ldy)), "gn_apply: bad split layout");
     const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 2048);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
     CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_apply: input must be fp16 or fp32");
-    PROF_WORK(0, (x_dtype == DT_F32 ? 6.0 : 4.0) * imgs * rows_per_img * C);
+    PROF_WORK(0, ((x_dtype == DT_F32 ? 6.0 : 4.0) + (lo_off ? 2.0 : 0.0)) * imgs * rows_per_img * C);
     if (x_dtype == DT_F32)
         LAUNCH("gn_apply", gn_apply_kernel<float>, dim3(chunks, imgs), dim3(256), 0, s,
-               (const float*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block);
+               (const float*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block, ldy, lo_off);
     else
         LAUNCH("gn_apply", gn_apply_kernel<half_t>, dim3(chunks, imgs), dim3(256), 0, s,
-               (const half_t*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block);
+               (const half_t*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block, ldy, lo_off);
     return 0;
 }
 

@@ -42,8 +42,10 @@ int op_temporal_attn(const TAttnArgs& a, hipStream_t s);
 size_t op_gn_stats_floats(int imgs, int rows_per_img, int C, int G);
 int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s);
 // y = (x-mean)*rstd*gamma+beta (optionally SiLU); x,y [imgs*rows][C]
+// ldy / lo_off: row stride of y (0 = C) and, when > 0, the column offset of the LOW half of a split operand
+// (y[r][c] = hi = fp16(v), y[r][lo_off + c] = fp16(v - hi)): consumed by a convolution packed with dup weights
 int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
-                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s);
+                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s, long ldy = 0, int lo_off = 0);
 // LayerNorm over the last dim of x [M][C] -> y fp16
 int op_layernorm(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
                  int M, int C, float eps, hipStream_t s);
@@ -89,6 +91,8 @@ int op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w,
 // conv weight [Cout][Cin][kh][kw] (any dtype) -> fp16 [Cout][kh*kw][Cin]   (taps-major K)
 int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s, int* ovf = nullptr);
 //   ovf (optional, device): set to 1 when a value does not fit fp16 (|w| > 65504, inf, nan)
+// split-operand form: fp16 [Cout][taps][2*Cin], the Cin weights of every tap twice
+int op_pack_conv_w_dup(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s, int* ovf = nullptr);
 // conv weight [Cout][Cin][3][3] -> fp32 [9][Cin][Cout] for the direct kernel
 int op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, hipStream_t s);
 // linear weight [N][K] -> fp16 [N][K]; optional GEGLU interleave of rows (N = 2*inner)

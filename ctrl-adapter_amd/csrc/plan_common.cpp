@@ -4,15 +4,15 @@
 #include "plan_common.h"
 
 // ------------------------------------------------------------------------------------------ builders
-int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w) {
+int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w, bool dup) {
     w->Cin = Cin; w->Cout = Cout;
     TRY(ps.norm(pre + ".norm1", Cin, &w->norm1));
-    TRY(ps.conv(pre + ".conv1", Cout, Cin, 3, false, &w->conv1));
+    TRY(ps.conv(pre + ".conv1", Cout, Cin, 3, false, &w->conv1, dup));
     // time_emb_proj is registered by the caller (batched across blocks) to keep state-dict order irrelevant
     TRY(ps.norm(pre + ".norm2", Cout, &w->norm2));
-    TRY(ps.conv(pre + ".conv2", Cout, Cout, 3, false, &w->conv2));
+    TRY(ps.conv(pre + ".conv2", Cout, Cout, 3, false, &w->conv2, dup));
     w->has_shortcut = force_shortcut || (Cin != Cout);
-    if (w->has_shortcut) TRY(ps.conv(pre + ".conv_shortcut", Cout, Cin, 1, false, &w->shortcut));
+    if (w->has_shortcut) TRY(ps.conv(pre + ".conv_shortcut", Cout, Cin, 1, false, &w->shortcut, dup));
     return 0;
 }
 
@@ -62,10 +62,10 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
 }
 
 // ------------------------------------------------------------------------------------------ runners
-int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu) {
+int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu, bool split) {
     float* st = cx.stats(op_gn_stats_floats(imgs, rows, n.C, 32));
     RUN(cx, op_gn_stats(x.p, x.dt, st, imgs, rows, n.C, 32, cx.s));
-    RUN(cx, op_gn_apply(x.p, x.dt, st, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s));
+    RUN(cx, op_gn_apply(x.p, x.dt, st, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s, split ? 2 * n.C : n.C, split ? n.C : 0));
     return 0;
 }
 
@@ -82,7 +82,7 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
     g.Hin = Hin; g.Win = Win; g.Hout = Hout; g.Wout = Wout; g.stride = o.stride; g.up = o.up;
     g.W = c.w; g.M = N * Hout * Wout; g.Nout = c.Cout; g.Ktot = c.taps * c.Cin;
     g.bias = c.b; g.rowvec = o.rowvec; g.rowvec_ld = o.rowvec_ld; g.rows_per_img = Hout * Wout;
-    g.scale = 1.f; g.act = o.act;
+    g.scale = 1.f; g.act = o.act; g.a_split = c.dup ? 1 : 0;
     set_res(g, o.res, c.Cout);
     set_out(g, y, c.Cout, c.Cout);
     const size_t mk = cx.mark();
@@ -114,17 +114,18 @@ int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int
                const float* temb_proj, int temb_ld, float eps) {
     const int Ho = H * up, Wo = W * up;
     const size_t m = cx.mark();
-    half_t* a = cx.h((size_t)N * H * W * w.Cin);
-    TRY(run_groupnorm(cx, w.norm1, x, a, N, H * W, eps, true));
+    half_t* a = cx.h((size_t)N * H * W * w.conv1.Cin);          // 2 x Cin wide for a split-operand conv1
+    TRY(run_groupnorm(cx, w.norm1, x, a, N, H * W, eps, true, w.conv1.dup));
     // conv1 output feeds only GroupNorm: keep it in the stream dtype (its statistics are taken from this copy)
     TV h1 = stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
     ConvOpts o1; o1.up = up; o1.rowvec = temb_proj; o1.rowvec_ld = temb_ld;
     TRY(run_conv(cx, w.conv1, a, h1, N, H, W, o1));
-    half_t* b = cx.h((size_t)N * Ho * Wo * w.Cout);
-    TRY(run_groupnorm(cx, w.norm2, h1, b, N, Ho * Wo, eps, true));
+    half_t* b = cx.h((size_t)N * Ho * Wo * w.conv2.Cin);
+    TRY(run_groupnorm(cx, w.norm2, h1, b, N, Ho * Wo, eps, true, w.conv2.dup));
     TV sc = x;
     if (w.has_shortcut) {
         CTRL_CHECK(cx.dry || x.m16 != nullptr, "resnet: the shortcut conv needs an fp16 copy of its input");
+        CTRL_CHECK((x.lo_off > 0) == w.shortcut.dup, "resnet: split-operand shortcut conv and its input mirror disagree");
         TV s2 = stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
         ConvOpts os; os.up = up;
         TRY(run_conv(cx, w.shortcut, x.m16, s2, N, H, W, os));

@@ -14,7 +14,9 @@
 
 // ------------------------------------------------------------------------------------------ packed params
 struct Lin { half_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; bool geglu = false; };
-struct ConvW { half_t* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, taps = 0; };
+// dup: split-operand convolution -- Cin is the K per tap the kernel walks (2 x the logical width: [hi | lo] halves of the
+// operand rows against the weights repeated twice), see ctrl_igemm_desc::a_split
+struct ConvW { half_t* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, taps = 0; bool dup = false; };
 struct ConvD { float* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0; };
 struct Norm { float* g = nullptr; float* b = nullptr; int C = 0; };
 
@@ -27,7 +29,7 @@ struct ParamSink {
     // several bias-free / biased linears with the same K concatenated along N (QKV, batched time projections)
     virtual int linear_cat(const std::vector<std::string>& names, const std::vector<int>& Ns, int K, bool bias, Lin* out) = 0;
     // nn.Conv2d(Cin, Cout, k) for the implicit GEMM: k = 1 | 3 ; nn.Conv3d (3,1,1) when temporal
-    virtual int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW* out) = 0;
+    virtual int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW* out, bool dup = false) = 0;
     // nn.Conv2d(Cin, Cout, 3) for the direct small-channel kernel
     virtual int conv_direct(const std::string& name, int Cout, int Cin, ConvD* out) = 0;
     virtual int norm(const std::string& name, int C, Norm* out) = 0;
@@ -47,7 +49,7 @@ struct SpecCollector : ParamSink {
         for (size_t i = 0; i < names.size(); ++i) linear(names[i], Ns[i], K, bias, false, nullptr);
         return 0;
     }
-    int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW*) override {
+    int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW*, bool) override {
         if (temporal) entries.push_back({name + ".weight", {Cout, Cin, 3, 1, 1}});
         else entries.push_back({name + ".weight", {Cout, Cin, k, k}});
         entries.push_back({name + ".bias", {Cout}});
@@ -152,16 +154,17 @@ struct Packer : ParamSink {
         out->N = Ntot; out->K = K; out->geglu = false;
         return 0;
     }
-    int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW* out) override {
+    int conv(const std::string& name, int Cout, int Cin, int k, bool temporal, ConvW* out, bool dup) override {
         const ctrl_tensor_ref* t;
         const int taps = temporal ? 3 : k * k;
         if (temporal) TRY(get(name + ".weight", {Cout, Cin, 3, 1, 1}, &t));
         else TRY(get(name + ".weight", {Cout, Cin, k, k}, &t));
-        TRY(dalloc((size_t)Cout * Cin * taps * sizeof(half_t), (void**)&out->w));
-        TRY(op_pack_conv_w(t->data, t->dtype, out->w, Cout, Cin, taps, s, ovf_flag()));
+        TRY(dalloc((size_t)Cout * Cin * taps * (dup ? 2 : 1) * sizeof(half_t), (void**)&out->w));
+        if (dup) TRY(op_pack_conv_w_dup(t->data, t->dtype, out->w, Cout, Cin, taps, s, ovf_flag()));
+        else TRY(op_pack_conv_w(t->data, t->dtype, out->w, Cout, Cin, taps, s, ovf_flag()));
         TRY(dalloc((size_t)Cout * sizeof(float), (void**)&out->b));
         TRY(vec(name + ".bias", Cout, false, out->b));
-        out->Cout = Cout; out->Cin = Cin; out->taps = taps;
+        out->Cout = Cout; out->Cin = dup ? 2 * Cin : Cin; out->taps = taps; out->dup = dup;
         return 0;
     }
     int conv_direct(const std::string& name, int Cout, int Cin, ConvD* out) override {
@@ -264,6 +267,7 @@ struct Ctx {
     hipStream_t s;
     bool dry;
     bool f32stream = true;     // residual streams kept in fp32 (set from CTRL_STREAM_F32, default on)
+    bool split = false;        // GEMM-operand mirrors of the streams are split [hi | lo] rows (ControlNet, CTRL_CN_SPLIT)
     // pooled GroupNorm statistics (zeroed once per forward with a single memset)
     float* stats_base = nullptr;
     size_t stats_off = 0, stats_total = 0;
@@ -319,7 +323,7 @@ struct TemporalTBW {        // TemporalBasicTransformerBlock
     int dim = 0, cross = 0;
 };
 
-int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w);
+int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w, bool dup = false);
 int build_attn_self(ParamSink& ps, const std::string& pre, int dim, int heads, int D, AttnW* w);
 int build_attn_cross(ParamSink& ps, const std::string& pre, int dim, int cross, int heads, int D, AttnW* w);
 int build_basic_tb(ParamSink& ps, const std::string& pre, int dim, int heads, int D, int cross, BasicTBW* w);
@@ -340,6 +344,7 @@ struct TV {
     void* p = nullptr;
     int dt = DT_F16;
     half_t* m16 = nullptr;
+    int lo_off = 0;      // > 0: m16 rows are [hi | lo] (2 x the width), lo at this column offset (split operand)
     bool ok() const { return p != nullptr; }
 };
 inline TV tv16(const half_t* x) { TV t; t.p = (void*)x; t.dt = DT_F16; t.m16 = (half_t*)x; return t; }
@@ -353,11 +358,19 @@ inline TV stream_alloc(Ctx& cx, size_t n, bool need16) {
     }
     return t;
 }
+// stream tensor [rows][C] whose GEMM-operand mirror is a split [hi | lo] row pair when the context asks for it
+inline TV stream_alloc_rc(Ctx& cx, size_t rows, int C, bool need16) {
+    if (!(cx.split && cx.f32stream && need16)) return stream_alloc(cx, rows * C, need16);
+    TV t;
+    t.p = cx.f(rows * C); t.dt = DT_F32;
+    t.m16 = cx.h(rows * C * 2); t.lo_off = C;
+    return t;
+}
 inline void set_out(IGemmArgs& g, const TV& out, long ld, int ncols) {
     g.nseg = 1;
     g.seg[0] = IGemmSeg{out.p, ld, 0, ncols, SEG_ROW, out.dt, 1, 0};
-    g.out16 = nullptr; g.ld16 = 0;
-    if (out.dt == DT_F32 && out.m16) { g.out16 = out.m16; g.ld16 = ld; }
+    g.out16 = nullptr; g.ld16 = 0; g.out16_lo_off = 0;
+    if (out.dt == DT_F32 && out.m16) { g.out16 = out.m16; g.ld16 = out.lo_off ? 2 * ld : ld; g.out16_lo_off = out.lo_off; }
 }
 inline void set_res(IGemmArgs& g, const TV& res, long ld) {
     g.res = res.p; g.ldres = ld; g.res_f32 = (res.ok() && res.dt == DT_F32) ? 1 : 0;
@@ -370,7 +383,8 @@ inline void set_blend(IGemmArgs& g, const float* mix, const TV& other, long ld) 
 
 // ------------------------------------------------------------------------------------------ block runners
 // y = GroupNorm(x) (optional SiLU);  x [imgs*rows][C] fp16 or fp32 stream, y fp16
-int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu);
+// split: y rows are [hi | lo] (2C wide), the operand of a dup-packed convolution
+int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu, bool split = false);
 // 3x3 / 1x1 conv through the implicit GEMM, NHWC fp16 operand -> NHWC stream tensor
 struct ConvOpts {
     int stride = 1, up = 1;

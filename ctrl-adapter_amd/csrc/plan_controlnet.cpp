@@ -37,19 +37,31 @@ struct ControlNetW {
     Norm mid_tnorm; ConvW mid_pin, mid_pout; BasicTBW mid_tb;
     std::vector<ConvW> zero_convs;      // 12 down + 1 mid
     int temb_total = 0;
+    // split-operand convolutions (CTRL_CN_SPLIT, default on): every convolution fed by a GroupNorm output or by the fp32
+    // residual stream takes its A operand as [hi | lo] fp16 halves, so the operand is exact to ~2^-22 instead of 2^-11.
+    // The ControlNet's ~25 residual branches otherwise accumulate the fp16 operand rounding to ~1e-3 rel-inf on its outputs
+    // (tools/experiments/fp16_error_budget.py), which the adapter chain inherits; costs 2 x the MFMA work of those convs.
+    bool split = true;
 };
 
+bool cn_split_enabled() {
+    const char* e = getenv("CTRL_CN_SPLIT");
+    return !(e && e[0] == '0') && stream_f32_enabled();
+}
+
 int build_transformer2d(ParamSink& ps, const std::string& pre, int C, int heads, int cross, Norm* n, ConvW* pin,
-                        ConvW* pout, BasicTBW* tb) {
+                        ConvW* pout, BasicTBW* tb, bool dup) {
     TRY(ps.norm(pre + ".norm", C, n));
-    TRY(ps.conv(pre + ".proj_in", C, C, 1, false, pin));
+    TRY(ps.conv(pre + ".proj_in", C, C, 1, false, pin, dup));
     TRY(build_basic_tb(ps, pre + ".transformer_blocks.0", C, heads, C / heads, cross, tb));
-    TRY(ps.conv(pre + ".proj_out", C, C, 1, false, pout));
+    TRY(ps.conv(pre + ".proj_out", C, C, 1, false, pout, dup));
     return 0;
 }
 
 int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW* w) {
     w->cfg = c;
+    w->split = cn_split_enabled();
+    const bool dup = w->split;
     const int c0 = c.block_out_channels[0], temb_dim = 4 * c0;
     CTRL_CHECK(c.in_channels == 4 || c.in_channels == 3, "controlnet: in_channels must be 3 or 4 (direct stem kernel)");
     CTRL_CHECK(c.conditioning_channels == 3 || c.conditioning_channels == 4, "controlnet: conditioning_channels must be 3 or 4");
@@ -97,7 +109,7 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
     std::vector<std::string> temb_names;
     std::vector<int> temb_ns;
     auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r) -> int {
-        TRY(build_resnet(ps, pre, Cin, Cout, false, r));
+        TRY(build_resnet(ps, pre, Cin, Cout, false, r, dup));
         r->temb_off = w->temb_total;
         w->temb_total += Cout;
         temb_names.push_back(pre + ".time_emb_proj");
@@ -119,13 +131,13 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
             TRY(add_resnet(pre + ".resnets." + std::to_string(j), j == 0 ? d.Cin : d.Cout, d.Cout, &d.resnets[j]));
             if (d.has_attn)
                 TRY(build_transformer2d(ps, pre + ".attentions." + std::to_string(j), d.Cout, c.num_attention_heads,
-                                        c.cross_attention_dim, &d.tnorm[j], &d.proj_in[j], &d.proj_out[j], &d.tb[j]));
+                                        c.cross_attention_dim, &d.tnorm[j], &d.proj_in[j], &d.proj_out[j], &d.tb[j], dup));
         }
-        if (d.has_down) TRY(ps.conv(pre + ".downsamplers.0.conv", d.Cout, d.Cout, 3, false, &d.down));
+        if (d.has_down) TRY(ps.conv(pre + ".downsamplers.0.conv", d.Cout, d.Cout, 3, false, &d.down, dup));
     }
     TRY(add_resnet("mid_block.resnets.0", out_c, out_c, &w->mid_r0));
     TRY(build_transformer2d(ps, "mid_block.attentions.0", out_c, c.num_attention_heads, c.cross_attention_dim,
-                            &w->mid_tnorm, &w->mid_pin, &w->mid_pout, &w->mid_tb));
+                            &w->mid_tnorm, &w->mid_pin, &w->mid_pout, &w->mid_tb, dup));
     TRY(add_resnet("mid_block.resnets.1", out_c, out_c, &w->mid_r1));
     TRY(ps.linear_cat(temb_names, temb_ns, temb_dim, true, &w->temb_cat));
 
@@ -135,8 +147,8 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
         for (int j = 0; j < c.layers_per_block + (i != 3 ? 1 : 0); ++j) slot_c.push_back(c.block_out_channels[i]);
     w->zero_convs.resize(slot_c.size() + 1);
     for (size_t i = 0; i < slot_c.size(); ++i)
-        TRY(ps.conv("controlnet_down_blocks." + std::to_string(i), slot_c[i], slot_c[i], 1, false, &w->zero_convs[i]));
-    TRY(ps.conv("controlnet_mid_block", out_c, out_c, 1, false, &w->zero_convs[slot_c.size()]));
+        TRY(ps.conv("controlnet_down_blocks." + std::to_string(i), slot_c[i], slot_c[i], 1, false, &w->zero_convs[i], dup));
+    TRY(ps.conv("controlnet_mid_block", out_c, out_c, 1, false, &w->zero_convs[slot_c.size()], dup));
     return 0;
 }
 
@@ -190,12 +202,12 @@ int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& po
                       const TV& out, int N, int H, int W, const EhsCtx& e) {
     const size_t mk = cx.mark();
     const int C = tn.C, M = N * H * W;
-    half_t* n = cx.h((size_t)M * C);
-    TRY(run_groupnorm(cx, tn, x, n, N, H * W, 1e-6f, false));
+    half_t* n = cx.h((size_t)M * pin.Cin);
+    TRY(run_groupnorm(cx, tn, x, n, N, H * W, 1e-6f, false, pin.dup));
     TV t0 = stream_alloc(cx, (size_t)M * C, false);
     ConvOpts o;
     TRY(run_conv(cx, pin, n, t0, N, H, W, o));
-    TV t1 = stream_alloc(cx, (size_t)M * C, true);      // its fp16 mirror is proj_out's operand
+    TV t1 = stream_alloc_rc(cx, (size_t)M, C, true);    // its fp16 mirror is proj_out's operand
     TRY(run_basic_tb(cx, tb, t0, t1, N, H * W, e));
     ConvOpts oo; oo.res = x;
     TRY(run_conv(cx, pout, t1.m16, out, N, H, W, oo));
@@ -229,7 +241,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
 
     // ---- 2. stem: conv_in(sample) (:802-807) ----
     const int H = a.Hs, W = a.Ws;
-    TV x = stream_alloc(cx, (size_t)N * H * W * c0, true);     // block input (also residual slot 0)
+    TV x = stream_alloc_rc(cx, (size_t)N * H * W, c0, true);   // block input (also residual slot 0)
     half_t* stem = nullptr;
     if (!(a.flags & CTRL_SKIP_CONV_IN)) {
         stem = cx.h((size_t)N * H * W * c0);
@@ -280,7 +292,8 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         const ConvW& z = w.zero_convs[i];
         const int HW = hh * ww;
         IGemmArgs g = {};
-        g.A = r.m16; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1;
+        CTRL_CHECK(cx.dry || (r.lo_off > 0) == z.dup, "controlnet: split-operand zero conv and its input mirror disagree");
+        g.A = r.m16; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1; g.a_split = z.dup ? 1 : 0;
         g.W = z.w; g.M = N * HW; g.Nout = z.Cout; g.Ktot = z.Cin; g.bias = z.b; g.scale = sc;
         g.nseg = 1;
         g.seg[0] = IGemmSeg{a.outs[i], HW, 0, z.Cout, SEG_TRANSPOSED, a.out_dt, HW, 0};
@@ -295,11 +308,11 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     for (int i = 0; i < 4; ++i) {
         const DownBlockW& d = w.down[i];
         for (size_t j = 0; j < d.resnets.size(); ++j) {
-            TV r = stream_alloc(cx, (size_t)N * h * wd * d.Cout, true);
+            TV r = stream_alloc_rc(cx, (size_t)N * h * wd, d.Cout, true);
             TRY(run_resnet(cx, d.resnets[j], cur, r, N, h, wd, 1, tproj + d.resnets[j].temb_off, w.temb_total, c.norm_eps));
             cur = r;
             if (d.has_attn) {
-                TV t = stream_alloc(cx, (size_t)N * h * wd * d.Cout, true);
+                TV t = stream_alloc_rc(cx, (size_t)N * h * wd, d.Cout, true);
                 TRY(run_transformer2d(cx, d.tnorm[j], d.proj_in[j], d.proj_out[j], d.tb[j], cur, t, N, h, wd, e));
                 cur = t;
             }
@@ -307,7 +320,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         }
         if (d.has_down) {
             const int ho = (h - 1) / 2 + 1, wo = (wd - 1) / 2 + 1;
-            TV y = stream_alloc(cx, (size_t)N * ho * wo * d.Cout, true);
+            TV y = stream_alloc_rc(cx, (size_t)N * ho * wo, d.Cout, true);
             ConvOpts o; o.stride = 2;
             TRY(run_conv(cx, d.down, cur.m16, y, N, h, wd, o));
             cur = y; h = ho; wd = wo;
@@ -317,11 +330,11 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     // ---- 4. mid block (:836-846) ----
     {
         const int C = c.block_out_channels[3];
-        TV m0 = stream_alloc(cx, (size_t)N * h * wd * C, true);
+        TV m0 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
         TRY(run_resnet(cx, w.mid_r0, cur, m0, N, h, wd, 1, tproj + w.mid_r0.temb_off, w.temb_total, c.norm_eps));
-        TV m1 = stream_alloc(cx, (size_t)N * h * wd * C, true);
+        TV m1 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
         TRY(run_transformer2d(cx, w.mid_tnorm, w.mid_pin, w.mid_pout, w.mid_tb, m0, m1, N, h, wd, e));
-        TV m2 = stream_alloc(cx, (size_t)N * h * wd * C, true);
+        TV m2 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
         TRY(run_resnet(cx, w.mid_r1, m1, m2, N, h, wd, 1, tproj + w.mid_r1.temb_off, w.temb_total, c.norm_eps));
         TRY(emit(m2, h, wd));
     }
@@ -405,11 +418,15 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
+    dry.split = h->w.split;
+    CTRL_CHECK(!dry.split || dry.f32stream, "controlnet_forward: the plan was built with split-operand convolutions "
+               "(CTRL_CN_SPLIT) and needs fp32 residual streams (CTRL_STREAM_F32 was switched off after create)");
     TRY(controlnet_run(dry, h->w, a));
     TRY(h->arena.ensure(workspace_bytes(dry)));
     h->arena.off = 0;
     Ctx cx{&h->arena, s, false};
     cx.f32stream = dry.f32stream;
+    cx.split = dry.split;
     cx.stats_total = dry.stats_total;
     TRY(controlnet_run(cx, h->w, a));
     if (keep && !reuse) { h->cond_N = N; h->cond_H = Hs; h->cond_W = Ws; }

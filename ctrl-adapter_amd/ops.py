@@ -26,6 +26,15 @@ def pack_conv_w(w):
     return out
 
 
+def pack_conv_w_dup(w):
+    """[Cout][Cin][kh][kw] -> fp16 [Cout][kh*kw][2*Cin] (split-operand convolution: every tap's weights twice)"""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    out = _f16(cout, taps * 2 * cin)
+    L.check(L.lib().ctrl_op_pack_conv_w_dup(L.ptr(w.contiguous()), L.dtype_code(w.dtype), L.ptr(out), cout, cin, taps, L.cur_stream()))
+    return out
+
+
 def pack_conv_w_direct(w):
     cout, cin = w.shape[0], w.shape[1]
     out = torch.empty(9, cin, cout, dtype=torch.float32, device=w.device)
@@ -48,7 +57,7 @@ def pack_vec(v, geglu=False):
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
           res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None,
-          blend_mix=None, blend_x=None, ld_blend=0):
+          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0):
     """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
@@ -73,6 +82,7 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.ld_blend = ld_blend
     d.blend_f32 = int(blend_x is not None and blend_x.dtype == torch.float32)
     d.scale = scale; d.geglu = int(geglu)
+    d.a_split = int(a_split); d.out16_lo_off = out16_lo_off
     d.nseg = len(segs)
     for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):
         d.seg[i].out = out.data_ptr(); d.seg[i].ld = ld; d.seg[i].col_begin = cb; d.seg[i].ncols = nc
@@ -140,6 +150,18 @@ def groupnorm(x, gamma, beta, imgs, rows_per_img, G=32, eps=1e-5, silu=False):
     L.check(lib.ctrl_op_gn_stats(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), imgs, rows_per_img, Cc, G, L.cur_stream()))
     L.check(lib.ctrl_op_gn_apply(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(y), imgs, rows_per_img, Cc, G,
                                  C.c_float(eps), int(silu), L.cur_stream()))
+    return y
+
+
+def groupnorm_split(x, gamma, beta, imgs, rows_per_img, G=32, eps=1e-5, silu=False):
+    """GroupNorm whose result is a split operand: [rows][2C] = [hi | lo], hi + lo == the fp32 result to ~2^-22"""
+    Cc = x.shape[-1]
+    lib = L.lib()
+    stats = torch.zeros(lib.ctrl_op_gn_stats_floats(imgs, rows_per_img, Cc, G), dtype=torch.float32, device=x.device)
+    y = torch.empty(tuple(x.shape[:-1]) + (2 * Cc,), dtype=torch.float16, device=x.device)
+    L.check(lib.ctrl_op_gn_stats(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), imgs, rows_per_img, Cc, G, L.cur_stream()))
+    L.check(lib.ctrl_op_gn_apply_split(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(y),
+                                       C.c_int64(2 * Cc), Cc, imgs, rows_per_img, Cc, G, C.c_float(eps), int(silu), L.cur_stream()))
     return y
 
 

@@ -81,12 +81,15 @@ typedef struct ctrl_igemm_desc {
     int32_t nseg;
     int32_t act;        /* 0 none, 1 SiLU applied after bias/rowvec (before residual) */
     int32_t res_f32;    /* residual is fp32 (the fp32 residual stream) */
-    int32_t pad3_;
+    int32_t a_split;    /* A rows hold [hi | lo] halves of an fp32 operand along Cin (lo = fp16(x - hi)) and W repeats every
+                           tap's Cin/2 weights twice: the product is exact in A to ~2^-22 at twice the MFMA work (used for
+                           the ControlNet's convolutions).  Only the algorithmic-FLOP accounting reads this flag. */
     void* splitk_ws; int64_t splitk_ws_bytes;   /* optional fp32 scratch: enables split-K for small-M / long-K problems */
     void* out16; int64_t ld16;   /* optional fp16 row-major mirror of the (single, row-major) output: GEMM-operand copy of an fp32 stream */
     /* optional AlphaBlender fold (diffusers AlphaBlender, model/adapter_spatial_temporal.py:229,282), row-major outputs
      * only: out = (1-a) * y + a * blend_x[m*ld_blend + n], a = sigmoid(*blend_mix), y = the epilogue result above */
-    const float* blend_mix; const void* blend_x; int64_t ld_blend; int32_t blend_f32; int32_t pad4_;
+    const float* blend_mix; const void* blend_x; int64_t ld_blend; int32_t blend_f32;
+    int32_t out16_lo_off;   /* > 0: the fp16 mirror is a split operand, out16[m*ld16 + n] = hi, out16[m*ld16 + out16_lo_off + n] = lo */
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
@@ -117,6 +120,9 @@ size_t ctrl_op_gn_stats_floats(int imgs, int rows_per_img, int C, int G);
 int ctrl_op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, void* stream);
 int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
+/* split-operand variant: y rows are [hi | lo] (row stride ldy, lo at column offset lo_off), hi + lo = the fp32 result to ~2^-22 */
+int ctrl_op_gn_apply_split(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
+                           int64_t ldy, int lo_off, int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
 int ctrl_op_layernorm(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                       int M, int C, float eps, void* stream);
 int ctrl_op_nchw_to_nhwc(const void* x, int dtype, void* y, int N, int C, int HW, void* stream);
@@ -133,6 +139,8 @@ int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const floa
                            int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, void* stream);
 /* load-time packers */
 int ctrl_op_pack_conv_w(const void* w, int dtype, void* out, int Cout, int Cin, int taps, void* stream);
+/* weights of a split-operand convolution: [Cout][taps][2*Cin], every tap's Cin weights twice (for the hi and the lo half) */
+int ctrl_op_pack_conv_w_dup(const void* w, int dtype, void* out, int Cout, int Cin, int taps, void* stream);
 int ctrl_op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Cin, void* stream);
 int ctrl_op_pack_linear_w(const void* w, int dtype, void* out, int N, int K, int geglu, void* stream);
 int ctrl_op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, void* stream);
