@@ -21,7 +21,7 @@ class IGemmSeg(C.Structure):
 class IGemmDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("mode", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32),
                 ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
-                ("stride", C.c_int32), ("up", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32), ("pad0_", C.c_int32),
+                ("stride", C.c_int32), ("up", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32), ("t_pad", C.c_int32),
                 ("W", C.c_void_p), ("M", C.c_int32), ("Nout", C.c_int32), ("Ktot", C.c_int32), ("pad1_", C.c_int32),
                 ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_ld", C.c_int32), ("rows_per_img", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int64), ("scale", C.c_float), ("geglu", C.c_int32),
@@ -41,9 +41,10 @@ class AttnDesc(C.Structure):
 
 
 class TAttnDesc(C.Structure):
-    _fields_ = [("QKV", C.c_void_p), ("ld", C.c_int64), ("O", C.c_void_p), ("ldo", C.c_int64),
+    _fields_ = [("Q", C.c_void_p), ("ld", C.c_int64), ("O", C.c_void_p), ("ldo", C.c_int64),
                 ("Bc", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32), ("heads", C.c_int32),
-                ("scale", C.c_float), ("pad0_", C.c_int32)]
+                ("scale", C.c_float), ("Fq", C.c_int32), ("KV", C.c_void_p), ("ldkv", C.c_int64),
+                ("Fl", C.c_int32), ("pad0_", C.c_int32)]
 
 
 class TensorRef(C.Structure):
@@ -68,6 +69,17 @@ class AdapterConfig(C.Structure):
                 ("loc_M", C.c_int32)]
 
 
+CB_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
+CB_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
+CB_HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
+
+
+class ClipComm(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+                ("all_gather", CB_GATHER), ("all_reduce_sum_f32", CB_REDUCE), ("halo_exchange", CB_HALO),
+                ("user", C.c_void_p), ("ws_needed", C.c_int64)]
+
+
 # every symbol include/ctrl_hip.h declares (tests check the library exports all of them)
 ABI_VERSION = 3       # CTRL_ABI_VERSION of include/ctrl_hip.h
 EXPORTS = [
@@ -82,7 +94,7 @@ EXPORTS = [
     "ctrl_controlnet_destroy", "ctrl_controlnet_forward",
     "ctrl_adapter_param_count", "ctrl_adapter_param_spec", "ctrl_adapter_create", "ctrl_adapter_destroy",
     "ctrl_adapter_forward",
-    "ctrl_adapter_forward_scatter",
+    "ctrl_adapter_forward_scatter", "ctrl_adapter_forward_clip_sharded",
     "ctrl_step_forward",
     "ctrl_router_weights", "ctrl_router_merge",
 ]

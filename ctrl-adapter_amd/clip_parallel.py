@@ -1,0 +1,201 @@
+"""One clip split across GPUs by frames (BASELINE.json config 4 with fewer clips than GPUs).
+
+Every rank holds F / world consecutive frames of every clip and runs the whole hot path on them; only the three frame-mixing
+ops of the adapter exchange data (include/ctrl_hip.h, ctrl_clip_comm):
+    temporal attention   all-gather of the K|V rows over the frame axis     (model/adapter_spatial_temporal.py:280)
+    Conv3d (3,1,1)       +-1-frame halo with the neighbour ranks            (TemporalResnetBlock, :226)
+    temporal GroupNorm   all-reduce of the 2 x 32 x clips partial sums      (TemporalResnetBlock, :226)
+The native side calls back into a *transport* with byte offsets into an exchange workspace the transport owns:
+
+    TorchDistTransport   torch.distributed: backend "nccl" (= RCCL over xGMI) on the GPUs, one process per GPU; "gloo" in
+                         the CPU tests of the transport itself.  Exchanges are enqueued on the current stream.
+    LoopbackTransport    `world` threads of ONE process (virtual ranks on one GPU): used by the single-GPU parity test
+                         that proves frame-sharded == unsharded results.
+
+Usage (per rank):  comm = TorchDistTransport(group=None);  adapter(down, mid, num_frames=F_local, ..., clip_comm=comm)
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from . import _lib as L
+
+
+def shard_frames(x, num_frames, rank, world):
+    """[(b f) ...] -> the rank's [(b f_local) ...] slice: frames [rank*Fl, (rank+1)*Fl) of every clip"""
+    n = x.shape[0]
+    if n % num_frames or num_frames % world:
+        raise ValueError("frames per clip (%d) must divide the batch (%d) and be a multiple of world (%d)" % (num_frames, n, world))
+    fl = num_frames // world
+    v = x.reshape(n // num_frames, num_frames, *x.shape[1:])[:, rank * fl:(rank + 1) * fl]
+    return v.reshape(-1, *x.shape[1:]).contiguous()
+
+
+def unshard_frames(parts, num_frames):
+    """inverse of shard_frames over the list of every rank's tensor (rank order)"""
+    world = len(parts)
+    fl = num_frames // world
+    b = parts[0].shape[0] // fl
+    return torch.cat([p.reshape(b, fl, *p.shape[1:]) for p in parts], dim=1).reshape(b * num_frames, *parts[0].shape[1:])
+
+
+class ClipTransport:
+    """Exchange workspace + the ctypes callbacks handed to ctrl_adapter_forward_clip_sharded."""
+
+    def __init__(self, rank, world, device):
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        self.ws = None
+        self.error = None
+        self._cb = (L.CB_GATHER(self._c_gather), L.CB_REDUCE(self._c_reduce), L.CB_HALO(self._c_halo))
+        self.ensure(1 << 20)
+
+    def ensure(self, nbytes):
+        if self.ws is None or self.ws.numel() < nbytes:
+            self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)     # torch allocations are >= 256-B aligned
+        return self.ws
+
+    def view(self, off, nbytes, dtype=torch.uint8):
+        return self.ws[off:off + nbytes].view(dtype)
+
+    def c_struct(self):
+        s = L.ClipComm()
+        s.rank, s.world = self.rank, self.world
+        s.ws, s.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        s.all_gather, s.all_reduce_sum_f32, s.halo_exchange = self._cb
+        s.user, s.ws_needed = None, 0
+        return s
+
+    # ---- C callbacks: never let an exception cross the C frame ----
+    def _guard(self, fn, *a):
+        try:
+            fn(*a)
+            return 0
+        except BaseException as e:      # noqa: BLE001 - reported to the caller of the forward
+            self.error = e
+            return 1
+
+    def _c_gather(self, user, send_off, recv_off, nbytes, stream):
+        return self._guard(self.all_gather, send_off, recv_off, nbytes)
+
+    def _c_reduce(self, user, off, count, stream):
+        return self._guard(self.all_reduce_sum_f32, off, count)
+
+    def _c_halo(self, user, sp, sn, rp, rn, nbytes, stream):
+        return self._guard(self.halo_exchange, sp, sn, rp, rn, nbytes)
+
+
+class TorchDistTransport(ClipTransport):
+    """torch.distributed transport: `group` = the ranks that share one clip (None = the default group)."""
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+        super().__init__(rank, world, device)
+
+    def _peer(self, r):
+        return self.dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def all_gather(self, send_off, recv_off, nbytes):
+        send = self.view(send_off, nbytes)
+        recv = self.view(recv_off, nbytes * self.world)
+        try:
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        except (RuntimeError, NotImplementedError):        # backends without the flat form
+            self.dist.all_gather([recv[r * nbytes:(r + 1) * nbytes] for r in range(self.world)], send, group=self.group)
+
+    def all_reduce_sum_f32(self, off, count):
+        self.dist.all_reduce(self.view(off, 4 * count, torch.float32), op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def halo_exchange(self, sp, sn, rp, rn, nbytes):
+        d, ops = self.dist, []
+        if self.rank > 0:
+            ops += [d.P2POp(d.isend, self.view(sp, nbytes), self._peer(self.rank - 1), self.group),
+                    d.P2POp(d.irecv, self.view(rp, nbytes), self._peer(self.rank - 1), self.group)]
+        if self.rank < self.world - 1:
+            ops += [d.P2POp(d.isend, self.view(sn, nbytes), self._peer(self.rank + 1), self.group),
+                    d.P2POp(d.irecv, self.view(rn, nbytes), self._peer(self.rank + 1), self.group)]
+        if ops:
+            for req in d.batch_isend_irecv(ops):
+                req.wait()            # nccl: orders the current stream behind the transfer (no host block)
+
+
+class LoopbackWorld:
+    """`world` virtual ranks = threads of this process; make one LoopbackTransport per thread with .transport(rank)."""
+
+    def __init__(self, world, device):
+        self.world, self.device = world, torch.device(device)
+        self.barrier = threading.Barrier(world, timeout=600)     # a failed rank must not hang the others
+        self.peers = [None] * world
+
+    def transport(self, rank):
+        t = LoopbackTransport(rank, self)
+        self.peers[rank] = t
+        return t
+
+
+class LoopbackTransport(ClipTransport):
+    def __init__(self, rank, lw):
+        self.lw = lw
+        super().__init__(rank, lw.world, lw.device)
+
+    def _sync(self):
+        if self.ws.is_cuda:
+            torch.cuda.current_stream(self.ws.device).synchronize()
+
+    def _rendezvous(self, copy):
+        self._sync()                     # my send buffers are complete
+        self.lw.barrier.wait()           # ... and so are everyone's
+        copy()
+        self._sync()
+        self.lw.barrier.wait()           # nobody re-uses a send buffer before every reader is done
+
+    def all_gather(self, send_off, recv_off, nbytes):
+        def copy():
+            for r, p in enumerate(self.lw.peers):
+                self.view(recv_off + r * nbytes, nbytes).copy_(p.view(send_off, nbytes))
+        self._rendezvous(copy)
+
+    def all_reduce_sum_f32(self, off, count):
+        def copy():
+            parts = [p.view(off, 4 * count, torch.float32).clone() for p in self.lw.peers]     # rank order: deterministic
+            self._tmp = sum(parts[1:], parts[0])
+        self._rendezvous(copy)
+        self.view(off, 4 * count, torch.float32).copy_(self._tmp)      # after the second barrier: every rank has read the inputs
+
+    def halo_exchange(self, sp, sn, rp, rn, nbytes):
+        def copy():
+            if self.rank > 0:
+                self.view(rp, nbytes).copy_(self.lw.peers[self.rank - 1].view(sn, nbytes))
+            if self.rank < self.world - 1:
+                self.view(rn, nbytes).copy_(self.lw.peers[self.rank + 1].view(sp, nbytes))
+        self._rendezvous(copy)
+
+
+def run_virtual_ranks(world, fn):
+    """runs fn(rank) on `world` threads (each with its own CUDA stream when a GPU is present); returns the results in rank
+    order and re-raises the first exception"""
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            if torch.cuda.is_available():
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    out[r] = fn(r)
+                    torch.cuda.current_stream().synchronize()
+            else:
+                out[r] = fn(r)
+        except BaseException as e:      # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out

@@ -301,42 +301,62 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
 // Temporal attention: sequence = frames (F <= 32), batch = clips x pixels, head_dim 64.
 // Replaces the Attention inside diffusers' TemporalBasicTransformerBlock (constructed
 // model/adapter_spatial_temporal.py:120-130, called :280) after its [bF,L,C] -> [b*L,F,C] reshape.
-// The F x F score matrix is tiny, so this kernel is HBM-bound: one wavefront per (clip, pixel, head)
-// reads q/k/v rows once (128-B contiguous head slices), keeps everything in registers and writes the
-// result back in the original frame-major layout (no materialised permute).
-//   lane l: frame f = l % F_PAD handles query f; the 64-dim dot products are done by the F lanes
-//   cooperatively via LDS-free shuffles is wasteful for F=16, so instead each lane owns (query f, 16-dim
-//   slice s): lanes = F_PAD(16) x 4 slices.
+// The F x F score matrix is tiny, so this kernel is HBM-bound: one wavefront per (clip, pixel, head) stages the K and V
+// head slices of all F key frames ONCE into a wave-private LDS area (16-byte coalesced loads, each byte fetched once),
+// then every lane = (query frame, 16-dim slice) reads the key / value slices from LDS (same-address broadcast) and
+// keeps the F scores in registers; the result goes back in the original frame-major layout (no materialised permute).
+// Q and K|V are addressed separately so that the same kernel serves a clip whose frames are sharded over GPUs
+// (SURVEY.md 8e): queries = the local frames, keys / values = the all-gathered K|V rows of every rank:
+//   Q  row (b*Fq + fq)*HW + p                       in Q  (ld),   head h at column h*64
+//   KV row ((r*Bc + b)*Fl + fl)*HW + p, r = kf / Fl in KV (ldkv), K at column h*64, V at column C + h*64
+// (unsharded: KV = Q + C, ldkv = ld, Fl = Fq = F).
 // ---------------------------------------------------------------------------------------------
 template <int FP>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs a) {
-    // work item = (clip b, pixel p, head h), one wavefront each.  Lane = (16-dim slice sl, query frame fl);
-    // FP = padded frame count (16 or 32): every loop over key frames is fully unrolled so the score
-    // vector stays in VGPRs (runtime-indexed arrays would spill to scratch).
+    __shared__ __attribute__((aligned(16))) half_t kv_s[4][2][FP][64];      // [wave][K|V][key frame][dim]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long item = (long)blockIdx.x * 4 + wave;
     const long nitems = (long)a.Bc * a.HW * a.heads;
-    if (item >= nitems) return;
-    const int h = (int)(item % a.heads);
-    const long bp = item / a.heads;
+    const bool live = item < nitems;
+    const long it = live ? item : 0;
+    const int h = (int)(it % a.heads);
+    const long bp = it / a.heads;
     const int p = (int)(bp % a.HW);
     const int b = (int)(bp / a.HW);
     const int C = a.heads * 64;
-    const int F = a.F;
-    const int sl = lane >> 4;          // 16-dim slice of the head
-    const int fl = lane & 15;          // query frame handled by this lane (within a pass)
+    const int F = a.F, Fq = a.Fq, Fl = a.Fl;
     const float c = a.scale * 1.4426950408889634f;
     const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- stage K and V of every key frame: FP rows x 8 chunks of 16 B each, one chunk per lane per pass ----
+#pragma unroll
+    for (int i = 0; i < (FP * 8 + 63) / 64; ++i) {
+        const int idx = i * 64 + lane;
+        const int kf = idx >> 3, c8 = idx & 7;
+        h8 kk = hzero, vv = hzero;
+        if (live && kf < F) {
+            const int r = kf / Fl, fl = kf - r * Fl;
+            const half_t* kp = (const half_t*)a.KV + (((size_t)(r * a.Bc + b) * Fl + fl) * a.HW + p) * a.ldkv + (size_t)h * 64 + c8 * 8;
+            kk = *(const h8*)kp;
+            vv = *(const h8*)(kp + C);
+        }
+        if (kf < FP) {
+            *(h8*)&kv_s[wave][0][kf][c8 * 8] = kk;
+            *(h8*)&kv_s[wave][1][kf][c8 * 8] = vv;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const int sl = lane >> 4;          // 16-dim slice of the head
+    const int fl_ = lane & 15;         // query frame handled by this lane (within a pass)
     const size_t col = (size_t)h * 64 + sl * 16;
-
 #pragma unroll
     for (int f0 = 0; f0 < FP; f0 += 16) {
-        if (f0 >= F) break;
-        const int fq = f0 + fl;
-        const bool qok = fq < F;
+        if (f0 >= Fq) break;
+        const int fq = f0 + fl_;
+        const bool qok = fq < Fq;
         h8 q0 = hzero, q1 = hzero;
         if (qok) {
-            const half_t* qp = (const half_t*)a.QKV + ((size_t)(b * F + fq) * a.HW + p) * a.ld + col;
+            const half_t* qp = (const half_t*)a.Q + ((size_t)(b * Fq + fq) * a.HW + p) * a.ld + col;
             q0 = *(const h8*)qp;
             q1 = *(const h8*)(qp + 8);
         }
@@ -346,8 +366,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs a) {
         for (int kf = 0; kf < FP; ++kf) {
             sc[kf] = -1e30f;
             if (kf < F) {
-                const half_t* kp = (const half_t*)a.QKV + ((size_t)(b * F + kf) * a.HW + p) * a.ld + C + col;
-                const h8 k0 = *(const h8*)kp, k1 = *(const h8*)(kp + 8);
+                const h8 k0 = *(const h8*)&kv_s[wave][0][kf][sl * 16], k1 = *(const h8*)&kv_s[wave][0][kf][sl * 16 + 8];
                 float d = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d += (float)q0[j] * (float)k0[j] + (float)q1[j] * (float)k1[j];
@@ -370,15 +389,14 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs a) {
 #pragma unroll
         for (int kf = 0; kf < FP; ++kf) {
             if (kf < F) {
-                const half_t* vp = (const half_t*)a.QKV + ((size_t)(b * F + kf) * a.HW + p) * a.ld + 2 * C + col;
-                const h8 v0 = *(const h8*)vp, v1 = *(const h8*)(vp + 8);
+                const h8 v0 = *(const h8*)&kv_s[wave][1][kf][sl * 16], v1 = *(const h8*)&kv_s[wave][1][kf][sl * 16 + 8];
                 const float w = sc[kf] * inv;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { acc[j] += w * (float)v0[j]; acc[8 + j] += w * (float)v1[j]; }
             }
         }
         if (qok) {
-            half_t* op = (half_t*)a.O + ((size_t)(b * F + fq) * a.HW + p) * a.ldo + col;
+            half_t* op = (half_t*)a.O + ((size_t)(b * Fq + fq) * a.HW + p) * a.ldo + col;
             h8 o0, o1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { o0[j] = (half_t)acc[j]; o1[j] = (half_t)acc[8 + j]; }
@@ -409,14 +427,20 @@ int op_flash_attn(const AttnArgs& a, hipStream_t s) {
     }
 }
 
-int op_temporal_attn(const TAttnArgs& a, hipStream_t s) {
-    CTRL_CHECK(a.F > 0 && a.F <= 32, "temporal_attn: F must be in 1..32");
-    CTRL_CHECK(a.ld % 8 == 0 && a.ldo % 8 == 0, "temporal_attn: leading dims must be multiples of 8");
+int op_temporal_attn(const TAttnArgs& a_in, hipStream_t s) {
+    TAttnArgs a = a_in;
+    // descriptor defaults of the unsharded form: queries = keys = all F frames, K|V in the same rows as Q
+    if (a.Fq <= 0) a.Fq = a.F;
+    if (a.Fl <= 0) a.Fl = a.F;
+    if (!a.KV) { a.KV = (const half_t*)a.Q + (size_t)a.heads * 64; a.ldkv = a.ld; }
+    CTRL_CHECK(a.F > 0 && a.F <= 32 && a.Fq <= a.F && a.F % a.Fl == 0, "temporal_attn: F must be in 1..32 (Fq <= F, Fl | F)");
+    CTRL_CHECK(a.ld % 8 == 0 && a.ldo % 8 == 0 && a.ldkv % 8 == 0, "temporal_attn: leading dims must be multiples of 8");
+    CTRL_CHECK((((uintptr_t)a.Q | (uintptr_t)a.KV | (uintptr_t)a.O) & 15) == 0, "temporal_attn: pointers must be 16-byte aligned");
     const long nitems = (long)a.Bc * a.HW * a.heads;
     CTRL_CHECK(nitems > 0, "temporal_attn: empty problem");
     dim3 grid((unsigned)((nitems + 3) / 4));
-    PROF_WORK(4.0 * nitems * a.F * a.F * 64, 2.0 * 4.0 * nitems * a.F * 64);
-    prof_detail("clips%d F%d HW%d heads%d", a.Bc, a.F, a.HW, a.heads);
+    PROF_WORK(4.0 * nitems * a.Fq * a.F * 64, 2.0 * nitems * 64 * (2.0 * a.Fq + 2.0 * a.F));
+    prof_detail("clips%d Fq%d F%d HW%d heads%d", a.Bc, a.Fq, a.F, a.HW, a.heads);
     if (a.F <= 16) LAUNCH("temporal_attn", temporal_attn_kernel<16>, grid, dim3(256), 0, s, a);
     else LAUNCH("temporal_attn", temporal_attn_kernel<32>, grid, dim3(256), 0, s, a);
     return 0;

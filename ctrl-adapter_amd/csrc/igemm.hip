@@ -93,8 +93,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
             a_y[i] = oy * a.stride - pad;
             a_x[i] = ox * a.stride - pad;
         } else {
-            a_off[i] = (size_t)mm * a.lda;
-            a_y[i] = (mm / a.HW) % a.F;
+            const int fr = mm / a.HW;
+            if (a.t_pad) {
+                // frame-sharded clip: A is the padded operand [clip][F + 2][HW][lda] whose frame slots 0 and F + 1 hold the
+                // neighbour ranks' halo frames (zeros at the clip's ends), so no tap is ever masked
+                a_off[i] = ((size_t)mm + (size_t)(2 * (fr / a.F) + 1) * a.HW) * a.lda;
+                a_y[i] = 1;
+            } else {
+                a_off[i] = (size_t)mm * a.lda;
+                a_y[i] = fr % a.F;
+            }
             a_x[i] = 0;
         }
     }
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs
                 off = (a_off[i] + (size_t)(ok ? sy : 0) * a.Win + (ok ? sx : 0)) * a.lda + c0 + a_c8[i];
             } else {
                 const int f = a_y[i] + tap - 1;
-                ok = ok && f >= 0 && f < a.F;
+                ok = ok && f >= 0 && f < (a.t_pad ? 3 : a.F);
                 off = a_off[i] + (ok ? (long)(tap - 1) * a.HW * a.lda : 0) + c0 + a_c8[i];
             }
             const half_t* src = ok ? (Aptr + off) : zeros;          // zero padding = load from a zero page

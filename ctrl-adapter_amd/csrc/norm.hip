@@ -131,7 +131,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        half_t* __restrict__ y, int rows, int C, int G, float eps,
-                                                       int silu, int rows_per_block, long ldy, int lo_off) {
+                                                       int silu, int rows_per_block, long ldy, int lo_off,
+                                                       float stat_rows, long y_img_rows, long y_row0) {
     const int tid = threadIdx.x;
     const int lpr = C >> 3;
     const int rpi = 256 / lpr;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
     const int cg = C / G;
-    const float inv_cnt = 1.0f / ((float)rows * (float)cg);
+    const float inv_cnt = 1.0f / (stat_rows * (float)cg);     // rows the statistics span (>= rows when frames are sharded)
     float sc[8], sf[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         sf[j] = beta[c] - mean * sc[j];
     }
     const T* xp = x + ((size_t)img * rows) * C + tc * 8;
-    half_t* yp = y + ((size_t)img * rows) * ldy + tc * 8;
+    half_t* yp = y + ((size_t)img * y_img_rows + y_row0) * ldy + tc * 8;
     // split operand (lo_off > 0): the row also carries lo = fp16(f - hi), so that hi + lo == f to ~2^-22
     auto emit = [&](const float (&v)[8], half_t* dst) {
         h8 o, l;
@@ -269,9 +270,13 @@ int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per
 }
 
 int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
-                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s, long ldy, int lo_off) {
+                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s, long ldy, int lo_off,
+                long stat_rows, long y_img_rows, long y_row0) {
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_apply: C must be a multiple of 8 and of G, <= 2048");
     if (ldy == 0) ldy = C;
+    if (stat_rows <= 0) stat_rows = rows_per_img;
+    if (y_img_rows <= 0) y_img_rows = rows_per_img;
+    CTRL_CHECK(y_row0 >= 0 && y_row0 + rows_per_img <= y_img_rows, "gn_apply: bad output image layout");
     CTRL_CHECK(ldy % 8 == 0 && lo_off % 8 == 0 && (lo_off == 0 || (lo_off >= C && lo_off + C <= ldy)), "gn_apply: bad split layout");
     const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 2048);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
@@ -279,10 +284,12 @@ int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gam
     PROF_WORK(0, ((x_dtype == DT_F32 ? 6.0 : 4.0) + (lo_off ? 2.0 : 0.0)) * imgs * rows_per_img * C);
     if (x_dtype == DT_F32)
         LAUNCH("gn_apply", gn_apply_kernel<float>, dim3(chunks, imgs), dim3(256), 0, s,
-               (const float*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block, ldy, lo_off);
+               (const float*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block, ldy, lo_off,
+               (float)stat_rows, y_img_rows, y_row0);
     else
         LAUNCH("gn_apply", gn_apply_kernel<half_t>, dim3(chunks, imgs), dim3(256), 0, s,
-               (const half_t*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block, ldy, lo_off);
+               (const half_t*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block, ldy, lo_off,
+               (float)stat_rows, y_img_rows, y_row0);
     return 0;
 }
 

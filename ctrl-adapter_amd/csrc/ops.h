@@ -45,7 +45,11 @@ int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per
 // ldy / lo_off: row stride of y (0 = C) and, when > 0, the column offset of the LOW half of a split operand
 // (y[r][c] = hi = fp16(v), y[r][lo_off + c] = fp16(v - hi)): consumed by a convolution packed with dup weights
 int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
-                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s, long ldy = 0, int lo_off = 0);
+                int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s, long ldy = 0, int lo_off = 0,
+                long stat_rows = 0, long y_img_rows = 0, long y_row0 = 0);
+//   stat_rows: rows per image the statistics in `stats` span (0 = rows_per_img; larger when a clip's frames are sharded
+//   over ranks and the sums were all-reduced); y_img_rows / y_row0: image i of y starts at row i*y_img_rows + y_row0
+//   (0 = dense): the padded operand layout of the frame-sharded temporal convolution
 // LayerNorm over the last dim of x [M][C] -> y fp16
 int op_layernorm(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
                  int M, int C, float eps, hipStream_t s);

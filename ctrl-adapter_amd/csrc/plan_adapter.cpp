@@ -123,7 +123,54 @@ struct AFwd {
     EhsCtx e_first;              // temporal cross-attention context (first frame of each clip), Lk == 1 only
     int in_dt, out_dt;
     const int* out_map = nullptr;   // device: input frame -> output frame (ctrl_adapter_forward_scatter), or null
+    // one clip's frames sharded over ranks: F / N / B above are LOCAL, Fg = frames of the whole clip
+    ctrl_clip_comm* comm = nullptr;
+    int Fg = 0;
+    size_t* ws_peak = nullptr;      // exchange-workspace bytes the forward needs (recorded by every exchange)
 };
+
+// ---- exchanges of the frame-sharded clip: every one lays its buffers out from offset 0 of the exchange workspace; reuse
+// is safe because everything (copies, transport calls, consumers) is ordered on the one stream the forward runs on ----
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline void ws_need(const AFwd& a, size_t bytes) { if (*a.ws_peak < bytes) *a.ws_peak = bytes; }
+#define COMM_TRY(expr) do { if ((expr) != 0) CTRL_FAIL("clip-sharded exchange failed: " #expr); } while (0)
+
+// clip-wide GroupNorm (statistics over all frames of a clip) on the local frames: local sums -> all-reduce over the
+// ranks -> apply with the global element count.  y is the padded conv operand [clip][Fl + 2][HW][C] (frames 1 .. Fl).
+int gn_clip_sharded(Ctx& cx, const Norm& n, const TV& x, half_t* y_padded, const AFwd& a, int HW, float eps) {
+    const int C = n.C, B = a.B, Fl = a.F;
+    float* st = cx.stats(op_gn_stats_floats(B, Fl * HW, C, 32));
+    RUN(cx, op_gn_stats(x.p, x.dt, st, B, Fl * HW, C, 32, cx.s));
+    const size_t nst = (size_t)B * 32 * 2;
+    ws_need(a, nst * sizeof(float));
+    if (!cx.dry) {
+        HIP_TRY(hipMemcpyAsync(a.comm->ws, st, nst * sizeof(float), hipMemcpyDeviceToDevice, cx.s));
+        COMM_TRY(a.comm->all_reduce_sum_f32(a.comm->user, 0, (int64_t)nst, cx.s));
+    }
+    RUN(cx, op_gn_apply(x.p, x.dt, (const float*)a.comm->ws, n.g, n.b, y_padded, B, Fl * HW, C, 32, eps, 1, cx.s,
+                        C, 0, (long)a.Fg * HW, (long)(Fl + 2) * HW, HW));
+    return 0;
+}
+
+// +-1-frame halo of the Conv3d operand: frame slots 0 / Fl + 1 of every clip <- the neighbour ranks' last / first frame
+int halo_exchange_frames(Ctx& cx, half_t* np, const AFwd& a, int HW, int C) {
+    const int B = a.B, Fl = a.F;
+    const size_t frame_b = (size_t)HW * C * sizeof(half_t), pitch = (size_t)(Fl + 2) * frame_b;
+    const size_t blk = al256((size_t)B * frame_b);
+    ws_need(a, 4 * blk);
+    if (cx.dry) return 0;
+    char* ws = (char*)a.comm->ws;
+    char* p = (char*)np;
+    HIP_TRY(hipMemcpy2DAsync(ws + 0 * blk, frame_b, p + 1 * frame_b, pitch, frame_b, B, hipMemcpyDeviceToDevice, cx.s));
+    HIP_TRY(hipMemcpy2DAsync(ws + 1 * blk, frame_b, p + (size_t)Fl * frame_b, pitch, frame_b, B, hipMemcpyDeviceToDevice, cx.s));
+    COMM_TRY(a.comm->halo_exchange(a.comm->user, 0, (int64_t)blk, (int64_t)(2 * blk), (int64_t)(3 * blk), (int64_t)((size_t)B * frame_b), cx.s));
+    if (a.comm->rank > 0) HIP_TRY(hipMemcpy2DAsync(p, pitch, ws + 2 * blk, frame_b, frame_b, B, hipMemcpyDeviceToDevice, cx.s));
+    else HIP_TRY(hipMemset2DAsync(p, pitch, 0, frame_b, B, cx.s));                       // first frames of the clip: zero padding
+    char* last = p + (size_t)(Fl + 1) * frame_b;
+    if (a.comm->rank < a.comm->world - 1) HIP_TRY(hipMemcpy2DAsync(last, pitch, ws + 3 * blk, frame_b, frame_b, B, hipMemcpyDeviceToDevice, cx.s));
+    else HIP_TRY(hipMemset2DAsync(last, pitch, 0, frame_b, B, cx.s));
+    return 0;
+}
 
 // temporal ResNet on frame-major rows [(b f) hw][C]
 // blend_mix (optional): AlphaBlender fold -- out = a*x + (1-a)*TemporalResnet(x), a = sigmoid(*blend_mix); the spatial
@@ -134,17 +181,28 @@ int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, 
     const int N = a.N, M = N * HW;
     float* tp = cx.f((size_t)N * C);
     RUN(cx, op_linear_small(temb, C, w.temb.w, w.temb.b, tp, C, N, C, C, 1, 0, cx.s));
-    half_t* n1 = cx.h((size_t)M * C);
-    TRY(run_groupnorm(cx, w.norm1, x, n1, a.B, a.F * HW, 1e-6f, true));     // statistics span the clip's frames
+    // frame-sharded clip: the conv operand is padded by one halo frame slot on each side of every clip's local frames
+    half_t* n1 = cx.h(a.comm ? (size_t)a.B * (a.F + 2) * HW * C : (size_t)M * C);
+    if (a.comm) {
+        TRY(gn_clip_sharded(cx, w.norm1, x, n1, a, HW, 1e-6f));
+        TRY(halo_exchange_frames(cx, n1, a, HW, C));
+    } else {
+        TRY(run_groupnorm(cx, w.norm1, x, n1, a.B, a.F * HW, 1e-6f, true));     // statistics span the clip's frames
+    }
     TV h1 = stream_alloc(cx, (size_t)M * C, false);
     IGemmArgs g = {};
-    g.A = n1; g.lda = C; g.mode = IG_TEMPORAL; g.Cin = C; g.taps = 3; g.F = a.F; g.HW = HW;
+    g.A = n1; g.lda = C; g.mode = IG_TEMPORAL; g.Cin = C; g.taps = 3; g.F = a.F; g.HW = HW; g.t_pad = a.comm ? 1 : 0;
     g.W = w.conv1.w; g.M = M; g.Nout = C; g.Ktot = 3 * C; g.bias = w.conv1.b;
     g.rowvec = tp; g.rowvec_ld = C; g.rows_per_img = HW; g.scale = 1.f;
     set_out(g, h1, C, C);
     RUN(cx, op_igemm(g, cx.s));
     half_t* n2 = n1;
-    TRY(run_groupnorm(cx, w.norm2, h1, n2, a.B, a.F * HW, 1e-6f, true));
+    if (a.comm) {
+        TRY(gn_clip_sharded(cx, w.norm2, h1, n2, a, HW, 1e-6f));
+        TRY(halo_exchange_frames(cx, n2, a, HW, C));
+    } else {
+        TRY(run_groupnorm(cx, w.norm2, h1, n2, a.B, a.F * HW, 1e-6f, true));
+    }
     IGemmArgs g2 = g;
     g2.A = n2; g2.W = w.conv2.w; g2.bias = w.conv2.b; g2.rowvec = nullptr;
     set_res(g2, x, C);
@@ -170,13 +228,37 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
     TRY(run_linear(cx, w.ffin2, mid, 4 * dim, x0, dim, M, X, dim));
     // x = attn1(norm1(x)) + x  (sequence = frames)
     TRY(run_layernorm(cx, w.norm1, x0, xn, M, dim));
-    half_t* qkv = cx.h((size_t)M * 3 * Ci);
-    TRY(run_linear(cx, w.attn1.qkv, xn, dim, tv16(qkv), 3 * Ci, M, TV(), 0));
-    half_t* o = cx.h((size_t)M * Ci);
-    TAttnArgs ta = {};
-    ta.QKV = qkv; ta.ld = 3 * Ci; ta.O = o; ta.ldo = Ci; ta.Bc = a.B; ta.F = a.F; ta.HW = L; ta.heads = w.attn1.heads;
-    ta.scale = 0.125f;
-    RUN(cx, op_temporal_attn(ta, cx.s));
+    half_t* o = nullptr;
+    if (!a.comm) {
+        half_t* qkv = cx.h((size_t)M * 3 * Ci);
+        TRY(run_linear(cx, w.attn1.qkv, xn, dim, tv16(qkv), 3 * Ci, M, TV(), 0));
+        o = cx.h((size_t)M * Ci);
+        TAttnArgs ta = {};
+        ta.Q = qkv; ta.ld = 3 * Ci; ta.O = o; ta.ldo = Ci; ta.Bc = a.B; ta.F = a.F; ta.HW = L; ta.heads = w.attn1.heads;
+        ta.scale = 0.125f;
+        RUN(cx, op_temporal_attn(ta, cx.s));
+    } else {
+        // frames sharded over ranks: Q stays local, the K|V rows of the local frames go straight from the QKV GEMM's
+        // epilogue into the exchange workspace and are all-gathered over the frame axis (one exchange per block)
+        half_t* q = cx.h((size_t)M * Ci);
+        const size_t per_rank = al256((size_t)M * 2 * Ci * sizeof(half_t));
+        ws_need(a, per_rank * (1 + (size_t)a.comm->world));
+        char* ws = cx.dry ? (char*)(uintptr_t)0x1000 : (char*)a.comm->ws;
+        IGemmArgs g = {};
+        g.A = xn; g.lda = dim; g.mode = IG_ROWS; g.Cin = dim; g.taps = 1;
+        g.W = w.attn1.qkv.w; g.M = M; g.Nout = 3 * Ci; g.Ktot = dim; g.scale = 1.f;
+        g.nseg = 2;
+        g.seg[0] = IGemmSeg{q, Ci, 0, Ci, SEG_ROW, DT_F16, 1, 0};
+        g.seg[1] = IGemmSeg{ws, 2 * Ci, Ci, 2 * Ci, SEG_ROW, DT_F16, 1, 0};
+        RUN(cx, op_igemm(g, cx.s));
+        if (!cx.dry) COMM_TRY(a.comm->all_gather(a.comm->user, 0, (int64_t)per_rank, (int64_t)per_rank, cx.s));
+        o = cx.h((size_t)M * Ci);
+        TAttnArgs ta = {};
+        ta.Q = q; ta.ld = Ci; ta.O = o; ta.ldo = Ci; ta.Bc = a.B; ta.F = a.Fg; ta.Fq = a.F; ta.Fl = a.F; ta.HW = L;
+        ta.heads = w.attn1.heads; ta.scale = 0.125f;
+        ta.KV = ws + per_rank; ta.ldkv = 2 * Ci;
+        RUN(cx, op_temporal_attn(ta, cx.s));
+    }
     // x = attn2(norm2(x), first-frame context) + attn1(...) + x : one key => the cross-attention term is one vector
     // (note N5), added by the out-projection's epilogue.  Rows are (b f p) and the context is the broadcast vector or
     // the first frame of the only clip: the same vector for every row.
@@ -218,12 +300,14 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
     }
     float* femb = nullptr;     // frame-index embedding [F][512] (:259-266)
     if (tt) {
-        float* fs = cx.f((size_t)a.F * C);
-        RUN(cx, op_frameidx_sincos(fs, a.F, a.F, C, cx.s));
-        float* f1 = cx.f((size_t)a.F * INNER);
-        RUN(cx, op_linear_small(fs, C, b.tte1.w, b.tte1.b, f1, INNER, a.F, INNER, C, 0, 1, cx.s));
-        femb = cx.f((size_t)a.F * INNER);
-        RUN(cx, op_linear_small(f1, INNER, b.tte2.w, b.tte2.b, femb, INNER, a.F, INNER, INNER, 0, 0, cx.s));
+        const int Fe = a.comm ? a.Fg : a.F;        // embedding of the GLOBAL frame index; a sharded rank uses its slice
+        float* fs = cx.f((size_t)Fe * C);
+        RUN(cx, op_frameidx_sincos(fs, Fe, Fe, C, cx.s));
+        float* f1 = cx.f((size_t)Fe * INNER);
+        RUN(cx, op_linear_small(fs, C, b.tte1.w, b.tte1.b, f1, INNER, Fe, INNER, C, 0, 1, cx.s));
+        femb = cx.f((size_t)Fe * INNER);
+        RUN(cx, op_linear_small(f1, INNER, b.tte2.w, b.tte2.b, femb, INNER, Fe, INNER, INNER, 0, 0, cx.s));
+        if (a.comm) femb += (size_t)a.comm->rank * a.F * INNER;
     }
     const size_t nl = b.layers.size();
     for (size_t i = 0; i < nl; ++i) {
@@ -347,6 +431,8 @@ struct AdapterCall {
     const int* map_dev; const int32_t* map_host; int N_out;     // frame scatter (null / null / N when off)
     ctrl_adapter* plan; int nlanes;                             // stream lanes (1 = everything on the caller's stream)
     const hipEvent_t* in_ev;                                    // optional [13]: input slot i is ready when in_ev[i] fires
+    ctrl_clip_comm* comm;                                       // frame-sharded clip (null = whole clips); F / N are then local
+    size_t* ws_peak;
 };
 
 size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
@@ -357,6 +443,7 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     AFwd a;
     a.N = k.N; a.F = k.F; a.B = k.N / k.F; a.t = k.t; a.t_count = k.t_count; a.in_dt = k.in_dt; a.out_dt = k.out_dt;
     a.out_map = k.map_dev;
+    a.comm = k.comm; a.Fg = k.comm ? k.F * k.comm->world : k.F; a.ws_peak = k.ws_peak;
     // frames of the dense output that no input frame lands on (zero-filled per slot below), as [begin, end) runs
     std::vector<std::pair<int, int>> holes;
     if (k.map_host) {
@@ -507,8 +594,14 @@ void ctrl_adapter_destroy(ctrl_adapter* h) { delete h; }
 static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
                                 const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
                                 int ehs_batch, int Lk, void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
-                                void* stream, const hipEvent_t* in_ev = nullptr) {
+                                void* stream, const hipEvent_t* in_ev = nullptr, ctrl_clip_comm* comm = nullptr) {
     CTRL_CHECK(h && ins && outs && timesteps, "adapter_forward: null argument");
+    if (comm) {
+        CTRL_CHECK(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "clip_sharded: bad rank / world");
+        CTRL_CHECK(comm->all_gather && comm->all_reduce_sum_f32 && comm->halo_exchange, "clip_sharded: missing transport callback");
+        CTRL_CHECK(num_frames * comm->world <= 32, "clip_sharded: at most 32 frames per clip");
+        CTRL_CHECK(((uintptr_t)comm->ws & 255) == 0, "clip_sharded: the exchange workspace must be 256-byte aligned");
+    }
     CTRL_CHECK(N >= 1 && H0 >= 1 && W0 >= 1 && num_frames >= 1 && N % num_frames == 0,
                "adapter_forward: batch must be a multiple of num_frames");
     CTRL_CHECK(t_count == 1 || t_count == N, "adapter_forward: need 1 or N timesteps");
@@ -547,13 +640,21 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     }
     // lanes are off while the per-launch profiler is recording (overlapping kernels make per-kernel times meaningless)
     static const int env_lanes = getenv("CTRL_ADAPTER_LANES") ? atoi(getenv("CTRL_ADAPTER_LANES")) : ctrl_adapter::kLanes;
-    const int nlanes = g_prof_on ? 1 : std::min(std::max(env_lanes, 1), (int)ctrl_adapter::kLanes);
+    // frame-sharded clips run on ONE stream: the exchanges of one communicator must be issued and executed in the same
+    // order on every rank
+    const int nlanes = (g_prof_on || comm) ? 1 : std::min(std::max(env_lanes, 1), (int)ctrl_adapter::kLanes);
+    size_t ws_peak = 0;
     AdapterCall k = {ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states, ehs_dtype,
-                     ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out, h, nlanes, in_ev};
+                     ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out, h, nlanes, in_ev, comm, &ws_peak};
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
     TRY(adapter_run(dry, h->w, k));
+    if (comm && (size_t)comm->ws_bytes < ws_peak) {
+        comm->ws_needed = (int64_t)ws_peak;
+        ctrl_set_error("clip_sharded: exchange workspace too small (need " + std::to_string(ws_peak) + " bytes); retry with ws_needed");
+        return 2;
+    }
     TRY(h->arena.ensure(workspace_bytes(dry)));
     h->arena.off = 0;
     Ctx cx{&h->arena, s, false};
@@ -577,6 +678,15 @@ int ctrl_adapter_forward_scatter(ctrl_adapter* h, const void* const* ins, int in
     CTRL_CHECK(frame_pos, "adapter_forward_scatter: null frame_pos");
     return adapter_forward_impl(h, ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states,
                                 ehs_dtype, ehs_batch, Lk, outs, out_dtype, frame_pos, N_out, stream);
+}
+
+int ctrl_adapter_forward_clip_sharded(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                                      const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
+                                      int ehs_batch, int Lk, void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
+                                      ctrl_clip_comm* comm, void* stream) {
+    CTRL_CHECK(comm, "adapter_forward_clip_sharded: null comm");
+    return adapter_forward_impl(h, ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states,
+                                ehs_dtype, ehs_batch, Lk, outs, out_dtype, frame_pos, frame_pos ? N_out : N, stream, nullptr, comm);
 }
 
 }  // extern "C"

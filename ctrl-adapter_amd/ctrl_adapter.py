@@ -67,7 +67,7 @@ class ControlNetAdapter(ParamTreeModule):
 
     @torch.no_grad()
     def forward(self, down_block_res_samples, mid_block_res_sample=None, sparsity_masking=None, num_frames=None,
-                timestep=None, encoder_hidden_states=None, *, scatter_to=None, out_dtype=None, clip_batch=None):
+                timestep=None, encoder_hidden_states=None, *, scatter_to=None, out_dtype=None, clip_batch=None, clip_comm=None):
         """Reference signature (model/ctrl_adapter.py:171) plus three keyword-only extensions that fold the pipelines'
         residual hand-over into the last epilogue of every adapter block:
 
@@ -77,13 +77,30 @@ class ControlNetAdapter(ParamTreeModule):
         out_dtype: dtype of the returned tensors (those loops build float32 tensors); default = the input dtype.
         clip_batch=bs: return `[bs, c, nf, h, w]` tensors, i.e. rearrange(x, "(bs nf) c h w -> bs c nf h w"), as
             zero-copy views; the UNets' inverse rearrange (i2vgen_xl/models/unets/unet_i2vgen_xl.py:683-684) is then a
-            view of the same memory as well."""
+            view of the same memory as well.
+        clip_comm=transport (clip_parallel.ClipTransport): ONE clip's frames are sharded over the transport's ranks; the
+            tensors of this call hold the rank's `num_frames` LOCAL frames of every clip (frames [rank*num_frames,
+            (rank+1)*num_frames)), and the three frame-mixing ops exchange through the transport."""
         # sparsity_masking is accepted and ignored, exactly like the reference (SURVEY.md note N7)
         outs, mid_out, args, tail, finish, _keep = self._launch_args(
             down_block_res_samples, mid_block_res_sample, num_frames, timestep, encoder_hidden_states, scatter_to, out_dtype, clip_batch)
         in_ptrs, in_dt = _keep[0], _keep[1]
         with torch.cuda.device(down_block_res_samples[0].device):
-            if tail is None:
+            if clip_comm is not None:
+                pos, n_out = (tail[0], tail[1]) if tail is not None else (None, args[0])
+                for attempt in range(2):
+                    cs = clip_comm.c_struct()
+                    clip_comm.error = None
+                    rc = L.lib().ctrl_adapter_forward_clip_sharded(self._ensure_plan(), in_ptrs, in_dt, *args, pos, n_out,
+                                                                   C.byref(cs), L.cur_stream())
+                    if rc == 2 and attempt == 0:         # exchange workspace too small: grow it and retry
+                        clip_comm.ensure(cs.ws_needed)
+                        continue
+                    if clip_comm.error is not None:
+                        raise clip_comm.error
+                    L.check(rc)
+                    break
+            elif tail is None:
                 L.check(L.lib().ctrl_adapter_forward(self._ensure_plan(), in_ptrs, in_dt, *args, L.cur_stream()))
             else:
                 L.check(L.lib().ctrl_adapter_forward_scatter(self._ensure_plan(), in_ptrs, in_dt, *args, *tail, L.cur_stream()))

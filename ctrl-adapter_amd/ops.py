@@ -57,14 +57,14 @@ def pack_vec(v, geglu=False):
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
           res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None,
-          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0):
+          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False):
     """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
     g = geom or {}
     d.Hin = g.get("Hin", 1); d.Win = g.get("Win", 1); d.Hout = g.get("Hout", 1); d.Wout = g.get("Wout", 1)
     d.stride = g.get("stride", 1); d.up = g.get("up", 1)
-    d.F = F; d.HW = HW
+    d.F = F; d.HW = HW; d.t_pad = int(t_pad)
     d.W = W.data_ptr(); d.M = M; d.Nout = Nout; d.Ktot = taps * Cin
     d.bias = bias.data_ptr() if bias is not None else None
     d.rowvec = rowvec.data_ptr() if rowvec is not None else None
@@ -132,12 +132,17 @@ def flash_attn(Q, ldq, K, ldk, Vt, Lkpad, B, heads, D, Lq, Lk, scale=None, kvB=0
     return out
 
 
-def temporal_attn(qkv, Bc, F, HW, heads):
+def temporal_attn(qkv, Bc, F, HW, heads, kv=None, Fq=0, Fl=0):
+    """qkv [(b f) p][3C] (q | k | v) -> [(b f) p][C]; sharded form: qkv holds the LOCAL Fq query frames as [..][C] rows
+    and kv = the gathered K|V rows [world][Bc][Fl][HW][2C]"""
     Cc = heads * 64
     out = _f16(qkv.shape[0], Cc)
     d = L.TAttnDesc()
-    d.QKV = qkv.data_ptr(); d.ld = 3 * Cc; d.O = out.data_ptr(); d.ldo = Cc
+    d.Q = qkv.data_ptr(); d.ld = qkv.shape[1]; d.O = out.data_ptr(); d.ldo = Cc
     d.Bc = Bc; d.F = F; d.HW = HW; d.heads = heads; d.scale = 64 ** -0.5
+    d.Fq = Fq; d.Fl = Fl
+    if kv is not None:
+        d.KV = kv.data_ptr(); d.ldkv = kv.shape[-1]
     L.check(L.lib().ctrl_op_temporal_attn(C.byref(d), L.cur_stream()))
     return out
 

@@ -69,7 +69,7 @@ typedef struct ctrl_igemm_desc {
     int32_t taps;       /* 1 | 9 | 3 */
     int32_t Hin, Win, Hout, Wout, stride, up;   /* conv2d geometry; up = nearest up-sampling folded into the gather */
     int32_t F, HW;      /* temporal: frames per clip, rows per frame */
-    int32_t pad0_;
+    int32_t t_pad;      /* temporal, frame-sharded clip: A = padded [clip][F+2][HW][lda] (slots 0 / F+1 = halo frames), M rows = the F local frames */
     const void* W;      /* fp16 [Nout][taps*Cin] */
     int32_t M, Nout, Ktot;
     int32_t pad1_;
@@ -105,10 +105,16 @@ typedef struct ctrl_attn_desc {
 int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream);
 
 typedef struct ctrl_tattn_desc {
-    const void* QKV; int64_t ld;     /* [(b*F+f)*HW + p][3*C]  q | k | v */
+    const void* Q; int64_t ld;       /* [(b*Fq+f)*HW + p][ld], head h at column h*64; unsharded: rows are q | k | v, 3*C wide */
     void* O; int64_t ldo;            /* [rows][C] */
-    int32_t Bc, F, HW, heads;        /* head_dim 64 */
+    int32_t Bc, F, HW, heads;        /* clips, key frames per clip (<= 32), pixels, heads of 64 */
     float scale;
+    int32_t Fq;                      /* query frames per clip held in Q / O (0 = F) */
+    /* keys / values: NULL = the k | v columns of the Q rows.  Otherwise K|V rows [((r*Bc + b)*Fl + fl)*HW + p][ldkv]
+       (k at column h*64, v at C + h*64) for key frame kf = r*Fl + fl: the all-gathered K|V of a clip whose frames are
+       sharded over ranks, Fl frames per rank */
+    const void* KV; int64_t ldkv;
+    int32_t Fl;                      /* key frames per gathered shard (0 = F) */
     int32_t pad0_;
 } ctrl_tattn_desc;
 int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream);
@@ -233,6 +239,38 @@ int ctrl_adapter_forward_scatter(ctrl_adapter* h,
                                  const float* timesteps, int t_count,
                                  const void* encoder_hidden_states, int ehs_dtype, int ehs_batch, int Lk,
                                  void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out, void* stream);
+
+/* ---- One clip split across GPUs by frames (BASELINE.json config 4 with clips < GPUs).
+ * Every rank holds Fl = F / world consecutive frames of every clip: `N` = clips * Fl LOCAL frames (frame-major, rank r
+ * owns frames [r*Fl, (r+1)*Fl) of each clip), num_frames = Fl.  All ops of the adapter are per frame except three, and
+ * each of those does exactly one exchange through the caller-supplied transport (stream-ordered on `stream`; byte
+ * offsets into the exchange workspace `ws`, which the caller registered with its transport):
+ *   temporal attention  (model/adapter_spatial_temporal.py:280)  all_gather of the K|V rows over the frame axis
+ *   Conv3d (3,1,1)      (TemporalResnetBlock, :226)              halo_exchange of the first / last local frame
+ *   temporal GroupNorm  (TemporalResnetBlock, :226)              all_reduce_sum_f32 of the (clip, group) sums
+ * The transports used are torch.distributed over RCCL (ctrl-adapter_amd/clip_parallel.py); any transport with these
+ * semantics works.  Callbacks return 0 on success.  If `ws_bytes` is too small the call fails with return code 2 and
+ * `ws_needed` holds the size to retry with.  Runs on the caller's stream only (no stream lanes). */
+typedef struct ctrl_clip_comm {
+    int32_t rank, world;
+    void* ws; int64_t ws_bytes;
+    /* recv[r*bytes .. (r+1)*bytes) = rank r's send[0 .. bytes) */
+    int (*all_gather)(void* user, int64_t send_off, int64_t recv_off, int64_t bytes_per_rank, void* stream);
+    /* count floats at off, summed over ranks in place */
+    int (*all_reduce_sum_f32)(void* user, int64_t off, int64_t count, void* stream);
+    /* send_prev -> rank-1's recv_next, send_next -> rank+1's recv_prev (edge ranks have no such neighbour: nothing is
+       sent and the corresponding recv area is left untouched) */
+    int (*halo_exchange)(void* user, int64_t send_prev_off, int64_t send_next_off, int64_t recv_prev_off, int64_t recv_next_off,
+                         int64_t bytes, void* stream);
+    void* user;
+    int64_t ws_needed;
+} ctrl_clip_comm;
+int ctrl_adapter_forward_clip_sharded(ctrl_adapter* h,
+                                      const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
+                                      const float* timesteps, int t_count,
+                                      const void* encoder_hidden_states, int ehs_dtype, int ehs_batch, int Lk,
+                                      void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
+                                      ctrl_clip_comm* comm, void* stream);
 
 /* ---- Fused step: ctrl_controlnet_forward + ctrl_adapter_forward[_scatter] of one denoise step as one call (the two
  * back-to-back calls of the pipelines, sdxl/pipelines/sdxl_controlnet_adapter_pipeline.py:1323,1338 and

@@ -426,3 +426,47 @@ def test_video_chain_at_benched_shapes_vs_oracle(P, gpu):
     assert o[0].shape == (N, 320, 64, 64) and om.shape == (N, 1280, 8, 8)
     assert max(e_ad) <= TOL_ADAPTER
     assert max(e_cn) <= TOL and max(e_chain) <= TOL_CHAIN
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_clip_sharded_adapter_equals_unsharded(P, gpu, world):
+    """SURVEY.md 8e row 2 / BASELINE config 4 with fewer clips than GPUs: ONE clip's frames sharded over `world` ranks.
+    Virtual ranks = threads of this process on one GPU (each with its own plan, stream and exchange workspace; the
+    transport is clip_parallel.LoopbackTransport -- the RCCL transport runs the same native code with the same
+    callbacks).  Every rank runs ctrl_adapter_forward_clip_sharded on its F / world frames of both clips; gathered, the
+    results must equal the unsharded forward: the all-gathered temporal attention and the halo Conv3d are bit-exact
+    (tests/test_gpu_ops.py), only the order in which the clip-wide GroupNorm sums are added differs (per-rank partials
+    then ranks), i.e. ~1e-7 on the statistics -> isolated fp16 operand flips -> <= 1e-4 rel-inf on fp32 outputs."""
+    from ctrl_adapter_amd.clip_parallel import LoopbackWorld, run_virtual_ranks, shard_frames, unshard_frames
+    from oracle.adapter import ControlNetAdapterOracle
+    torch.set_grad_enabled(False)
+    F_, clips = 8, 2
+    N = F_ * clips
+    cfg = dict(cases.ADAPTER_VIDEO, num_frames=F_)
+    downs, mid = cases.pyramid_inputs(N=N, h0=16, seed=1300, with_mid=True)
+    e_img = seeded_tensor((1, 1, 1024), 1301)
+    t = torch.full((N,), 961.0)
+    ad = seeded_init(P.ControlNetAdapter(**cfg), seed=33).to(gpu)
+    kw = dict(encoder_hidden_states=e_img.half().to(gpu), out_dtype=torch.float32)
+    ref, ref_mid = ad([d.half().to(gpu) for d in downs], mid_block_res_sample=mid.half().to(gpu), num_frames=F_, timestep=t.to(gpu), **kw)
+    lw = LoopbackWorld(world, gpu)
+    plans = [ad] + [seeded_init(P.ControlNetAdapter(**cfg), seed=33).to(gpu) for _ in range(world - 1)]
+    comms = [lw.transport(r) for r in range(world)]
+
+    def rank_body(r):
+        ins = [shard_frames(d.half().to(gpu), F_, r, world) for d in downs]
+        m = shard_frames(mid.half().to(gpu), F_, r, world)
+        return plans[r](ins, mid_block_res_sample=m, num_frames=F_ // world, timestep=shard_frames(t.to(gpu), F_, r, world),
+                        clip_comm=comms[r], **kw)
+    res = run_virtual_ranks(world, rank_body)
+    got = [unshard_frames([res[r][0][i] for r in range(world)], F_) for i in range(12)]
+    got_mid = unshard_frames([res[r][1] for r in range(world)], F_)
+    errs = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ref) + [ref_mid])]
+    print("PARITY clip-sharded (%d ranks x %d frames) vs unsharded rel_inf: %s" % (world, F_ // world, " ".join("%.1e" % e for e in errs)))
+    assert max(errs) <= 1e-4
+    if world == 2:       # and against the oracle directly
+        oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=33)
+        ro, rom = oa(downs, mid_block_res_sample=mid, num_frames=F_, timestep=t, encoder_hidden_states=e_img)
+        eo = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ro) + [rom])]
+        print("PARITY clip-sharded (2 ranks) vs oracle rel_inf: " + " ".join("%.2e" % e for e in eo))
+        assert max(eo) <= TOL_ADAPTER

@@ -360,3 +360,38 @@ def test_split_operand_conv(ops, gpu, cin, cout, h, taps):
     ops.igemm(y1, cin, ops.pack_conv_w(w.to(gpu)), n * h * h, cout, cin, taps=taps, mode=ops.IG_CONV2D, geom=geom,
               bias=b.to(gpu), rows_per_img=h * h, segs=[(out1, cout, 0, cout, ops.SEG_ROW, 1)])
     print("PARITY   (plain fp16-operand conv beside it: rel_inf=%.3e)" % rel_inf(out1.double(), ref))
+
+
+def test_frame_sharded_temporal_ops_are_bit_exact(ops, gpu):
+    """the two frame-mixing kernels of a clip whose frames are sharded over ranks, given exact exchanges:
+    temporal attention with LOCAL query frames against the all-gathered K|V rows, and the Conv3d over the halo-padded
+    operand (ctrl_igemm_desc.t_pad) must reproduce the unsharded kernels bit for bit"""
+    Bc, Fr, HW, heads, W = 2, 16, 20, 5, 4
+    Cc, Fl = heads * 64, Fr // W
+    qkv = rnd(Bc * Fr * HW, 3 * Cc, seed=5).half().to(gpu)
+    full = ops.temporal_attn(qkv, Bc, Fr, HW, heads).reshape(Bc, Fr, HW, Cc)
+    v5 = qkv.reshape(Bc, Fr, HW, 3 * Cc)
+    kv_all = torch.stack([v5[:, r * Fl:(r + 1) * Fl, :, Cc:] for r in range(W)]).contiguous()      # [W][Bc][Fl][HW][2C]
+    for r in range(W):
+        q_loc = v5[:, r * Fl:(r + 1) * Fl, :, :Cc].reshape(Bc * Fl * HW, Cc).contiguous()
+        out = ops.temporal_attn(q_loc, Bc, Fr, HW, heads, kv=kv_all.reshape(-1, 2 * Cc), Fq=Fl, Fl=Fl)
+        assert torch.equal(out.reshape(Bc, Fl, HW, Cc), full[:, r * Fl:(r + 1) * Fl]), "rank %d" % r
+    # Conv3d (3,1,1): padded operand [clip][Fl + 2][HW][C] with the neighbours' frames (zeros at the clip ends) in the halo slots
+    Cc = 64
+    x = rnd(Bc * Fr * HW, Cc, seed=6).half().to(gpu)
+    w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=0.05)
+    bias = rnd(Cc, seed=3).to(gpu)
+    wp = ops.pack_conv_w(w.reshape(Cc, Cc, 3, 1).to(gpu))
+    ref = torch.empty(Bc * Fr * HW, Cc, dtype=torch.float16, device=gpu)
+    ops.igemm(x, Cc, wp, Bc * Fr * HW, Cc, Cc, taps=3, mode=ops.IG_TEMPORAL, bias=bias, segs=[(ref, Cc, 0, Cc, ops.SEG_ROW, 1)], F=Fr, HW=HW)
+    ref = ref.reshape(Bc, Fr, HW, Cc)
+    x5 = x.reshape(Bc, Fr, HW, Cc)
+    for r in range(W):
+        pad = torch.zeros(Bc, Fl + 2, HW, Cc, dtype=torch.float16, device=gpu)
+        lo, hi = r * Fl - 1, (r + 1) * Fl + 1
+        pad[:, (1 if lo < 0 else 0):(Fl + 1 if hi > Fr else Fl + 2)] = x5[:, max(lo, 0):min(hi, Fr)]
+        out = torch.empty(Bc * Fl * HW, Cc, dtype=torch.float16, device=gpu)
+        ops.igemm(pad, Cc, wp, Bc * Fl * HW, Cc, Cc, taps=3, mode=ops.IG_TEMPORAL, bias=bias, segs=[(out, Cc, 0, Cc, ops.SEG_ROW, 1)],
+                  F=Fl, HW=HW, t_pad=True)
+        assert torch.equal(out.reshape(Bc, Fl, HW, Cc), ref[:, r * Fl:(r + 1) * Fl]), "rank %d" % r
+    print("PARITY frame-sharded temporal attention / Conv3d: bit-exact vs unsharded (4 shards)")
