@@ -4,9 +4,10 @@
   * size-independent properties at batch 8 (batch consistency, linearity in conditioning_scale, zero slots)
 Tolerance: rel-inf = max|a-b| / max|b| per output tensor.  The HIP path stores activations
 in fp16 with fp32 accumulation / statistics / softmax; weights and inputs are fp16-representable on both sides.
-Residual streams are fp32.  Asserted: adapter residuals <= 1e-3 (the north-star bound), also when
-chained behind the HIP ControlNet at the full SDXL shapes; ControlNet outputs <= 1.5e-3.  Achieved values are printed
-(and recorded in profiles/)."""
+Residual streams are fp32 and the ControlNet's convolutions take split [hi | lo] fp16 operands.
+Asserted everywhere: <= 1e-3 (the north-star bound) -- ControlNet outputs, adapter residuals on identical inputs, and the
+chains HIP ControlNet -> HIP adapter (the pipelines' own data flow) at the SDXL, SVD-16-frame and multi-condition shapes.
+Achieved values are printed (and recorded in profiles/)."""
 import pytest
 import torch
 
@@ -16,7 +17,7 @@ from conftest import rel_inf
 from oracle.init import seeded_init, seeded_tensor
 
 pytestmark = pytest.mark.gpu
-TOL = 1.5e-3          # ControlNet outputs (13 tensors, ~60 layers deep)
+TOL = 1e-3            # ControlNet outputs (13 tensors, ~60 layers deep)
 TOL_ADAPTER = 1e-3    # the north-star bound on the adapter residuals (BASELINE.json)
 TOL_CHAIN = 1e-3      # ... also when the adapter is fed by the HIP ControlNet (the pipelines' own output)
 
@@ -143,7 +144,7 @@ def test_full_size_sdxl_vs_oracle_and_batch_properties(P, controlnet, gpu):
     print("PARITY full-size adapter (same inputs) rel_inf: " + " ".join("%.2e" % e for e in e_ad))
     print("PARITY full-size chain (HIP ControlNet -> HIP adapter vs oracle -> oracle) rel_inf: " + " ".join("%.2e" % e for e in e_chain))
     assert max(e_cn) <= TOL and max(e_ad) <= TOL_ADAPTER
-    assert max(e_chain) <= TOL          # the chain carries the ControlNet's fp16-operand noise into the adapter
+    assert max(e_chain) <= TOL_CHAIN
     # batch 8: every image of a replicated batch must reproduce the single-image result
     d8, m8, o8 = run(8)
     for a, b in zip(o8[:9], o1[:9]):
@@ -196,7 +197,7 @@ def test_multi_condition_router_pipeline_vs_oracle(P, gpu):
     go, gmid = ad(gmd, mid_block_res_sample=gmm, num_frames=F_, timestep=t, encoder_hidden_states=e_img.half().to(gpu))
     errs = [rel_inf(a, b) for a, b in zip(list(go) + [gmid], list(ro) + [rmid])]
     print("PARITY config-5 chain (3 nets, router, merge, video adapter) rel_inf: " + " ".join("%.2e" % e for e in errs))
-    assert max(errs) <= 1.5e-3
+    assert max(errs) <= TOL_CHAIN
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
