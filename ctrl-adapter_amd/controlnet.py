@@ -146,6 +146,7 @@ class ControlNetModel(ParamTreeModule):
         outs, args, _keep = self._launch_args(sample, timestep, ehs, controlnet_cond, conditioning_scale, guess_mode,
                                               skip_conv_in, skip_time_emb, out_dtype)
         with torch.cuda.device(sample.device):      # plan, stream and launches follow the tensors' device, not the current one
+            self._text_cache_mode(encoder_hidden_states, L.lib().ctrl_controlnet_text_cache)
             L.check(L.lib().ctrl_controlnet_forward(self._ensure_plan(), *args, L.cur_stream()))
         down, mid = outs[:12], outs[12]
         if not return_dict:

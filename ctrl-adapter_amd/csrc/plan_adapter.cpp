@@ -389,6 +389,7 @@ struct ctrl_adapter : PlanBase {
     AdapterW w;
     std::unique_ptr<Packer> packer;
     Arena arena;
+    KvCache kvc;                         // text K/V cache (ctrl_*_text_cache)
     // frame scatter map: pinned staging + device copy, re-uploaded (on the caller's stream) only when it changes
     static constexpr int kMaxMap = 1024;
     int* map_host = nullptr;
@@ -591,6 +592,12 @@ int ctrl_adapter_create(const ctrl_adapter_config* cfg, const ctrl_tensor_ref* t
 
 void ctrl_adapter_destroy(ctrl_adapter* h) { delete h; }
 
+int ctrl_adapter_text_cache(ctrl_adapter* h, int mode) {
+    CTRL_CHECK(h && mode >= 0 && mode <= 2, "adapter_text_cache: mode must be 0 (off), 1 (keep) or 2 (reuse)");
+    h->kvc.mode = mode;
+    return 0;
+}
+
 static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
                                 const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype,
                                 int ehs_batch, int Lk, void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
@@ -649,6 +656,9 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
+    dry.kvc = &h->kvc; h->kvc.next = 0;
+    if (h->kvc.mode == KvCache::REUSE)
+        CTRL_CHECK(h->kvc.key_batch == ehs_batch && h->kvc.key_Lk == Lk, "adapter_forward: text K/V cache was kept for another batch / prompt length");
     TRY(adapter_run(dry, h->w, k));
     if (comm && (size_t)comm->ws_bytes < ws_peak) {
         comm->ws_needed = (int64_t)ws_peak;
@@ -660,7 +670,9 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     Ctx cx{&h->arena, s, false};
     cx.f32stream = dry.f32stream;
     cx.stats_total = dry.stats_total;
+    cx.kvc = &h->kvc; h->kvc.next = 0;
     TRY(adapter_run(cx, h->w, k));
+    if (h->kvc.mode == KvCache::KEEP) { h->kvc.key_batch = ehs_batch; h->kvc.key_Lk = Lk; }
     return h->leave(s, capturing);
 }
 

@@ -208,19 +208,30 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, 
     TRY(run_linear(cx, w.q, xn, dim, tv16(q), Ci, M, TV(), 0));
     const int Lkpad = (e.Lk + 63) / 64 * 64;
     const int Mk = e.batch * e.Lk;
-    half_t* k = cx.h((size_t)Mk * Ci);
-    half_t* vt = cx.h((size_t)e.batch * Ci * Lkpad);
-    if (e.Lk % 8) RUN(cx, op_fill_zero(vt, (size_t)e.batch * Ci * Lkpad * sizeof(half_t), cx.s));   // finite pad columns
-    IGemmArgs g = {};
-    g.A = e.h16; g.lda = e.cross; g.mode = IG_ROWS; g.Cin = e.cross; g.taps = 1;
-    g.W = w.kv.w; g.M = Mk; g.Nout = Ci; g.Ktot = e.cross; g.scale = 1.f;
-    g.nseg = 1;
-    g.seg[0] = IGemmSeg{k, Ci, 0, Ci, SEG_ROW, DT_F16, 1, 0};
-    RUN(cx, op_igemm(g, cx.s));
-    IGemmArgs gv = g;
-    gv.W = w.kv.w + (size_t)Ci * e.cross;
-    gv.seg[0] = IGemmSeg{vt, Lkpad, 0, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
-    RUN(cx, op_igemm(gv, cx.s));
+    // K and V^T of the text states: step-invariant, optionally kept in / taken from the plan's cache
+    const bool cached = cx.kvc && cx.kvc->mode != KvCache::OFF;
+    half_t* k = nullptr; half_t* vt = nullptr;
+    if (cached) {
+        KvCache::Slot* sl = nullptr;
+        TRY(cx.kvc->get((size_t)Mk * Ci, (size_t)e.batch * Ci * Lkpad, cx.dry, &sl));
+        k = sl->k; vt = sl->vt;
+    } else {
+        k = cx.h((size_t)Mk * Ci);
+        vt = cx.h((size_t)e.batch * Ci * Lkpad);
+    }
+    if (!(cached && cx.kvc->mode == KvCache::REUSE)) {
+        if (e.Lk % 8) RUN(cx, op_fill_zero(vt, (size_t)e.batch * Ci * Lkpad * sizeof(half_t), cx.s));   // finite pad columns
+        IGemmArgs g = {};
+        g.A = e.h16; g.lda = e.cross; g.mode = IG_ROWS; g.Cin = e.cross; g.taps = 1;
+        g.W = w.kv.w; g.M = Mk; g.Nout = Ci; g.Ktot = e.cross; g.scale = 1.f;
+        g.nseg = 1;
+        g.seg[0] = IGemmSeg{k, Ci, 0, Ci, SEG_ROW, DT_F16, 1, 0};
+        RUN(cx, op_igemm(g, cx.s));
+        IGemmArgs gv = g;
+        gv.W = w.kv.w + (size_t)Ci * e.cross;
+        gv.seg[0] = IGemmSeg{vt, Lkpad, 0, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
+        RUN(cx, op_igemm(gv, cx.s));
+    }
     half_t* o = cx.h((size_t)M * Ci);
     TRY(run_attention(cx, q, Ci, k, Ci, vt, Lkpad, o, Ci, B, e.batch == 1 ? 1 : B, w.heads, w.D, L, e.Lk));
     TRY(run_linear(cx, w.out, o, Ci, out, dim, M, x, dim));

@@ -261,6 +261,39 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
 };
 
+// Step-invariant cache of the cross-attention K / V^T projections of the text states: the
+// encoder_hidden_states of a request do not change over its ~50 denoise steps, but the reference recomputes to_k / to_v of
+// every cross-attention each step.  mode KEEP: the projections are written into plan-owned buffers (allocated on that
+// forward: run it eagerly, not under stream capture); mode REUSE: the GEMMs are skipped and the buffers are read.
+struct KvCache {
+    enum { OFF = 0, KEEP = 1, REUSE = 2 };
+    int mode = OFF;
+    size_t next = 0;                     // index of the next cross-attention of the forward
+    struct Slot { half_t* k = nullptr; half_t* vt = nullptr; size_t k_elems = 0, vt_elems = 0; };
+    std::vector<Slot> slots;
+    std::vector<void*> retired;          // outgrown buffers stay alive (captured graphs may address them)
+    int key_batch = 0, key_Lk = 0;       // what the cache was filled for
+    ~KvCache() {
+        for (auto& s : slots) { if (s.k) hipFree(s.k); if (s.vt) hipFree(s.vt); }
+        for (void* p : retired) hipFree(p);
+    }
+    int get(size_t k_elems, size_t vt_elems, bool dry, Slot** out) {
+        if (next >= slots.size()) slots.resize(next + 1);
+        Slot& s = slots[next++];
+        if (!dry && mode == KEEP && (s.k_elems < k_elems || s.vt_elems < vt_elems)) {
+            if (s.k) retired.push_back(s.k);
+            if (s.vt) retired.push_back(s.vt);
+            s.k = s.vt = nullptr;
+            HIP_TRY(hipMalloc((void**)&s.k, k_elems * sizeof(half_t)));
+            HIP_TRY(hipMalloc((void**)&s.vt, vt_elems * sizeof(half_t)));
+            s.k_elems = k_elems; s.vt_elems = vt_elems;
+        }
+        if (!dry && mode == REUSE) CTRL_CHECK(s.k && s.k_elems >= k_elems && s.vt_elems >= vt_elems, "text K/V cache: REUSE without a matching KEEP forward");
+        *out = &s;
+        return 0;
+    }
+};
+
 // Execution context: `dry` = sizing pass (allocations only advance the offset, nothing is launched).
 struct Ctx {
     Arena* ar;
@@ -268,6 +301,7 @@ struct Ctx {
     bool dry;
     bool f32stream = true;     // residual streams kept in fp32 (set from CTRL_STREAM_F32, default on)
     bool split = false;        // GEMM-operand mirrors of the streams are split [hi | lo] rows (ControlNet, CTRL_CN_SPLIT)
+    KvCache* kvc = nullptr;    // text K/V cache of the plan (mode OFF: not used)
     // pooled GroupNorm statistics (zeroed once per forward with a single memset)
     float* stats_base = nullptr;
     size_t stats_off = 0, stats_total = 0;

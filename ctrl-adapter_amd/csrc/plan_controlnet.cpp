@@ -158,6 +158,7 @@ struct ctrl_controlnet : PlanBase {
     ControlNetW w;
     std::unique_ptr<Packer> packer;
     Arena arena;
+    KvCache kvc;                         // text K/V cache (ctrl_*_text_cache)
     // fused step (ctrl_step_forward): the network runs on its own stream and signals every output with an event
     hipStream_t side = nullptr;
     hipEvent_t fork_ev = nullptr, done_ev = nullptr, out_ev[13] = {};
@@ -382,6 +383,12 @@ int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_
 
 void ctrl_controlnet_destroy(ctrl_controlnet* h) { delete h; }
 
+int ctrl_controlnet_text_cache(ctrl_controlnet* h, int mode) {
+    CTRL_CHECK(h && mode >= 0 && mode <= 2, "controlnet_text_cache: mode must be 0 (off), 1 (keep) or 2 (reuse)");
+    h->kvc.mode = mode;
+    return 0;
+}
+
 static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int sample_dtype, int N, int Hs, int Ws,
                                    const float* timesteps, int t_count, const void* encoder_hidden_states, int ehs_dtype, int Lk,
                                    const void* controlnet_cond, int cond_dtype, float conditioning_scale, int flags,
@@ -419,6 +426,9 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
     dry.split = h->w.split;
+    dry.kvc = &h->kvc; h->kvc.next = 0;
+    if (h->kvc.mode == KvCache::REUSE)
+        CTRL_CHECK(h->kvc.key_batch == N && h->kvc.key_Lk == Lk, "controlnet_forward: text K/V cache was kept for another batch / prompt length");
     CTRL_CHECK(!dry.split || dry.f32stream, "controlnet_forward: the plan was built with split-operand convolutions "
                "(CTRL_CN_SPLIT) and needs fp32 residual streams (CTRL_STREAM_F32 was switched off after create)");
     TRY(controlnet_run(dry, h->w, a));
@@ -427,8 +437,10 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     Ctx cx{&h->arena, s, false};
     cx.f32stream = dry.f32stream;
     cx.split = dry.split;
+    cx.kvc = &h->kvc; h->kvc.next = 0;
     cx.stats_total = dry.stats_total;
     TRY(controlnet_run(cx, h->w, a));
+    if (h->kvc.mode == KvCache::KEEP) { h->kvc.key_batch = N; h->kvc.key_Lk = Lk; }
     if (keep && !reuse) { h->cond_N = N; h->cond_H = Hs; h->cond_W = Ws; }
     return h->leave(s, capturing);
 }

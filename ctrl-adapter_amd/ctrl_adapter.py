@@ -86,6 +86,7 @@ class ControlNetAdapter(ParamTreeModule):
             down_block_res_samples, mid_block_res_sample, num_frames, timestep, encoder_hidden_states, scatter_to, out_dtype, clip_batch)
         in_ptrs, in_dt = _keep[0], _keep[1]
         with torch.cuda.device(down_block_res_samples[0].device):
+            self._text_cache_mode(encoder_hidden_states, L.lib().ctrl_adapter_text_cache)
             if clip_comm is not None:
                 pos, n_out = (tail[0], tail[1]) if tail is not None else (None, args[0])
                 for attempt in range(2):

@@ -16,18 +16,29 @@ from . import _lib as L
 @torch.no_grad()
 def controlled_step(controlnet, adapter, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0,
                     guess_mode=False, skip_conv_in=False, skip_time_emb=False, *, adapter_encoder_hidden_states,
-                    adapter_timestep=None, num_frames=None, use_mid=None, scatter_to=None, out_dtype=None, clip_batch=None):
+                    adapter_timestep=None, num_frames=None, use_mid=None, scatter_to=None, out_dtype=None, clip_batch=None,
+                    discard_when_off=False):
     """-> ((down_block_res_samples, mid_block_res_sample), (adapted_down_block_res_samples, adapted_mid | None))
 
     Positional part = ControlNetModel.forward's arguments; keyword part = ControlNetAdapter.forward's
     (`adapter_timestep` defaults to `timestep`; `use_mid` defaults to the adapter having a mid block, as in the video
-    pipelines that pass `mid_block_res_sample`)."""
+    pipelines that pass `mid_block_res_sample`).
+
+    discard_when_off=True: on a step whose control is switched off (conditioning_scale == 0, i.e. controlnet_keep == 0
+    outside [control_guidance_start, control_guidance_end]) the SDXL pipeline throws the adapter's down residuals away
+    (sdxl/pipelines/sdxl_controlnet_adapter_pipeline.py:1348 `if cond_scale == 0: ...down_block_res_samples = None`) after
+    having computed them.  With this flag the adapter is not run at all on such a step when it has no mid block to
+    deliver (what the pipeline keeps in that case is None as well) and (None, None) is returned for it: 40 % of the steps
+    at control_guidance_end = 0.6 (note N8).  Off by default: the plain call returns what the two
+    modules return."""
     cn_dtype = controlnet._check_inputs(sample, encoder_hidden_states, controlnet_cond)
     if isinstance(conditioning_scale, (int, float)) and conditioning_scale == 0:
         # control off for this step: the separate calls already skip the ControlNet (note N8); nothing to overlap
         down, mid = controlnet(sample, timestep, encoder_hidden_states, controlnet_cond, 0, guess_mode=guess_mode,
                                return_dict=False, skip_conv_in=skip_conv_in, skip_time_emb=skip_time_emb)
         use_m = adapter.add_adapter_location_M if use_mid is None else use_mid
+        if discard_when_off and not use_m:
+            return (down, mid), (None, None)
         return (down, mid), adapter(down, mid if use_m else None, num_frames=num_frames,
                                     timestep=timestep if adapter_timestep is None else adapter_timestep,
                                     encoder_hidden_states=adapter_encoder_hidden_states, scatter_to=scatter_to,

@@ -240,6 +240,14 @@ int ctrl_adapter_forward_scatter(ctrl_adapter* h,
                                  const void* encoder_hidden_states, int ehs_dtype, int ehs_batch, int Lk,
                                  void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out, void* stream);
 
+/* ---- Step-invariant text K/V cache: the to_k / to_v projections of encoder_hidden_states of every
+ * cross-attention (Lk > 1) are kept in plan-owned buffers.  mode 1 (keep): the next forwards compute and store them (run
+ * the first one eagerly, not under stream capture: it allocates); mode 2 (reuse): the projection GEMMs are skipped and
+ * the stored K / V^T are read -- valid while encoder_hidden_states (values, batch, length) are unchanged, which the
+ * caller guarantees; mode 0: off (default).  Results are bit-identical in all three modes. */
+int ctrl_controlnet_text_cache(ctrl_controlnet* h, int mode);
+int ctrl_adapter_text_cache(ctrl_adapter* h, int mode);
+
 /* ---- One clip split across GPUs by frames (BASELINE.json config 4 with clips < GPUs).
  * Every rank holds Fl = F / world consecutive frames of every clip: `N` = clips * Fl LOCAL frames (frame-major, rank r
  * owns frames [r*Fl, (r+1)*Fl) of each clip), num_frames = Fl.  All ops of the adapter are per frame except three, and

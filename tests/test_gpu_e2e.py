@@ -435,9 +435,13 @@ def test_clip_sharded_adapter_equals_unsharded(P, gpu, world):
     Virtual ranks = threads of this process on one GPU (each with its own plan, stream and exchange workspace; the
     transport is clip_parallel.LoopbackTransport -- the RCCL transport runs the same native code with the same
     callbacks).  Every rank runs ctrl_adapter_forward_clip_sharded on its F / world frames of both clips; gathered, the
-    results must equal the unsharded forward: the all-gathered temporal attention and the halo Conv3d are bit-exact
-    (tests/test_gpu_ops.py), only the order in which the clip-wide GroupNorm sums are added differs (per-rank partials
-    then ranks), i.e. ~1e-7 on the statistics -> isolated fp16 operand flips -> <= 1e-4 rel-inf on fp32 outputs."""
+    results must reproduce the unsharded forward.  The frame-mixing kernels are bit-exact given exact exchanges
+    (tests/test_gpu_ops.py::test_frame_sharded_temporal_ops_are_bit_exact); what differs end to end is fp32 summation order
+    -- the clip-wide GroupNorm sums (per-rank partials, then ranks) and the GEMM tile / split-K configuration the smaller
+    per-rank M selects (slots whose configuration does not change come out bit-identical) -- which moves isolated fp16
+    operand roundings: the same effect as running the unsharded forward at another batch size (2e-3 allowed there,
+    test_full_size_sdxl_vs_oracle_and_batch_properties).  Asserted: <= 5e-4 against the unsharded forward and <= 1e-3
+    against the fp32 oracle, like every other adapter result."""
     from ctrl_adapter_amd.clip_parallel import LoopbackWorld, run_virtual_ranks, shard_frames, unshard_frames
     from oracle.adapter import ControlNetAdapterOracle
     torch.set_grad_enabled(False)
@@ -464,10 +468,52 @@ def test_clip_sharded_adapter_equals_unsharded(P, gpu, world):
     got_mid = unshard_frames([res[r][1] for r in range(world)], F_)
     errs = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ref) + [ref_mid])]
     print("PARITY clip-sharded (%d ranks x %d frames) vs unsharded rel_inf: %s" % (world, F_ // world, " ".join("%.1e" % e for e in errs)))
-    assert max(errs) <= 1e-4
-    if world == 2:       # and against the oracle directly
-        oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=33)
-        ro, rom = oa(downs, mid_block_res_sample=mid, num_frames=F_, timestep=t, encoder_hidden_states=e_img)
-        eo = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ro) + [rom])]
-        print("PARITY clip-sharded (2 ranks) vs oracle rel_inf: " + " ".join("%.2e" % e for e in eo))
-        assert max(eo) <= TOL_ADAPTER
+    assert max(errs) <= 5e-4
+    oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=33)
+    ro, rom = oa(downs, mid_block_res_sample=mid, num_frames=F_, timestep=t, encoder_hidden_states=e_img)
+    eo = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ro) + [rom])]
+    print("PARITY clip-sharded (%d ranks) vs oracle rel_inf: %s" % (world, " ".join("%.2e" % e for e in eo)))
+    assert max(eo) <= TOL_ADAPTER
+
+
+def test_text_kv_cache_and_discard_when_off(P, controlnet, gpu):
+    """`cache_text` keeps the to_k / to_v projections of the text states of every cross-attention in
+    the plans and re-uses them while the same, unmodified encoder_hidden_states tensors come back (bit-identical results,
+    32 small GEMM launches fewer per SDXL step); an in-place write or another tensor recomputes.  `discard_when_off`
+    skips the adapter on steps whose residuals the SDXL pipeline discards."""
+    torch.set_grad_enabled(False)
+    inp = cases.controlnet_inputs(N=2, hs=8, seed=1500)
+    sample, ehs, cond = inp["sample"].half().to(gpu), inp["encoder_hidden_states"].half().to(gpu), inp["controlnet_cond"].half().to(gpu)
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+    ehs_a = seeded_tensor((2, 77, 2048), 1501).half().to(gpu)
+    ts = [torch.tensor(999.0), torch.tensor(749.0), torch.tensor(499.0)]
+
+    def run(t):
+        d, m = controlnet(sample, t, ehs, cond, return_dict=False)
+        o, _ = ad(d, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+        return list(d) + [m] + list(o)
+    ref = [run(t) for t in ts]
+    from ctrl_adapter_amd import ops
+    controlnet.cache_text = ad.cache_text = True
+    try:
+        with ops.Profiler() as p0:
+            got0 = run(ts[0])                         # keep
+        with ops.Profiler() as p1:
+            got1 = run(ts[1])                         # reuse
+        got2 = run(ts[2])                             # reuse
+        for g, r in zip((got0, got1, got2), ref):
+            assert all(torch.equal(a, b) for a, b in zip(g, r))
+        n0, n1 = len(p0.launches), len(p1.launches)
+        print("PARITY text K/V cache: bit-identical; launches per step %d -> %d" % (n0, n1))
+        assert n1 <= n0 - 2 * (7 + 9)                 # 7 ControlNet + 9 adapter cross-attentions, K and V^T GEMM each
+        ehs_a.mul_(0.5)                               # in-place change: version counter invalidates the adapter's cache
+        got = run(ts[0])
+        ad.cache_text = False
+        want = run(ts[0])
+        assert all(torch.equal(a, b) for a, b in zip(got, want)) and not torch.equal(got[13], ref[0][13])
+    finally:
+        controlnet.cache_text = ad.cache_text = False
+    assert all(torch.equal(a, b) for a, b in zip(run(ts[1])[:13], ref[1][:13]))      # cache off again: same results
+    (zd, zm), (zo, zmid) = P.controlled_step(controlnet, ad, sample, ts[0], ehs, cond, 0, adapter_encoder_hidden_states=ehs_a,
+                                             num_frames=1, discard_when_off=True)
+    assert zo is None and zmid is None and all(x.abs().max().item() == 0.0 for x in list(zd) + [zm])
