@@ -5,3 +5,4 @@ from .controlnet import ControlNetModel, ControlNetOutput, MultiControlNetModel,
 from .ctrl_adapter import ControlNetAdapter  # noqa: F401
 from .ctrl_router import ControlNetRouter  # noqa: F401
 from .fused import controlled_step  # noqa: F401
+from .image_prep import prepare_images  # noqa: F401

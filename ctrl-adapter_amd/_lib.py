@@ -96,7 +96,7 @@ EXPORTS = [
     "ctrl_adapter_forward",
     "ctrl_adapter_forward_scatter", "ctrl_adapter_forward_clip_sharded", "ctrl_controlnet_text_cache", "ctrl_adapter_text_cache",
     "ctrl_step_forward",
-    "ctrl_router_weights", "ctrl_router_merge",
+    "ctrl_router_weights", "ctrl_router_merge", "ctrl_prepare_images",
 ]
 
 _lib = None

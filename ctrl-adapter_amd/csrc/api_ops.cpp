@@ -82,4 +82,10 @@ int ctrl_router_merge(const void* const* experts_host, const float* weights_row,
                       void* out, int dtype, size_t n, void* stream) {
     return op_weighted_merge(experts_host, weights_row, widx_host, K, out, dtype, n, S(stream));
 }
+int ctrl_prepare_images(const void* src_u8, int F, int Hin, int Win, const int32_t* hbounds, const int32_t* hk, int hks,
+                        const int32_t* vbounds, const int32_t* vk, int vks, void* tmp_u8, void* out, int out_dtype,
+                        int W, int H, int repeat, int cfg, void* stream) {
+    return op_prepare_images((const unsigned char*)src_u8, F, Hin, Win, hbounds, hk, hks, vbounds, vk, vks, (unsigned char*)tmp_u8,
+                             out, out_dtype, W, H, repeat, cfg, S(stream));
+}
 }

@@ -103,3 +103,12 @@ int op_pack_conv_w_direct(const void* w, int dtype, float* out, int Cout, int Ci
 int op_pack_linear_w(const void* w, int dtype, half_t* out, int N, int K, int geglu, hipStream_t s, int* ovf = nullptr);
 // vector -> fp32 (optional GEGLU interleave)
 int op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// Conditioning-image preparation (model/ctrl_helper.py:268-296): Pillow-exact 8-bit Lanczos resize + /255 + NCHW + repeats
+//   src uint8 [F][Hin][Win][3]; h/v bounds int32 [out][2] + weights int32 [out][ks] (null = axis not resampled);
+//   tmp uint8 [F][Hin][W][3] (horizontal pass result); out [cfg][rep*F][3][H][W] in out_dtype
+// ------------------------------------------------------------------------------------------
+int op_prepare_images(const unsigned char* src, int F, int Hin, int Win, const int* hbounds, const int* hk, int hks,
+                      const int* vbounds, const int* vk, int vks, unsigned char* tmp, void* out, int out_dtype,
+                      int W, int H, int rep, int cfg, hipStream_t s);

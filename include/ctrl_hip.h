@@ -143,6 +143,14 @@ int ctrl_op_add_rowvec(const void* x, int x_dtype, const float* v, int64_t ldv, 
                        int rows_per_img, int vmod, void* stream);
 int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w, const float* bias, void* out,
                            int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, void* stream);
+/* Conditioning-image preparation feeding the path (model/ctrl_helper.py:268-296 prepare_images = per frame diffusers
+ * VaeImageProcessor(do_convert_rgb, no normalisation).preprocess -> batch repeat -> CFG duplication), bit-exact with Pillow's
+ * 8-bit Lanczos resampling: src uint8 RGB [F][Hin][Win][3]; per resampled axis the bounds int32 [out][2] and the 22-bit
+ * fixed-point weights int32 [out][ks] of Pillow's precompute_coeffs (device; NULL when the axis keeps its size); tmp uint8
+ * [F][Hin][W][3]; out [cfg][repeat*F][3][H][W] in out_dtype, out[g][r*F + f] = frame f / 255 */
+int ctrl_prepare_images(const void* src_u8, int F, int Hin, int Win, const int32_t* hbounds, const int32_t* hk, int hks,
+                        const int32_t* vbounds, const int32_t* vk, int vks, void* tmp_u8, void* out, int out_dtype,
+                        int W, int H, int repeat, int cfg, void* stream);
 /* load-time packers */
 int ctrl_op_pack_conv_w(const void* w, int dtype, void* out, int Cout, int Cin, int taps, void* stream);
 /* weights of a split-operand convolution: [Cout][taps][2*Cin], every tap's Cin weights twice (for the hi and the lo half) */
