@@ -35,7 +35,7 @@ __device__ __forceinline__ int tile_swz(int row) {
     return ROW_CHUNKS == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-template <int D, int NW, bool BATCH>
+template <int D, int NW, bool BATCH, bool LAZY>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(AttnArgs a, const half_t* zeros) {
     constexpr int DP = (D + 31) / 32 * 32;      // padded head dim (zero filled): 64, 64, 96, 160
     constexpr int KS = (D + 15) / 16;           // k-steps of the 32x32x16 MFMA for QK^T (40 -> 3, 80 -> 5: no all-zero steps)
@@ -209,15 +209,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
                 }
         }
         // ---- online softmax (exp2 domain) ----
-        float mx = sacc[0][0];
+        float psum;
+        h8 pf[2][2];
+        auto probabilities = [&]() {
+            psum = 0.f;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * c);
-        // rescale only when some query's running maximum moved (exact: alpha == 1 otherwise); wave-uniform branch
-        if (__any(m_new != m_run)) {
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[mb][r] * c - m_run);
+                    psum += p;
+                    pf[mb][r >> 3][r & 7] = (half_t)p;
+                }
+        };
+        auto new_maximum = [&]() {
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            return fmaxf(m_run, mx * c);
+        };
+        auto rescale_to = [&](float m_new) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
 #pragma unroll
@@ -225,17 +239,26 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
             m_run = m_new;
-        }
-        float psum = 0.f;
-        h8 pf[2][2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sacc[mb][r] * c - m_run);
-                psum += p;
-                pf[mb][r >> 3][r & 7] = (half_t)p;
+        };
+        if constexpr (LAZY) {
+            // Lazy running maximum: the probabilities are taken against the maximum of an EARLIER tile and the row maximum
+            // of this tile is not computed at all, as long as nothing can overflow the fp16 P operand -- the lane's own sum
+            // of probabilities bounds every one of them.  softmax = P / l is invariant to the reference point, fp16 keeps
+            // its relative precision for P in (1, 2^14], so the result is the same to rounding; the max tree (22 VALU of
+            // ~140 per tile in a loop whose VALU time exceeds its MFMA time) only runs on the tiles that raise a row's
+            // maximum by more than 2^14 -- in practice the first tile(s).  !(x <= t) also catches the inf / nan produced
+            // against the initial -1e30.  Wave-uniform branch.
+            probabilities();
+            if (__any(!(psum <= 16384.f))) {
+                rescale_to(new_maximum());
+                probabilities();
             }
+        } else {
+            const float m_new = new_maximum();
+            // rescale only when some query's running maximum moved (exact: alpha == 1 otherwise); wave-uniform branch
+            if (__any(m_new != m_run)) rescale_to(m_new);
+            probabilities();
+        }
         l_run += psum;
 
         // ---- O^T += V^T . P^T ----
@@ -276,14 +299,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
 
 const half_t* attn_zero_page() { return (const half_t*)device_zero_page(); }
 
-template <int D, int NW, bool BATCH>
-int launch_attn(const AttnArgs& a, hipStream_t s) {
+template <int D, int NW, bool BATCH, bool LAZY>
+int launch_attn2(const AttnArgs& a, hipStream_t s) {
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr size_t smem = (size_t)3 * 2 * 64 * DP * sizeof(half_t);
     static bool attr_done[kMaxDevices] = {};
     const int dev = cur_device();
     if (!attr_done[dev]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D, NW, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D, NW, BATCH, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done[dev] = true;
     }
     const half_t* zeros = attn_zero_page();
@@ -292,9 +315,16 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
     dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
     PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
     prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
-    prof_symbol("flash_attn_kernel<%d, %d, %s>", D, NW, BATCH ? "true" : "false");
-    LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH>), grid, dim3(NW * 64), smem, s, a, zeros);
+    prof_symbol("flash_attn_kernel<%d, %d, %s, %s>", D, NW, BATCH ? "true" : "false", LAZY ? "true" : "false");
+    LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH, LAZY>), grid, dim3(NW * 64), smem, s, a, zeros);
     return 0;
+}
+
+// CTRL_ATTN_EXACT_MAX=1 selects the textbook form (row maximum of every tile) for A/B measurements
+template <int D, int NW, bool BATCH>
+int launch_attn(const AttnArgs& a, hipStream_t s) {
+    static const bool exact = getenv("CTRL_ATTN_EXACT_MAX") && atoi(getenv("CTRL_ATTN_EXACT_MAX")) != 0;
+    return exact ? launch_attn2<D, NW, BATCH, false>(a, s) : launch_attn2<D, NW, BATCH, true>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------

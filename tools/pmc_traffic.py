@@ -33,9 +33,10 @@ def symbol_of(name):
     if m:
         g = m.groups()
         return "igemm_kernel<%s, %s, %s, %s, %s, %s, %s, %s>" % (g[:7] + ("true" if g[7] == "1" else "false",))
-    m = re.search(r"flash_attn_kernelILi(\d+)ELi(\d+)ELb([01])E", name)
+    m = re.search(r"flash_attn_kernelILi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
     if m:
-        return "flash_attn_kernel<%s, %s, %s>" % (m.group(1), m.group(2), "true" if m.group(3) == "1" else "false")
+        tf = lambda v: "true" if v == "1" else "false"
+        return "flash_attn_kernel<%s, %s, %s, %s>" % (m.group(1), m.group(2), tf(m.group(3)), tf(m.group(4)))
     m = re.search(r"((?:igemm|flash_attn)_kernel<[^>]*>)", name)
     if m:
         return re.sub(r",\s*", ", ", m.group(1))
