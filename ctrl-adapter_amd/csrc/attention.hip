@@ -320,11 +320,13 @@ int launch_attn2(const AttnArgs& a, hipStream_t s) {
     return 0;
 }
 
-// CTRL_ATTN_EXACT_MAX=1 selects the textbook form (row maximum of every tile) for A/B measurements
+// The lazy-maximum form is opt-in (CTRL_ATTN_LAZY_MAX=1): measured on MI355X at B8 h5 L16384 it LOSES to the textbook form,
+// 786 vs 880 TFLOP/s (profiles/r02_attention_lazy_max.md) -- taking the decision needs all 32 probabilities of the tile,
+// which serialises the exponentials in front of the P.V MFMAs that the textbook form lets hipcc interleave with them.
 template <int D, int NW, bool BATCH>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
-    static const bool exact = getenv("CTRL_ATTN_EXACT_MAX") && atoi(getenv("CTRL_ATTN_EXACT_MAX")) != 0;
-    return exact ? launch_attn2<D, NW, BATCH, false>(a, s) : launch_attn2<D, NW, BATCH, true>(a, s);
+    static const bool lazy = getenv("CTRL_ATTN_LAZY_MAX") && atoi(getenv("CTRL_ATTN_LAZY_MAX")) != 0;
+    return lazy ? launch_attn2<D, NW, BATCH, true>(a, s) : launch_attn2<D, NW, BATCH, false>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------

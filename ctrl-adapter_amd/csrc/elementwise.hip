@@ -1,6 +1,7 @@
 // Layout conversion, pooling, embeddings, small-M linears, blends, router softmax / merge and the
 // load-time weight packers (gfx950).  All HBM- or latency-bound helper kernels of the hot path.
 #include "ops.h"
+#include <algorithm>
 
 namespace {
 
@@ -123,6 +124,54 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
             float v = r + (b ? b[n] : 0.f);
             if (out_silu) v = silu_f(v);
             out[(size_t)(m0 + i) * ldo + n] = v;
+        }
+    }
+}
+
+// Grouped form: up to kSmallGroup independent small-M linears in ONE launch (block -> problem by a scan of the block
+// prefix).  The adapter's time / frame-index embedding MLPs, per-layer time projections and single-key cross-attention
+// vectors depend on (timestep, encoder states) only: ~10 such linears per adapter block, ~130 per video forward, are
+// gathered into one launch per dependency level at the start of the forward (plan_adapter.cpp:precompute_small).
+__global__ __launch_bounds__(256) void linear_small_group_kernel(SmallLinGroup g) {
+    int p = 0;
+#pragma unroll 1
+    while (p + 1 < g.count && (int)blockIdx.x >= g.blk_begin[p + 1]) ++p;
+    const SmallLin q = g.p[p];
+    const int blk = blockIdx.x - g.blk_begin[p];
+    const int nbn = (q.N + 3) >> 2;
+    const int bm = blk / nbn, bn = blk - bm * nbn;
+    constexpr int MT = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = bn * 4 + wave;
+    if (n >= q.N) return;
+    const int m0 = bm * MT;
+    float acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = 0.f;
+    const half_t* wp = q.w + (size_t)n * q.K;
+    for (int k = lane * 8; k < q.K; k += 512) {
+        const h8 wv = *(const h8*)(wp + k);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (m0 + i < q.M) {
+                const float* xp = q.x + (size_t)(m0 + i) * q.ldx + k;
+                const f4 a0 = *(const f4*)xp, a1 = *(const f4*)(xp + 4);
+                float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xx = q.in_silu ? silu_f(xv[j]) : xv[j];
+                    acc[i] += xx * (float)wv[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const float r = wave_sum(acc[i]);
+        if (lane == 0 && m0 + i < q.M) {
+            float v = r + (q.b ? q.b[n] : 0.f);
+            if (q.out_silu) v = silu_f(v);
+            q.out[(size_t)(m0 + i) * q.ldo + n] = v;
         }
     }
 }
@@ -321,6 +370,24 @@ int op_linear_small(const float* x, long ldx, const half_t* w, const float* b, f
     LAUNCH("linear_small", linear_small_kernel<8>, grid, dim3(256), 0, s, x, ldx, w, b, out, ldo, M, N, K, in_silu, out_silu);
     return 0;
 }
+int op_linear_small_group(const SmallLin* probs, int count, hipStream_t s) {
+    for (int base = 0; base < count; base += kSmallGroup) {
+        SmallLinGroup g;
+        g.count = std::min(kSmallGroup, count - base);
+        int blocks = 0;
+        for (int i = 0; i < g.count; ++i) {
+            const SmallLin& q = probs[base + i];
+            CTRL_CHECK(q.K % 8 == 0 && q.ldx % 4 == 0 && q.M >= 1 && q.N >= 1, "linear_small_group: K must be a multiple of 8");
+            g.p[i] = q;
+            g.blk_begin[i] = blocks;
+            blocks += ((q.N + 3) / 4) * ((q.M + 7) / 8);
+        }
+        prof_detail("%d problems", g.count);
+        LAUNCH("linear_small", linear_small_group_kernel, dim3(blocks), dim3(256), 0, s, g);
+    }
+    return 0;
+}
+
 int op_blend(const void* xs, int xs_dt, const void* xt, int xt_dt, const float* mix, void* y, int y_dt, size_t n, hipStream_t s) {
     CTRL_CHECK(n % 8 == 0, "blend: element count must be a multiple of 8");
     CTRL_CHECK(xs_dt != DT_BF16 && xt_dt != DT_BF16 && y_dt != DT_BF16, "blend: fp16 / fp32 only");

@@ -72,6 +72,11 @@ int op_frameidx_sincos(float* out, int N, int F, int dim, hipStream_t s);
 //   in_silu: apply SiLU to x on load; out_silu: apply SiLU to the result
 int op_linear_small(const float* x, long ldx, const half_t* w, const float* b, float* out, long ldo,
                     int M, int N, int K, int in_silu, int out_silu, hipStream_t s);
+// grouped form: `count` independent small-M linears, kSmallGroup per launch
+struct SmallLin { const float* x; long ldx; const half_t* w; const float* b; float* out; long ldo; int M, N, K, in_silu, out_silu; };
+constexpr int kSmallGroup = 40;
+struct SmallLinGroup { SmallLin p[kSmallGroup]; int blk_begin[kSmallGroup]; int count; };
+int op_linear_small_group(const SmallLin* probs, int count, hipStream_t s);
 // y[m][c] = a*x1[m][c] + b*x2[m][c]   (AlphaBlender; a=alpha, b=1-alpha read from device: alpha=sigmoid(*mix))
 int op_blend(const void* x_spatial, int xs_dt, const void* x_temporal, int xt_dt, const float* mix_factor, void* y, int y_dt, size_t n, hipStream_t s);
 // y[m][c] = x[m][c] + v[(m / rows_per_img) % vmod][c]   (fp32 per-image vector broadcast add)

@@ -172,15 +172,84 @@ int halo_exchange_frames(Ctx& cx, half_t* np, const AFwd& a, int HW, int C) {
     return 0;
 }
 
+// Everything of a block that depends on (timestep, encoder states, frame index) only -- the time / frame-index embedding
+// MLPs, the per-layer time projections, the single-key cross-attention vectors -- is computed for ALL blocks at the start of
+// the forward, one grouped launch per dependency level (instead of ~10 small-M launches inside every block)
+struct BlockPre {
+    float* temb = nullptr;                 // resnet_time_embedding(t) [N][C]
+    float* femb = nullptr;                 // transformer_time_embedding(frame index) [F][512]
+    std::vector<float*> sres_tp, tres_tp;  // per layer: time_emb_proj(SiLU(temb)) [N][C]
+    std::vector<float*> stb_ov, ttb_ov;    // per layer: to_out(to_v(context)) of the one-key cross-attentions
+};
+
+int precompute_small(Ctx& cx, const ctrl_adapter_config& c, const std::vector<const AdapterBlockW*>& blocks, const AFwd& a,
+                     std::vector<BlockPre>* pre) {
+    const bool sr = c.add_spatial_resnet, tr = c.add_temporal_resnet, st = c.add_spatial_transformer, tt = c.add_temporal_transformer;
+    const int N = a.N, Fe = a.comm ? a.Fg : a.F;
+    pre->assign(blocks.size(), BlockPre());
+    std::vector<SmallLin> L1, L2, L3;
+    float* ts_by_c[3] = {nullptr, nullptr, nullptr};     // sinusoids shared by the blocks of one width (320 / 640 / 1280)
+    float* fs_by_c[3] = {nullptr, nullptr, nullptr};
+    auto cidx = [](int C) { return C == 320 ? 0 : (C == 640 ? 1 : 2); };
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        const AdapterBlockW& b = *blocks[bi];
+        BlockPre& P = (*pre)[bi];
+        const int C = b.C, ci = cidx(C);
+        if (sr || tr) {
+            if (!ts_by_c[ci]) {
+                ts_by_c[ci] = cx.f((size_t)N * C);
+                RUN(cx, op_timestep_sincos(a.t, a.t_count, ts_by_c[ci], N, C, cx.s));
+            }
+            float* t1 = cx.f((size_t)N * C);
+            P.temb = cx.f((size_t)N * C);
+            L1.push_back({ts_by_c[ci], C, b.rte1.w, b.rte1.b, t1, C, N, C, C, 0, 1});
+            L2.push_back({t1, C, b.rte2.w, b.rte2.b, P.temb, C, N, C, C, 0, 0});
+        }
+        if (tt) {
+            if (!fs_by_c[ci]) {
+                fs_by_c[ci] = cx.f((size_t)Fe * C);
+                RUN(cx, op_frameidx_sincos(fs_by_c[ci], Fe, Fe, C, cx.s));
+            }
+            float* f1 = cx.f((size_t)Fe * INNER);
+            P.femb = cx.f((size_t)Fe * INNER);
+            L1.push_back({fs_by_c[ci], C, b.tte1.w, b.tte1.b, f1, INNER, Fe, INNER, C, 0, 1});
+            L2.push_back({f1, INNER, b.tte2.w, b.tte2.b, P.femb, INNER, Fe, INNER, INNER, 0, 0});
+        }
+        for (const AdapterLayerW& Lw : b.layers) {
+            if (sr) {
+                float* tp = cx.f((size_t)N * C);
+                P.sres_tp.push_back(tp);
+                L3.push_back({P.temb, C, Lw.sres_temb.w, Lw.sres_temb.b, tp, C, N, C, C, 1, 0});
+            }
+            if (tr) {
+                float* tp = cx.f((size_t)N * C);
+                P.tres_tp.push_back(tp);
+                L3.push_back({P.temb, C, Lw.tres.temb.w, Lw.tres.temb.b, tp, C, N, C, C, 1, 0});
+            }
+            auto one_key = [&](const AttnW& w, const EhsCtx& e, std::vector<float*>* dst) {
+                float* v = cx.f((size_t)e.batch * w.inner);
+                float* o = cx.f((size_t)e.batch * INNER);
+                L1.push_back({e.f32, e.cross, w.v.w, nullptr, v, w.inner, e.batch, w.inner, e.cross, 0, 0});
+                L2.push_back({v, w.inner, w.out.w, w.out.b, o, INNER, e.batch, INNER, w.inner, 0, 0});
+                dst->push_back(o);
+            };
+            if (st && a.e.Lk == 1) one_key(Lw.stb.attn2, a.e, &P.stb_ov);
+            if (tt) one_key(Lw.ttb.attn2, a.e_first, &P.ttb_ov);
+        }
+    }
+    if (!L1.empty()) RUN(cx, op_linear_small_group(L1.data(), (int)L1.size(), cx.s));
+    if (!L2.empty()) RUN(cx, op_linear_small_group(L2.data(), (int)L2.size(), cx.s));
+    if (!L3.empty()) RUN(cx, op_linear_small_group(L3.data(), (int)L3.size(), cx.s));
+    return 0;
+}
+
 // temporal ResNet on frame-major rows [(b f) hw][C]
 // blend_mix (optional): AlphaBlender fold -- out = a*x + (1-a)*TemporalResnet(x), a = sigmoid(*blend_mix); the spatial
 // branch of the blender IS this block's input (adapter_spatial_temporal.py:226-229), so the last conv's epilogue does it
 int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, const AFwd& a, int HW, int C,
-                        const float* temb /*[N][C]*/, const float* blend_mix) {
+                        const float* tp /*[N][C]: time_emb_proj(SiLU(temb)), precompute_small*/, const float* blend_mix) {
     const size_t mk = cx.mark();
     const int N = a.N, M = N * HW;
-    float* tp = cx.f((size_t)N * C);
-    RUN(cx, op_linear_small(temb, C, w.temb.w, w.temb.b, tp, C, N, C, C, 1, 0, cx.s));
     // frame-sharded clip: the conv operand is padded by one halo frame slot on each side of every clip's local frames
     half_t* n1 = cx.h(a.comm ? (size_t)a.B * (a.F + 2) * HW * C : (size_t)M * C);
     if (a.comm) {
@@ -216,7 +285,7 @@ int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, 
 // TemporalBasicTransformerBlock on frame-major tokens X [(b f) L][512]; every op but the attention is per token
 // blend_mix / blend_other (optional): out = a*blend_other + (1-a)*block(X), folded into the last GEMM's epilogue
 int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, const AFwd& a, int L,
-                    const float* blend_mix, const TV& blend_other) {
+                    const float* blend_mix, const TV& blend_other, const float* ov /*one-key cross-attention vector*/) {
     const size_t mk = cx.mark();
     const int M = a.N * L, dim = w.dim, Ci = w.attn1.inner;
     // x = ff_in(norm_in(x)) + x
@@ -263,11 +332,7 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
     // (note N5), added by the out-projection's epilogue.  Rows are (b f p) and the context is the broadcast vector or
     // the first frame of the only clip: the same vector for every row.
     TV x2 = stream_alloc(cx, (size_t)M * dim, false);
-    {
-        float* ov = nullptr;
-        TRY(single_key_vector(cx, w.attn2, dim, a.e_first, &ov));
-        TRY(run_linear(cx, w.attn1.out, o, Ci, x2, dim, M, x0, dim, ov, dim, M));
-    }
+    TRY(run_linear(cx, w.attn1.out, o, Ci, x2, dim, M, x0, dim, ov, dim, M));
     // x = ff(norm3(x)) + x
     TRY(run_layernorm(cx, w.norm3, x2, xn, M, dim));
     half_t* mid2 = mid;
@@ -278,8 +343,8 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
 }
 
 // one AdapterSpatioTemporal block: in NCHW [N][C][h][w] (in_dt) -> out NCHW [N][C][h*up][w*up] (out_dt)
-int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, const AFwd& a, const void* in, void* out,
-              int h, int w) {
+int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, const AFwd& a, const BlockPre& pre,
+              const void* in, void* out, int h, int w) {
     const size_t mk = cx.mark();
     const int N = a.N, C = b.C;
     const bool sr = c.add_spatial_resnet, tr = c.add_temporal_resnet, st = c.add_spatial_transformer, tt = c.add_temporal_transformer;
@@ -288,27 +353,11 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
     RUN(cx, op_nchw_to_nhwc(in, a.in_dt, x0, N, C, h * w, cx.s));
     TV x = tv16(x0);
     int H = h, W = w;
-    // resnet time embedding (:206-209): Timesteps(C) -> Linear -> SiLU -> Linear ; identical for every layer
-    float* temb = nullptr;
-    if (sr || tr) {
-        float* ts = cx.f((size_t)N * C);
-        RUN(cx, op_timestep_sincos(a.t, a.t_count, ts, N, C, cx.s));
-        float* t1 = cx.f((size_t)N * C);
-        RUN(cx, op_linear_small(ts, C, b.rte1.w, b.rte1.b, t1, C, N, C, C, 0, 1, cx.s));
-        temb = cx.f((size_t)N * C);
-        RUN(cx, op_linear_small(t1, C, b.rte2.w, b.rte2.b, temb, C, N, C, C, 0, 0, cx.s));
-    }
-    float* femb = nullptr;     // frame-index embedding [F][512] (:259-266)
-    if (tt) {
-        const int Fe = a.comm ? a.Fg : a.F;        // embedding of the GLOBAL frame index; a sharded rank uses its slice
-        float* fs = cx.f((size_t)Fe * C);
-        RUN(cx, op_frameidx_sincos(fs, Fe, Fe, C, cx.s));
-        float* f1 = cx.f((size_t)Fe * INNER);
-        RUN(cx, op_linear_small(fs, C, b.tte1.w, b.tte1.b, f1, INNER, Fe, INNER, C, 0, 1, cx.s));
-        femb = cx.f((size_t)Fe * INNER);
-        RUN(cx, op_linear_small(f1, INNER, b.tte2.w, b.tte2.b, femb, INNER, Fe, INNER, INNER, 0, 0, cx.s));
-        if (a.comm) femb += (size_t)a.comm->rank * a.F * INNER;
-    }
+    // resnet time embedding (:206-209) and frame-index embedding (:259-266): precompute_small
+    const float* temb = pre.temb;
+    const float* femb = pre.femb;
+    if (femb && a.comm) femb += (size_t)a.comm->rank * a.F * INNER;      // a sharded rank uses its slice of the global frames
+    (void)temb;
     const size_t nl = b.layers.size();
     for (size_t i = 0; i < nl; ++i) {
         const AdapterLayerW& Lw = b.layers[i];
@@ -317,8 +366,7 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
         // an fp16 copy of the layer's resnet output is needed only when nothing but a layout change follows it
         const bool need16 = !has_tf;
         if (sr) {
-            float* tp = cx.f((size_t)N * C);
-            RUN(cx, op_linear_small(temb, C, Lw.sres_temb.w, Lw.sres_temb.b, tp, C, N, C, C, 1, 0, cx.s));
+            const float* tp = pre.sres_tp[i];
             TV y = stream_alloc(cx, (size_t)N * H * up * W * up * C, need16 && !tr);
             TRY(run_resnet(cx, Lw.sres, x, y, N, H, W, up, tp, C, 1e-6f));
             x = y; H *= up; W *= up;
@@ -329,7 +377,7 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             // with a spatial ResNet in front the AlphaBlender (:229) is folded into the temporal block's last conv
             TV yt = stream_alloc(cx, (size_t)N * H * W * C, false);
             if (need16) yt = tv16(cx.h((size_t)N * H * W * C));       // only a layout change follows: fp16 is enough
-            TRY(run_temporal_resnet(cx, Lw.tres, x, yt, a, H * W, C, temb, sr ? Lw.res_mix : nullptr));
+            TRY(run_temporal_resnet(cx, Lw.tres, x, yt, a, H * W, C, pre.tres_tp[i], sr ? Lw.res_mix : nullptr));
             x = yt;
         }
         if (has_tf) {
@@ -341,7 +389,7 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             TV smix;
             if (st) {
                 TV t2 = stream_alloc(cx, (size_t)M * INNER, !tt);      // proj_out operand when no temporal block follows
-                TRY(run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e));
+                TRY(run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e, a.e.Lk == 1 ? pre.stb_ov[i] : nullptr));
                 tok = t2; smix = t2;
             }
             if (tt) {
@@ -351,11 +399,11 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
                     // AlphaBlender (:282) folded into the temporal block's last GEMM; the blended tokens are consumed
                     // only as proj_out's operand: fp16
                     TV t5 = tv16(cx.h((size_t)M * INNER));
-                    TRY(run_temporal_tb(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix));
+                    TRY(run_temporal_tb(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix, pre.ttb_ov[i]));
                     tok = t5;
                 } else {
                     TV t4 = stream_alloc(cx, (size_t)M * INNER, true);
-                    TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV()));
+                    TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV(), pre.ttb_ov[i]));
                     tok = t4;
                 }
             }
@@ -491,6 +539,13 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     static const int slot_c[12] = {320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280};
     static const int slot_f[12] = {1, 1, 1, 2, 2, 2, 4, 4, 4, 8, 8, 8};
     const int up = c.backbone_sdxl ? 2 : 1;
+    // ---- everything that depends on (timestep, context, frame index) only, for all blocks, before the lanes fork ----
+    const bool run_mid = w.has_mid && k.ins[12] && k.outs[12];
+    std::vector<const AdapterBlockW*> all_blocks;
+    for (const AdapterBlockW& b : w.blocks) all_blocks.push_back(&b);
+    if (run_mid) all_blocks.push_back(&w.mid);
+    std::vector<BlockPre> pre;
+    TRY(precompute_small(cx, c, all_blocks, a, &pre));
     // ---- lanes: one per pyramid level (slot_f = 1, 2, 4, 8 + mid); each lane owns a disjoint workspace region ----
     const int nl = k.nlanes;
     ctrl_adapter* P = k.plan;
@@ -507,12 +562,12 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
         for (int l = 1; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(P->side[l - 1], P->fork_ev, 0));
     }
     auto lane_of = [&](int f) { const int l = f == 1 ? 0 : (f == 2 ? 1 : (f == 4 ? 2 : 3)); return l % nl; };
-    auto run_in_lane = [&](int lane, int slot, const AdapterBlockW& bw, const void* in, void* out, int h, int wd, size_t frame_elems) -> int {
+    auto run_in_lane = [&](int lane, int slot, const AdapterBlockW& bw, const BlockPre& bp, const void* in, void* out, int h, int wd, size_t frame_elems) -> int {
         cx.s = lane == 0 ? main_s : P->side[lane - 1];
         if (!cx.dry && k.in_ev) HIP_TRY(hipStreamWaitEvent(cx.s, k.in_ev[slot], 0));     // fused step: producer still running
         cx.ar->off = lane_base[lane];
         if (cx.dry) cx.ar->peak = lane_base[lane];
-        TRY(run_block(cx, bw, c, a, in, out, h, wd));
+        TRY(run_block(cx, bw, c, a, bp, in, out, h, wd));
         TRY(fill_holes(out, frame_elems));
         if (cx.dry) {
             const size_t need = (cx.ar->peak - lane_base[lane] + 255) & ~(size_t)255;
@@ -526,16 +581,16 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
         const int h = std::max(k.H0 / slot_f[i], 1), wd = std::max(k.W0 / slot_f[i], 1);
         const bool has = bi < w.slot_ids.size() && w.slot_ids[bi] == i;
         if (has) {
-            TRY(run_in_lane(lane_of(slot_f[i]), i, w.blocks[bi], k.ins[i], k.outs[i], h, wd, (size_t)slot_c[i] * h * up * wd * up));
+            TRY(run_in_lane(lane_of(slot_f[i]), i, w.blocks[bi], pre[bi], k.ins[i], k.outs[i], h, wd, (size_t)slot_c[i] * h * up * wd * up));
             ++bi;
         } else {
             // torch.zeros_like(down_block_res_samples[i])  (ctrl_adapter.py:193): input-sized, not up-sampled
             RUN(cx, op_fill_zero(k.outs[i], (size_t)k.N_out * slot_c[i] * h * wd * dt_size(k.out_dt), cx.s));
         }
     }
-    if (w.has_mid && k.ins[12] && k.outs[12]) {
+    if (run_mid) {
         const int h = std::max(k.H0 / 8, 1), wd = std::max(k.W0 / 8, 1);
-        TRY(run_in_lane(lane_of(8), 12, w.mid, k.ins[12], k.outs[12], h, wd, (size_t)1280 * h * up * wd * up));
+        TRY(run_in_lane(lane_of(8), 12, w.mid, pre.back(), k.ins[12], k.outs[12], h, wd, (size_t)1280 * h * up * wd * up));
     }
     if (!cx.dry && nl > 1) {
         for (int l = 1; l < nl; ++l) {

@@ -251,7 +251,7 @@ static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const
     return 0;
 }
 
-int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e) {
+int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e, const float* ov_pre) {
     CTRL_CHECK(e.batch == 1 || e.batch == B, "encoder_hidden_states batch must be 1 or equal to the sample batch");
     const size_t mk = cx.mark();
     const int M = B * L, dim = w.dim;
@@ -261,8 +261,8 @@ int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, 
     if (e.Lk == 1) {
         // x2 = X + attn1(norm1 X) + to_out(to_v(ctx)): the query-independent cross-attention term rides on the self-
         // attention's out-projection epilogue (per-image vector; one vector for all rows when the context is broadcast)
-        float* ov = nullptr;
-        TRY(single_key_vector(cx, w.attn2, dim, e, &ov));
+        float* ov = const_cast<float*>(ov_pre);
+        if (!ov) TRY(single_key_vector(cx, w.attn2, dim, e, &ov));
         TRY(run_self_attn(cx, w.attn1, xn, dim, X, x2, B, L, ov, e.batch == 1 ? M : L));
     } else {
         TV x1 = stream_alloc(cx, (size_t)M * dim, false);
