@@ -22,6 +22,7 @@
 // layout (row-major slice, or transposed [img][C][tokens] for NCHW results / the V^T attention operand).
 #include "ops.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -34,8 +35,12 @@ __device__ __forceinline__ int chunk_swz(int row) {
     return (0 - (row >> 2)) & 3;                   // 64-B rows: 4 rows per bank line; {0,3,2,1} keeps mixed-chunk groups apart
 }
 
+// 128x256 / 256x128 tiles of 8 waves keep two workgroups resident per CU (72 KiB of LDS ring, <= 128 VGPRs per wave): one
+// workgroup's epilogue (HBM-bound fp32 stream traffic, GEGLU math) overlaps the other one's k-loop
+template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (NW == 8 && (BM * BN == 128 * 256 || BM * BN == 128 * 320)) ? 4 : 1; };
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // per-wave tile
@@ -728,6 +733,25 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
         if (sk > 1 && (size_t)a.splitk_ws_bytes >= (size_t)sk * a.M * a.Nout * sizeof(float) && (((uintptr_t)a.splitk_ws & 15) == 0)) {
             if (a.Nout % 320 == 0) return launch_cfg2<256, 320, 32, 2, 4, 4, MODE, true>(a, s, sk);
             return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
+        }
+    }
+    if (const char* f = getenv("CTRL_IGEMM_FORCE")) {      // tile experiments (tools/tile_experiment.py), row outputs only
+        if (can_swap(a) && MODE == IG_ROWS) {
+            if (!strcmp(f, "128x256")) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
+            if (!strcmp(f, "256x128")) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
+            if (!strcmp(f, "128x320") && a.Nout % 320 == 0 && !a.geglu) return launch_cfg2<128, 320, 32, 2, 4, 2, MODE, true>(a, s);
+        }
+    }
+    // Epilogue-heavy token GEMMs at large M (measured, tools/tile_experiment.py -> profiles/r02_tile_experiment.log): two
+    // resident workgroups per CU let one's epilogue -- the GEGLU math, or the HBM-bound fp32 residual read + fp32 master +
+    // fp16 mirror write of a stream update -- run under the other's k-loop.  GEGLU 512->4096 at M = 131072: 562 -> 677
+    // TFLOP/s (256x128); stream updates K = 320: 182 -> 217 (128x256), K = 2048: 551 -> 603 (256x128).
+    if (MODE == IG_ROWS && a.M >= 65536 && can_swap(a) && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && a.Nout % 128 == 0) {
+        const bool f32_stream = a.seg[0].dtype == DT_F32;
+        if (a.geglu && a.Nout % 256 == 0) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
+        if (f32_stream && a.Nout % 256 == 0) {
+            if (a.Ktot > 1024) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
+            return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
         }
     }
     // (vector-epilogue variant only: the scalar-epilogue one does not fit the register file at this tile size)

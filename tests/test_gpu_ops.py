@@ -395,3 +395,25 @@ def test_frame_sharded_temporal_ops_are_bit_exact(ops, gpu):
                   F=Fl, HW=HW, t_pad=True)
         assert torch.equal(out.reshape(Bc, Fl, HW, Cc), ref[:, r * Fl:(r + 1) * Fl]), "rank %d" % r
     print("PARITY frame-sharded temporal attention / Conv3d: bit-exact vs unsharded (4 shards)")
+
+
+@pytest.mark.parametrize("K,geglu,f32", [(320, False, True), (2048, False, True), (512, True, False)])
+def test_two_workgroup_tiles_at_large_m(ops, gpu, K, geglu, f32):
+    """the 128x256 / 256x128 tiles (two workgroups per CU) the dispatcher picks for epilogue-heavy token GEMMs at
+    M >= 65536: fp32 stream update (fp32 residual in, fp32 master + fp16 mirror out) and GEGLU"""
+    M, N = 65536 + 40, (1024 if geglu else 512)
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+    wp, bp = ops.pack_linear_w(w.to(gpu), geglu=geglu), ops.pack_vec(b.to(gpu), geglu=geglu)
+    y = x @ w.t() + b
+    if geglu:
+        ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+        out = ops.linear(x.half().to(gpu), wp, bias=bp, geglu=True)
+        report("2-WG tile geglu K%d" % K, rel_inf(out, ref))
+    else:
+        r = torch.randn(M, N, generator=torch.Generator().manual_seed(4))
+        ref = y + r
+        out = torch.empty(M, N, dtype=torch.float32, device=gpu)
+        mirror = torch.empty(M, N, dtype=torch.float16, device=gpu)
+        ops.igemm(x.half().to(gpu), K, wp, M, N, K, bias=bp, res=r.to(gpu), ldres=N, segs=[(out, N, 0, N, ops.SEG_ROW, 1)], out16=mirror, ld16=N)
+        report("2-WG tile f32 stream K%d master" % K, rel_inf(out, ref), 2e-5)
+        report("2-WG tile f32 stream K%d mirror" % K, rel_inf(mirror, ref))
