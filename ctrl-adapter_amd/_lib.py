@@ -28,7 +28,7 @@ class IGemmDesc(C.Structure):
                 ("nseg", C.c_int32), ("act", C.c_int32), ("res_f32", C.c_int32), ("a_split", C.c_int32),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
                 ("out16", C.c_void_p), ("ld16", C.c_int64),
-                ("blend_mix", C.c_void_p), ("blend_x", C.c_void_p), ("ld_blend", C.c_int64), ("blend_f32", C.c_int32), ("out16_lo_off", C.c_int32),
+                ("blend_mix", C.c_void_p), ("blend_x", C.c_void_p), ("ld_blend", C.c_int64), ("blend_f32", C.c_int32), ("out16_lo_off", C.c_int32), ("scale2", C.c_float), ("scale2_from", C.c_int32),
                 ("seg", IGemmSeg * 3)]
 
 
@@ -37,7 +37,7 @@ class AttnDesc(C.Structure):
                 ("Vt", C.c_void_p), ("Lkpad", C.c_int32), ("kvB", C.c_int32),
                 ("O", C.c_void_p), ("ldo", C.c_int64),
                 ("B", C.c_int32), ("heads", C.c_int32), ("D", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("k_prescaled", C.c_int32), ("pad0_", C.c_int32)]
 
 
 class TAttnDesc(C.Structure):

@@ -35,7 +35,7 @@ __device__ __forceinline__ int tile_swz(int row) {
     return ROW_CHUNKS == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-template <int D, int NW, bool BATCH, bool LAZY>
+template <int D, int NW, bool BATCH, bool FOLD>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(AttnArgs a, const half_t* zeros) {
     constexpr int DP = (D + 31) / 32 * 32;      // padded head dim (zero filled): 64, 64, 96, 160
     constexpr int KS = (D + 15) / 16;           // k-steps of the 32x32x16 MFMA for QK^T (40 -> 3, 80 -> 5: no all-zero steps)
@@ -63,7 +63,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
     const int b = pair / a.heads, h = pair - b * a.heads;
     const int q0 = (j % qtiles) * (NW * 32) + wave * 32;
     const int Lq = a.Lq, Lk = a.Lk;
-    const float c = a.scale * 1.4426950408889634f;   // softmax in the exp2 domain
+    // softmax in the exp2 domain.  FOLD: K rows arrive pre-multiplied by scale*log2(e) (ctrl_attn_desc::k_prescaled), so the
+    // MFMA output needs no scaling, and the running maximum is subtracted by INITIALISING the QK^T accumulator with -m
+    // (a lane owns one query = one column of S^T): the MFMA pipe does the subtraction and the loop loses its 32 v_fma per
+    // tile -- it is VALU-bound at head_dim 64 (~140 VALU against 16 MFMAs per 64-key tile)
+    const float c = FOLD ? 1.0f : a.scale * 1.4426950408889634f;
 
     const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = FOLD ? 0.f : -1e30f, l_run = 0.f;
 
     const int ntiles = (Lk + 63) / 64;
 #pragma unroll
@@ -165,10 +169,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
         // ---- S^T = K . Q^T  (two 32-key blocks); all K and V^T fragment reads of the tile are issued up front so the
         //      LDS latency is paid once (K) or hidden under the softmax (V^T) ----
         f16v sacc[2];
+        const float acc0 = FOLD ? -m_run : 0.f;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[mb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) sacc[mb][r] = acc0;
         h8 vfr[4][DB];
         if constexpr (BATCH) {
             h8 kfr[KS][2];
@@ -209,10 +214,51 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
                 }
         }
         // ---- online softmax (exp2 domain) ----
-        float psum;
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float psum = 0.f;
         h8 pf[2][2];
-        auto probabilities = [&]() {
-            psum = 0.f;
+        if constexpr (FOLD) {
+            // sacc = s - m_run already; mx > 0 <=> the row maximum moved (first tile: m_run = 0 stands for "none yet" and
+            // the update is forced so that an all-negative first tile is referenced to its own maximum)
+            if (t == 0 || __any(mx > 0.f)) {        // wave-uniform
+                const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
+                const float alpha = (t == 0) ? 1.f : __builtin_amdgcn_exp2f(-d);   // t == 0: l_run = o = 0 (and 2^-d may overflow)
+                l_run *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                m_run += d;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[mb][r] -= d;
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[mb][r]);
+                    psum += p;
+                    pf[mb][r >> 3][r & 7] = (half_t)p;
+                }
+        } else {
+            const float m_new = fmaxf(m_run, mx * c);
+            // rescale only when some query's running maximum moved (exact: alpha == 1 otherwise); wave-uniform branch
+            if (__any(m_new != m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                m_run = m_new;
+            }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -221,43 +267,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
                     psum += p;
                     pf[mb][r >> 3][r & 7] = (half_t)p;
                 }
-        };
-        auto new_maximum = [&]() {
-            float mx = sacc[0][0];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            return fmaxf(m_run, mx * c);
-        };
-        auto rescale_to = [&](float m_new) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-            m_run = m_new;
-        };
-        if constexpr (LAZY) {
-            // Lazy running maximum: the probabilities are taken against the maximum of an EARLIER tile and the row maximum
-            // of this tile is not computed at all, as long as nothing can overflow the fp16 P operand -- the lane's own sum
-            // of probabilities bounds every one of them.  softmax = P / l is invariant to the reference point, fp16 keeps
-            // its relative precision for P in (1, 2^14], so the result is the same to rounding; the max tree (22 VALU of
-            // ~140 per tile in a loop whose VALU time exceeds its MFMA time) only runs on the tiles that raise a row's
-            // maximum by more than 2^14 -- in practice the first tile(s).  !(x <= t) also catches the inf / nan produced
-            // against the initial -1e30.  Wave-uniform branch.
-            probabilities();
-            if (__any(!(psum <= 16384.f))) {
-                rescale_to(new_maximum());
-                probabilities();
-            }
-        } else {
-            const float m_new = new_maximum();
-            // rescale only when some query's running maximum moved (exact: alpha == 1 otherwise); wave-uniform branch
-            if (__any(m_new != m_run)) rescale_to(m_new);
-            probabilities();
         }
         l_run += psum;
 
@@ -299,14 +308,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
 
 const half_t* attn_zero_page() { return (const half_t*)device_zero_page(); }
 
-template <int D, int NW, bool BATCH, bool LAZY>
+template <int D, int NW, bool BATCH, bool FOLD>
 int launch_attn2(const AttnArgs& a, hipStream_t s) {
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr size_t smem = (size_t)3 * 2 * 64 * DP * sizeof(half_t);
     static bool attr_done[kMaxDevices] = {};
     const int dev = cur_device();
     if (!attr_done[dev]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D, NW, BATCH, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_kernel<D, NW, BATCH, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done[dev] = true;
     }
     const half_t* zeros = attn_zero_page();
@@ -315,18 +324,16 @@ int launch_attn2(const AttnArgs& a, hipStream_t s) {
     dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
     PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
     prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
-    prof_symbol("flash_attn_kernel<%d, %d, %s, %s>", D, NW, BATCH ? "true" : "false", LAZY ? "true" : "false");
-    LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH, LAZY>), grid, dim3(NW * 64), smem, s, a, zeros);
+    prof_symbol("flash_attn_kernel<%d, %d, %s, %s>", D, NW, BATCH ? "true" : "false", FOLD ? "true" : "false");
+    LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH, FOLD>), grid, dim3(NW * 64), smem, s, a, zeros);
     return 0;
 }
 
-// The lazy-maximum form is opt-in (CTRL_ATTN_LAZY_MAX=1): measured on MI355X at B8 h5 L16384 it LOSES to the textbook form,
-// 786 vs 880 TFLOP/s (profiles/r02_attention_lazy_max.md) -- taking the decision needs all 32 probabilities of the tile,
-// which serialises the exponentials in front of the P.V MFMAs that the textbook form lets hipcc interleave with them.
+// k_prescaled selects the folded form (see the kernel); the plain form serves callers that hand over unscaled K.
+// (A "lazy running maximum" form was measured and dropped in round 2: profiles/r02_attention_lazy_max.md.)
 template <int D, int NW, bool BATCH>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
-    static const bool lazy = getenv("CTRL_ATTN_LAZY_MAX") && atoi(getenv("CTRL_ATTN_LAZY_MAX")) != 0;
-    return lazy ? launch_attn2<D, NW, BATCH, true>(a, s) : launch_attn2<D, NW, BATCH, false>(a, s);
+    return a.k_prescaled ? launch_attn2<D, NW, BATCH, true>(a, s) : launch_attn2<D, NW, BATCH, false>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------

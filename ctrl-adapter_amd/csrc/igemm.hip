@@ -416,8 +416,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                         for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
                     }
                 }
+                {
+                    // an 8-column chunk never straddles scale2_from (a multiple of 8, checked by op_igemm)
+                    const float sc = (a.scale2_from > 0 && ocol >= a.scale2_from) ? a.scale2 : a.scale;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] *= a.scale;
+                    for (int i = 0; i < 8; ++i) x[i] *= sc;
+                }
                 if (a.blend_mix) {   // AlphaBlender fold: (1-a) * this branch + a * the other branch
                     const float al = __builtin_amdgcn_rcpf(1.0f + __expf(-a.blend_mix[0]));
                     float bx[8];
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                 if (a.act == 1) x = silu_f(x);
                 if (Rptr && row < a.M)
                     x += a.res_f32 ? ((const float*)a.res)[(size_t)row * a.ldres + ocol] : (float)Rptr[(size_t)row * a.ldres + ocol];
-                v[i] = x * a.scale;
+                v[i] = x * ((a.scale2_from > 0 && ocol >= a.scale2_from) ? a.scale2 : a.scale);
             }
             if (sg.fmt == SEG_ROW) {
 #pragma unroll
@@ -778,6 +782,8 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "igemm: A/W must be 16-byte aligned");
     CTRL_CHECK(a.nseg >= 1 && a.nseg <= 3, "igemm: nseg must be 1..3");
     CTRL_CHECK(!a.geglu || (a.Nout % 32) == 0, "igemm: GEGLU needs Nout % 32 == 0");
+    CTRL_CHECK(a.scale2_from == 0 || (a.scale2_from % 16 == 0 && !a.geglu && !a.splitk_ws && a.seg[0].fmt == SEG_ROW),
+               "igemm: scale2_from must be a multiple of 16 on a plain row-major output");
     CTRL_CHECK(!a.out16 || (a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a)), "igemm: the fp16 mirror needs a single aligned row-major output");
     CTRL_CHECK(!a.blend_mix || (a.blend_x && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && !a.geglu && can_swap(a)),
                "igemm: the blend fold needs a single aligned row-major output and an aligned blend operand");

@@ -137,11 +137,16 @@ int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int
     return 0;
 }
 
+// softmax scale in the exp2 domain: the K projections leave their GEMM epilogue multiplied by it (one fp32 multiply before
+// the rounding to fp16 that happens anyway), see ctrl_attn_desc::k_prescaled
+static inline float attn_k_scale(int D) { return 1.4426950408889634f / sqrtf((float)D); }
+
 static int run_attention(Ctx& cx, const half_t* Q, long ldq, const half_t* K, long ldk, const half_t* Vt, int Lkpad,
                          half_t* O, long ldo, int B, int kvB, int heads, int D, int Lq, int Lk) {
     AttnArgs a = {};
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.Vt = Vt; a.Lkpad = Lkpad; a.kvB = kvB;
     a.O = O; a.ldo = ldo; a.B = B; a.heads = heads; a.D = D; a.Lq = Lq; a.Lk = Lk;
+    a.k_prescaled = 1;
     a.scale = 1.0f / sqrtf((float)D);
     RUN(cx, op_flash_attn(a, cx.s));
     return 0;
@@ -164,10 +169,12 @@ static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, con
     IGemmArgs g = {};
     g.A = xn; g.lda = dim; g.mode = IG_ROWS; g.Cin = dim; g.taps = 1;
     g.W = w.qkv.w; g.M = M; g.Nout = 2 * Ci; g.Ktot = dim; g.scale = 1.f;
+    g.scale2_from = Ci; g.scale2 = attn_k_scale(w.D);          // the K half leaves pre-scaled for the attention kernel
     g.nseg = 1;
     g.seg[0] = IGemmSeg{qk, 2 * Ci, 0, 2 * Ci, SEG_ROW, DT_F16, 1, 0};
     RUN(cx, op_igemm(g, cx.s));
     IGemmArgs gv = g;
+    gv.scale2_from = 0; gv.scale2 = 0.f;
     gv.W = w.qkv.w + (size_t)2 * Ci * dim; gv.Nout = Ci;
     gv.seg[0] = IGemmSeg{vt, Lpad, 0, Ci, SEG_TRANSPOSED, DT_F16, L, 0};
     RUN(cx, op_igemm(gv, cx.s));
@@ -223,11 +230,12 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, 
         if (e.Lk % 8) RUN(cx, op_fill_zero(vt, (size_t)e.batch * Ci * Lkpad * sizeof(half_t), cx.s));   // finite pad columns
         IGemmArgs g = {};
         g.A = e.h16; g.lda = e.cross; g.mode = IG_ROWS; g.Cin = e.cross; g.taps = 1;
-        g.W = w.kv.w; g.M = Mk; g.Nout = Ci; g.Ktot = e.cross; g.scale = 1.f;
+        g.W = w.kv.w; g.M = Mk; g.Nout = Ci; g.Ktot = e.cross; g.scale = attn_k_scale(w.D);     // pre-scaled K
         g.nseg = 1;
         g.seg[0] = IGemmSeg{k, Ci, 0, Ci, SEG_ROW, DT_F16, 1, 0};
         RUN(cx, op_igemm(g, cx.s));
         IGemmArgs gv = g;
+        gv.scale = 1.f;
         gv.W = w.kv.w + (size_t)Ci * e.cross;
         gv.seg[0] = IGemmSeg{vt, Lkpad, 0, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
         RUN(cx, op_igemm(gv, cx.s));

@@ -57,7 +57,7 @@ def pack_vec(v, geglu=False):
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
           res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None,
-          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False):
+          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False, scale2=0.0, scale2_from=0):
     """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
@@ -82,6 +82,7 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.ld_blend = ld_blend
     d.blend_f32 = int(blend_x is not None and blend_x.dtype == torch.float32)
     d.scale = scale; d.geglu = int(geglu)
+    d.scale2 = scale2; d.scale2_from = scale2_from
     d.a_split = int(a_split); d.out16_lo_off = out16_lo_off
     d.nseg = len(segs)
     for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):
@@ -121,13 +122,14 @@ def conv2d(x_nhwc, w_packed, Cout, taps=9, stride=1, up=1, bias=None, rowvec=Non
     return out
 
 
-def flash_attn(Q, ldq, K, ldk, Vt, Lkpad, B, heads, D, Lq, Lk, scale=None, kvB=0):
+def flash_attn(Q, ldq, K, ldk, Vt, Lkpad, B, heads, D, Lq, Lk, scale=None, kvB=0, k_prescaled=False):
     out = _f16(B * Lq, heads * D)
     d = L.AttnDesc()
     d.Q = Q.data_ptr(); d.ldq = ldq; d.K = K.data_ptr(); d.ldk = ldk; d.Vt = Vt.data_ptr(); d.Lkpad = Lkpad
     d.O = out.data_ptr(); d.ldo = heads * D
     d.B = B; d.heads = heads; d.D = D; d.Lq = Lq; d.Lk = Lk; d.kvB = kvB if kvB else B
     d.scale = scale if scale is not None else D ** -0.5
+    d.k_prescaled = int(k_prescaled)
     L.check(L.lib().ctrl_op_flash_attn(C.byref(d), L.cur_stream()))
     return out
 

@@ -90,6 +90,9 @@ typedef struct ctrl_igemm_desc {
      * only: out = (1-a) * y + a * blend_x[m*ld_blend + n], a = sigmoid(*blend_mix), y = the epilogue result above */
     const float* blend_mix; const void* blend_x; int64_t ld_blend; int32_t blend_f32;
     int32_t out16_lo_off;   /* > 0: the fp16 mirror is a split operand, out16[m*ld16 + n] = hi, out16[m*ld16 + out16_lo_off + n] = lo */
+    float scale2; int32_t scale2_from;   /* scale2_from > 0: output columns >= scale2_from are multiplied by scale2 instead of scale
+                                            (row-major outputs): the K half of a Q|K projection leaves pre-multiplied by
+                                            softmax_scale * log2(e) for ctrl_attn_desc::k_prescaled */
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
@@ -101,6 +104,10 @@ typedef struct ctrl_attn_desc {
     void* O; int64_t ldo;            /* [B*Lq][ldo] */
     int32_t B, heads, D, Lq, Lk;
     float scale;
+    int32_t k_prescaled;             /* K rows already hold k * scale * log2(e) (applied in fp32 by the producing GEMM's epilogue,
+                                        before the one rounding to fp16): the kernel then folds the running maximum into the
+                                        accumulator initialisation of the QK^T MFMA and exponentiates its output directly */
+    int32_t pad0_;
 } ctrl_attn_desc;
 int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream);
 

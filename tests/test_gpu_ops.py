@@ -214,6 +214,12 @@ def test_flash_attn(ops, gpu, D, heads, Lq, Lk):
     out = ops.flash_attn(q.half().reshape(B * Lq, Cc).to(gpu), Cc, k.half().reshape(B * Lk, Cc).to(gpu), Cc,
                          vt.to(gpu), Lkpad, B, heads, D, Lq, Lk)
     report("flash_attn D%d h%d Lq%d Lk%d" % (D, heads, Lq, Lk), rel_inf(out.reshape(B, Lq, Cc), ref))
+    # folded form (ctrl_attn_desc.k_prescaled): K arrives multiplied by scale*log2(e) -- the product path's form; here the
+    # pre-scaled K is rounded to fp16 a second time (the plan rounds once, in the projection's epilogue), hence the same bound
+    ks = (k * (1.4426950408889634 / math.sqrt(D))).half()
+    out2 = ops.flash_attn(q.half().reshape(B * Lq, Cc).to(gpu), Cc, ks.reshape(B * Lk, Cc).to(gpu), Cc,
+                          vt.to(gpu), Lkpad, B, heads, D, Lq, Lk, k_prescaled=True)
+    report("flash_attn folded D%d h%d Lq%d Lk%d" % (D, heads, Lq, Lk), rel_inf(out2.reshape(B, Lq, Cc), ref))
 
 
 def test_temporal_attn(ops, gpu):
