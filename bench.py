@@ -220,6 +220,26 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = dp.aggregate_throughput(1, args.steps, elapsed, world)   # whole-job denoise-steps/s (each rank: its own batch / clip)
 
+    # ---- the same step through the fused entry point (ControlNet on its own stream, adapter blocks start when their input
+    #      exists): same arithmetic, bit-identical results; reported beside the headline, never as `value` ----
+    fused = None
+    if w["n_cn"] == 1 and not args.fused and not args.no_graph:
+        try:
+            for _ in range(2):
+                step_fused()
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                static_out2 = step_fused()      # noqa: F841
+            for _ in range(args.warmup):
+                g2.replay()
+            el2 = dp.timed_region(g2.replay, args.steps, device=dev)
+            fused = {"call_form": "controlled_step(controlnet, adapter, ...)", "ms_per_step": round(el2 / args.steps * 1e3, 3),
+                     "value": round(dp.aggregate_throughput(1, args.steps, el2, world), 3)}
+        except Exception as e:
+            print("bench: fused leg skipped (%s)" % str(e).split("\n")[0], file=sys.stderr)
+            torch.cuda.synchronize()
+
     # ---- roofline leg: eager steps with HIP events around every launch, on the launch stream (lanes off) ----
     kernels, per_kernel, roof = {}, [], None
     if rank == 0:
@@ -312,7 +332,7 @@ def main():
                                     "controlled_step(controlnet, adapter, ...) = both forwards, overlapped (bit-identical results)"},
             "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
             "mfma_frac_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "per_kernel": per_kernel,
+            "fused_step": fused, "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "per_kernel": per_kernel,
         }
         print(json.dumps(line))
     import torch.distributed as dist

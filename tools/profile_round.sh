@@ -1,16 +1,20 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r01 v4
+#   bash tools/profile_round.sh r02 v1 [1 = skip the pytest parity logs]
 # Writes under gpurun_out/final/; copy what should be judged into profiles/.
 set -u
-R=${1:-r01}; V=${2:-v4}
+R=${1:-r01}; V=${2:-v4}; SKIPTESTS=${3:-0}
 O=gpurun_out/final; mkdir -p $O
 export TMPDIR=/tmp
-(python -m pytest tests/test_gpu_ops.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_op_parity_${V}.log
+if [ "$SKIPTESTS" = "0" ]; then
+(python -m pytest tests/test_gpu_ops.py tests/test_image_prep.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_op_parity_${V}.log
 (python -m pytest tests/test_gpu_e2e.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_e2e_parity_${V}.log
+fi
 python -c "import __graft_entry__ as g; g.smoke()" > $O/${R}_smoke_${V}.log 2>&1
 python bench.py > $O/${R}_bench_${V}.json 2> $O/bench.err
 python bench.py --workload svd16 --steps 10 --warmup 3 > $O/${R}_bench_svd16_${V}.json 2>> $O/bench.err
+python bench.py --workload i2vgen16 --steps 10 --warmup 3 --no-cpu-baseline > $O/${R}_bench_i2vgen16_${V}.json 2>> $O/bench.err
+python bench.py --workload multi3 --steps 10 --warmup 3 --no-cpu-baseline > $O/${R}_bench_multi3_${V}.json 2>> $O/bench.err
 timeout 300 python tools/microbench.py > $O/${R}_microbench_${V}.log 2>&1
 # per-kernel time of the same command (its own run: no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/stats.log 2>&1
