@@ -21,7 +21,11 @@ def main():
             for row in csv.DictReader(fh):
                 if kernel_class(row["Kernel_Name"]) is None:
                     continue
-                k = (symbol_of(row["Kernel_Name"]), int(row["Grid_Size"]))
+                if "Grid_Size" in row:
+                    grid = int(row["Grid_Size"])
+                else:                       # kernel-trace CSVs carry the grid per dimension (work-items)
+                    grid = int(row["Grid_Size_X"]) * int(row.get("Grid_Size_Y", 1) or 1) * int(row.get("Grid_Size_Z", 1) or 1)
+                k = (symbol_of(row["Kernel_Name"]), grid)
                 a = acc.setdefault(k, [0, 0, 1 << 62, 0])
                 ns = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
                 a[0] += 1; a[1] += ns; a[2] = min(a[2], ns); a[3] = max(a[3], ns)
