@@ -197,25 +197,11 @@ int single_key_vector(Ctx& cx, const AttnW& w, int dim, const EhsCtx& e, float**
 }
 
 // cross attention; Lk == 1 is the degenerate query-independent case (SURVEY.md note N5)
-static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, int dim, const TV& out, int B, int L,
-                          const EhsCtx& e) {
-    const size_t mk = cx.mark();
-    const int M = B * L, Ci = w.inner;
-    if (e.Lk == 1) {
-        // softmax over one key == 1  =>  out = to_out(to_v(ctx)) for every query of the image
-        float* o = nullptr;
-        TRY(single_key_vector(cx, w, dim, e, &o));
-        RUN(cx, op_add_rowvec(x.p, x.dt, o, dim, out.p, out.dt, (size_t)M, dim, L, e.batch, cx.s));
-        cx.release(mk);
-        return 0;
-    }
-    half_t* xn = cx.h((size_t)M * dim);
-    TRY(run_layernorm(cx, ln, x, xn, M, dim));
-    half_t* q = cx.h((size_t)M * Ci);
-    TRY(run_linear(cx, w.q, xn, dim, tv16(q), Ci, M, TV(), 0));
+// K and V^T of the text states (step-invariant: optionally kept in / taken from the plan's cache)
+int project_text_kv(Ctx& cx, const AttnW& w, const EhsCtx& e, PreKV* out) {
+    const int Ci = w.inner;
     const int Lkpad = (e.Lk + 63) / 64 * 64;
     const int Mk = e.batch * e.Lk;
-    // K and V^T of the text states: step-invariant, optionally kept in / taken from the plan's cache
     const bool cached = cx.kvc && cx.kvc->mode != KvCache::OFF;
     half_t* k = nullptr; half_t* vt = nullptr;
     if (cached) {
@@ -240,6 +226,31 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, 
         gv.seg[0] = IGemmSeg{vt, Lkpad, 0, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
         RUN(cx, op_igemm(gv, cx.s));
     }
+    out->k = k; out->vt = vt;
+    return 0;
+}
+
+static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, int dim, const TV& out, int B, int L,
+                          const EhsCtx& e, const PreKV* pre = nullptr) {
+    const size_t mk = cx.mark();
+    const int M = B * L, Ci = w.inner;
+    if (e.Lk == 1) {
+        // softmax over one key == 1  =>  out = to_out(to_v(ctx)) for every query of the image
+        float* o = nullptr;
+        TRY(single_key_vector(cx, w, dim, e, &o));
+        RUN(cx, op_add_rowvec(x.p, x.dt, o, dim, out.p, out.dt, (size_t)M, dim, L, e.batch, cx.s));
+        cx.release(mk);
+        return 0;
+    }
+    half_t* xn = cx.h((size_t)M * dim);
+    TRY(run_layernorm(cx, ln, x, xn, M, dim));
+    half_t* q = cx.h((size_t)M * Ci);
+    TRY(run_linear(cx, w.q, xn, dim, tv16(q), Ci, M, TV(), 0));
+    const int Lkpad = (e.Lk + 63) / 64 * 64;
+    PreKV kv;
+    if (pre) kv = *pre;
+    else TRY(project_text_kv(cx, w, e, &kv));
+    half_t* k = kv.k; half_t* vt = kv.vt;
     half_t* o = cx.h((size_t)M * Ci);
     TRY(run_attention(cx, q, Ci, k, Ci, vt, Lkpad, o, Ci, B, e.batch == 1 ? 1 : B, w.heads, w.D, L, e.Lk));
     TRY(run_linear(cx, w.out, o, Ci, out, dim, M, x, dim));
@@ -259,7 +270,8 @@ static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const
     return 0;
 }
 
-int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e, const float* ov_pre) {
+int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e, const float* ov_pre,
+                 const PreKV* kv_pre) {
     CTRL_CHECK(e.batch == 1 || e.batch == B, "encoder_hidden_states batch must be 1 or equal to the sample batch");
     const size_t mk = cx.mark();
     const int M = B * L, dim = w.dim;
@@ -275,7 +287,7 @@ int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, 
     } else {
         TV x1 = stream_alloc(cx, (size_t)M * dim, false);
         TRY(run_self_attn(cx, w.attn1, xn, dim, X, x1, B, L));
-        TRY(run_cross_attn(cx, w.attn2, w.norm2, x1, dim, x2, B, L, e));
+        TRY(run_cross_attn(cx, w.attn2, w.norm2, x1, dim, x2, B, L, e, kv_pre));
     }
     TRY(run_ff(cx, w.norm3, w.ff1, w.ff2, x2, dim, out, M));
     cx.release(mk);

@@ -437,9 +437,14 @@ int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int
                const float* temb_proj, int temb_ld, float eps);
 // Encoder-hidden-state context prepared once per forward: fp16 copy [B*Lk][cross] (+ fp32 copy when Lk == 1)
 struct EhsCtx { const half_t* h16 = nullptr; const float* f32 = nullptr; int batch = 1, Lk = 0, cross = 0; };
+// K / V^T projections of the text states of one cross-attention, computed ahead of the block that uses them (they depend
+// on encoder_hidden_states only): project_text_kv enqueues the two GEMMs on cx.s (or takes the plan's text cache)
+struct PreKV { half_t* k = nullptr; half_t* vt = nullptr; };
+int project_text_kv(Ctx& cx, const AttnW& w, const EhsCtx& e, PreKV* out);
 // X [B*L][dim] stream -> out stream (out.m16 is filled when the caller needs a GEMM-operand copy)
 // ov_pre (optional, Lk == 1 only): the single-key cross-attention vector computed ahead of time (single_key_vector)
-int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e, const float* ov_pre = nullptr);
+int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e, const float* ov_pre = nullptr,
+                 const PreKV* kv_pre = nullptr);
 // [e.batch][dim] fp32 output of a one-key cross-attention (query independent, note N5)
 int single_key_vector(Ctx& cx, const AttnW& w, int dim, const EhsCtx& e, float** out);
 int run_layernorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int M, int dim);

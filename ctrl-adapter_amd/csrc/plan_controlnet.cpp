@@ -162,6 +162,11 @@ struct ctrl_controlnet : PlanBase {
     // fused step (ctrl_step_forward): the network runs on its own stream and signals every output with an event
     hipStream_t side = nullptr;
     hipEvent_t fork_ev = nullptr, done_ev = nullptr, out_ev[13] = {};
+    // auxiliary lane: work off the critical chain of the network -- the text K/V projections of all transformer blocks
+    // (they depend on encoder_hidden_states only) and the 13 zero-convs (each needs only its residual) -- runs on this
+    // stream, forked / joined with events (hipGraph-capturable), in the CUs the small-M chain leaves idle
+    hipStream_t aux = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_kv = nullptr, aux_done = nullptr, res_ev[13] = {};
     // step-invariant cache of the conditioning embedder's last hidden map (CTRL_COND_KEEP / CTRL_COND_REUSE)
     half_t* cond_cache = nullptr;
     std::vector<void*> cond_retired;    // outgrown caches stay alive (captured graphs may still address them)
@@ -172,6 +177,11 @@ struct ctrl_controlnet : PlanBase {
         HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&done_ev, hipEventDisableTiming));
         for (int i = 0; i < 13; ++i) HIP_TRY(hipEventCreateWithFlags(&out_ev[i], hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&aux_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&aux_kv, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&aux_done, hipEventDisableTiming));
+        for (int i = 0; i < 13; ++i) HIP_TRY(hipEventCreateWithFlags(&res_ev[i], hipEventDisableTiming));
         return 0;
     }
     ~ctrl_controlnet() {
@@ -182,6 +192,11 @@ struct ctrl_controlnet : PlanBase {
         if (fork_ev) (void)hipEventDestroy(fork_ev);
         if (done_ev) (void)hipEventDestroy(done_ev);
         for (int i = 0; i < 13; ++i) if (out_ev[i]) (void)hipEventDestroy(out_ev[i]);
+        if (aux) (void)hipStreamDestroy(aux);
+        if (aux_fork) (void)hipEventDestroy(aux_fork);
+        if (aux_kv) (void)hipEventDestroy(aux_kv);
+        if (aux_done) (void)hipEventDestroy(aux_done);
+        for (int i = 0; i < 13; ++i) if (res_ev[i]) (void)hipEventDestroy(res_ev[i]);
     }
 };
 
@@ -197,10 +212,12 @@ struct FwdArgs {
     hipEvent_t* out_ev;     // optional [13]: recorded on the launch stream right after output i has been enqueued
     half_t* cond_cache;     // plan-owned [N][H][W][c_last_hidden] or null
     bool cond_reuse;        // start the conditioning embedder from cond_cache
+    ctrl_controlnet* plan;  // auxiliary lane (streams / events); aux_on false: everything on the launch stream
+    bool aux_on;
 };
 
 int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& pout, const BasicTBW& tb, const TV& x,
-                      const TV& out, int N, int H, int W, const EhsCtx& e) {
+                      const TV& out, int N, int H, int W, const EhsCtx& e, const PreKV* kv) {
     const size_t mk = cx.mark();
     const int C = tn.C, M = N * H * W;
     half_t* n = cx.h((size_t)M * pin.Cin);
@@ -209,7 +226,7 @@ int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& po
     ConvOpts o;
     TRY(run_conv(cx, pin, n, t0, N, H, W, o));
     TV t1 = stream_alloc_rc(cx, (size_t)M, C, true);    // its fp16 mirror is proj_out's operand
-    TRY(run_basic_tb(cx, tb, t0, t1, N, H * W, e));
+    TRY(run_basic_tb(cx, tb, t0, t1, N, H * W, e, nullptr, kv));
     ConvOpts oo; oo.res = x;
     TRY(run_conv(cx, pout, t1.m16, out, N, H, W, oo));
     cx.release(mk);
@@ -239,6 +256,33 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         RUN(cx, op_nchw_to_nhwc(a.ehs, a.ehs_dt, e16, 1, 1, N * a.Lk * e.cross, cx.s));
         e.h16 = e16;
     }
+
+    // ---- text K / V^T projections of every transformer block, ahead of time on the auxiliary lane ----
+    hipStream_t const main_s = cx.s;
+    const bool aux = a.aux_on && !cx.dry;
+    std::vector<const BasicTBW*> tbs;
+    for (int i = 0; i < 4; ++i)
+        if (w.down[i].has_attn) for (const BasicTBW& t : w.down[i].tb) tbs.push_back(&t);
+    tbs.push_back(&w.mid_tb);
+    std::vector<PreKV> pre_kv(tbs.size());
+    {
+        if (aux) {
+            HIP_TRY(hipEventRecord(a.plan->aux_fork, main_s));
+            HIP_TRY(hipStreamWaitEvent(a.plan->aux, a.plan->aux_fork, 0));
+            cx.s = a.plan->aux;
+        }
+        for (size_t i = 0; i < tbs.size(); ++i) TRY(project_text_kv(cx, tbs[i]->attn2, e, &pre_kv[i]));
+        if (aux) {
+            HIP_TRY(hipEventRecord(a.plan->aux_kv, a.plan->aux));
+            cx.s = main_s;
+        }
+    }
+    bool kv_waited = !aux;
+    size_t tb_next = 0;
+    auto next_kv = [&]() -> const PreKV* {           // the main chain meets the projections at its first transformer block
+        if (!kv_waited) { (void)hipStreamWaitEvent(main_s, a.plan->aux_kv, 0); kv_waited = true; }
+        return &pre_kv[tb_next++];
+    };
 
     // ---- 2. stem: conv_in(sample) (:802-807) ----
     const int H = a.Hs, W = a.Ws;
@@ -298,8 +342,14 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         g.W = z.w; g.M = N * HW; g.Nout = z.Cout; g.Ktot = z.Cin; g.bias = z.b; g.scale = sc;
         g.nseg = 1;
         g.seg[0] = IGemmSeg{a.outs[i], HW, 0, z.Cout, SEG_TRANSPOSED, a.out_dt, HW, 0};
-        RUN(cx, op_igemm(g, cx.s));
-        if (!cx.dry && a.out_ev) HIP_TRY(hipEventRecord(a.out_ev[i], cx.s));
+        hipStream_t zs = cx.s;
+        if (aux) {      // the zero-conv only reads the residual that exists now: off the chain, onto the auxiliary lane
+            HIP_TRY(hipEventRecord(a.plan->res_ev[i], main_s));
+            HIP_TRY(hipStreamWaitEvent(a.plan->aux, a.plan->res_ev[i], 0));
+            zs = a.plan->aux;
+        }
+        RUN(cx, op_igemm(g, zs));
+        if (!cx.dry && a.out_ev) HIP_TRY(hipEventRecord(a.out_ev[i], zs));
         return 0;
     };
     // ---- 3. down blocks (:820-833) ----
@@ -314,7 +364,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
             cur = r;
             if (d.has_attn) {
                 TV t = stream_alloc_rc(cx, (size_t)N * h * wd, d.Cout, true);
-                TRY(run_transformer2d(cx, d.tnorm[j], d.proj_in[j], d.proj_out[j], d.tb[j], cur, t, N, h, wd, e));
+                TRY(run_transformer2d(cx, d.tnorm[j], d.proj_in[j], d.proj_out[j], d.tb[j], cur, t, N, h, wd, e, next_kv()));
                 cur = t;
             }
             TRY(emit(cur, h, wd));
@@ -334,12 +384,16 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         TV m0 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
         TRY(run_resnet(cx, w.mid_r0, cur, m0, N, h, wd, 1, tproj + w.mid_r0.temb_off, w.temb_total, c.norm_eps));
         TV m1 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
-        TRY(run_transformer2d(cx, w.mid_tnorm, w.mid_pin, w.mid_pout, w.mid_tb, m0, m1, N, h, wd, e));
+        TRY(run_transformer2d(cx, w.mid_tnorm, w.mid_pin, w.mid_pout, w.mid_tb, m0, m1, N, h, wd, e, next_kv()));
         TV m2 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
         TRY(run_resnet(cx, w.mid_r1, m1, m2, N, h, wd, 1, tproj + w.mid_r1.temb_off, w.temb_total, c.norm_eps));
         TRY(emit(m2, h, wd));
     }
     CTRL_CHECK(n_emitted == nout, "controlnet: residual/zero-conv count mismatch");
+    if (aux) {          // join: the launch stream does not run past the forward before the auxiliary lane has finished
+        HIP_TRY(hipEventRecord(a.plan->aux_done, a.plan->aux));
+        HIP_TRY(hipStreamWaitEvent(main_s, a.plan->aux_done, 0));
+    }
     return 0;
 }
 
@@ -419,8 +473,10 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
         }
         cache = h->cond_cache;
     }
+    static const bool aux_env = !(getenv("CTRL_CN_AUX") && atoi(getenv("CTRL_CN_AUX")) == 0);
     FwdArgs a = {sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
-                 controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, out_ev, cache, reuse};
+                 controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, out_ev, cache, reuse,
+                 h, aux_env && !g_prof_on};       // per-launch profiling needs one kernel at a time
     // sizing pass (no launches) -> workspace; then the real pass
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
