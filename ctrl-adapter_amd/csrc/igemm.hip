@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
         b_c8[i] = (lpos ^ chunk_swz<BK>(trow)) * 8;
         const int n = n0 + trow;
         b_ok[i] = (n < a.Nout) && (trow < BN);
-        b_off[i] = (size_t)(b_ok[i] ? n : 0) * a.Ktot;
+        b_off[i] = (size_t)(b_ok[i] ? n : 0) * (a.a_split == 2 ? a.Ktot / 2 : a.Ktot);
     }
 
     const half_t* Aptr = (const half_t*)a.A;
@@ -132,23 +132,42 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
 
     typedef const void __attribute__((address_space(1)))* gptr_t;
     typedef void __attribute__((address_space(3)))* lptr_t;
-    const int kt_begin = split * ((a.Ktot / BK + splitk - 1) / splitk);
+    // Paired split-operand walk (a_split == 2): A rows are [hi C | lo C]; k-tile 2p is the hi chunk p of a tap, k-tile 2p+1
+    // its lo chunk -- both multiply the SAME weight tile, which is therefore staged once per pair (into the B slot of the
+    // pair) and read by both; the weights are the plain [Cout][taps*C] pack.  28 % less global -> LDS traffic than walking
+    // [hi | lo] against weights packed twice, which is what limits these tiles.
+    const bool paired = (a.a_split == 2);
+    const int Cw = a.Cin >> 1;                         // logical channels per tap (paired walk)
+    int nk_per_ = (a.Ktot / BK + splitk - 1) / splitk;
+    if (paired) nk_per_ = (nk_per_ + 1) & ~1;          // a K split never cuts a (hi, lo) pair
+    const int kt_begin = split * nk_per_;
 
     // asynchronous global -> LDS staging of k-tile kt into buffer buf (no VGPR round trip)
     auto stage = [&](int kt, int buf) {
-        const int k0 = (kt_begin + kt) * BK;
+        int k0 = (kt_begin + kt) * BK;                 // K offset of the tile in W rows
         int tap = 0, c0 = k0;
-        if (MODE != IG_ROWS) { tap = k0 / a.Cin; c0 = k0 - tap * a.Cin; }
+        bool stage_b = true;
+        int bbuf = buf;
+        if (paired) {
+            const int tpt = a.Cin / BK;                // k-tiles per tap (hi and lo chunks)
+            const int ktg = kt_begin + kt;
+            tap = ktg / tpt;
+            const int r = ktg - tap * tpt, pr = r >> 1, hl = r & 1;
+            c0 = pr * BK + hl * Cw;
+            k0 = tap * Cw + pr * BK;
+            stage_b = (hl == 0);
+            bbuf = (kt >> 1) % NSTAGE;
+        } else if (MODE != IG_ROWS) { tap = k0 / a.Cin; c0 = k0 - tap * a.Cin; }
         int ky = 0, kx = 0;
         if (MODE == IG_CONV2D && a.taps == 9) { ky = tap / 3; kx = tap - 3 * ky; }
         half_t* Ab = As + buf * BM * BK;
-        half_t* Bb = Bs + buf * BNP * BK;
+        half_t* Bb = Bs + bbuf * BNP * BK;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             bool ok = a_ok[i];
             size_t off;
             if (MODE == IG_ROWS) {
-                off = a_off[i] + k0 + a_c8[i];
+                off = a_off[i] + (paired ? c0 : k0) + a_c8[i];
             } else if (MODE == IG_CONV2D) {
                 const int vy = a_y[i] + ky, vx = a_x[i] + kx;
                 ok = ok && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
@@ -162,10 +181,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
             const half_t* src = ok ? (Aptr + off) : zeros;          // zero padding = load from a zero page
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ab + (i * NW + wave) * RPW * BK), 16, 0, 0);
         }
+        if (stage_b) {
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const half_t* src = b_ok[i] ? (Wptr + b_off[i] + k0 + b_c8[i]) : zeros;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bb + (i * NW + wave) * RPW * BK), 16, 0, 0);
+            for (int i = 0; i < BPASS; ++i) {
+                const half_t* src = b_ok[i] ? (Wptr + b_off[i] + k0 + b_c8[i]) : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bb + (i * NW + wave) * RPW * BK), 16, 0, 0);
+            }
         }
     };
 
@@ -176,9 +197,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk_total = a.Ktot / BK;
-    const int nk_per = (nk_total + splitk - 1) / splitk;
-    const int kt_begin_ = split * nk_per;
-    const int nk = min(nk_per, nk_total - kt_begin_);
+    const int nk = min(nk_per_, nk_total - kt_begin);
     // NSTAGE-deep LDS ring: D = NSTAGE-1 tiles are in flight; a counted vmcnt (never 0 in steady state) retires only
     // the tile about to be consumed, so the LDS-DMA of later tiles stays in flight across the barrier.
     constexpr int D = NSTAGE - 1;
@@ -201,9 +220,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
     // hipcc re-uses one operand register and serialises {ds_read, lgkmcnt(0), 4 MFMAs} per fragment) + COMPUTE (MFMAs).
     constexpr int KK = BK / 32;
     h8 af[KK][MI], bf[KK][NI];
-    auto load_frags = [&](int slot) {
+    auto load_frags = [&](int slot, int bslot) {
         const half_t* Ab = As + slot * BM * BK;
-        const half_t* Bb = Bs + slot * BNP * BK;
+        const half_t* Bb = Bs + bslot * BNP * BK;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -223,12 +242,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                                        : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
         }
     };
-    // wait until this wave's LDS-DMA share of tile t has landed, leaving the D-1 younger tiles in flight
+    // wait until this wave's LDS-DMA share of tile t has landed, leaving the D-1 younger tiles in flight.  Paired walk:
+    // only the even tiles of the window t+1 .. t+D-1 carried a weight tile, so the count of younger loads alternates
     auto wait_tile = [&](int t) {
-        if (t + D - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + D - 1 >= nk) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        if (!paired) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPT) : "memory"); return; }
+        // evens among t+1 .. t+D-1 (local tile indices; the range of a workgroup starts at an even global tile)
+        const int nb = ((t + D - 1) >> 1) - (t >> 1);
+        if (nb <= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * APASS) : "memory");
+        else if (nb == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * APASS + BPASS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * APASS + 2 * BPASS) : "memory");
     };
+    static_assert(D - 1 <= 3, "paired walk: at most two weight tiles among the tiles in flight");
     auto slot_of = [&](int t) { return t % NSTAGE; };
+    auto bslot_of = [&](int t) { return paired ? (t >> 1) % NSTAGE : t % NSTAGE; };
 
     if constexpr (NW == 8 && (BM / WAVES_M) * (BN / WAVES_N) >= 128 * 64) {
         // (only for 128x64 per-wave tiles: with 64x64 wave tiles the LOAD phase outlasts the MFMAs and staggering loses)
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                 wait_tile(k);
                 __builtin_amdgcn_s_barrier();                     // interval 2k
                 if (k + D < nk) stage(k + D, slot_of(k + D));
-                load_frags(slot_of(k));
+                load_frags(slot_of(k), bslot_of(k));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();                     // interval 2k+1
@@ -261,7 +288,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
             for (int k = 0; k < nk; ++k) {
                 __builtin_amdgcn_s_barrier();                     // interval 2k+1
                 if (k + D < nk) stage(k + D, slot_of(k + D));
-                load_frags(slot_of(k));
+                load_frags(slot_of(k), bslot_of(k));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if (k + 1 < nk) wait_tile(k + 1);
@@ -277,7 +304,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
             wait_tile(kt);
             __builtin_amdgcn_s_barrier();               // every wave's part of tile kt is visible; slot of tile kt-1 is free
             if (kt + D < nk) stage(kt + D, slot_of(kt + D));  // streams into LDS under the MFMAs below
-            load_frags(slot_of(kt));
+            load_frags(slot_of(kt), bslot_of(kt));
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __builtin_amdgcn_sched_barrier(0);
@@ -778,6 +805,7 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(a.M > 0 && a.Nout > 0 && a.Ktot > 0, "igemm: empty problem");
     CTRL_CHECK(a.Cin % 32 == 0, "igemm: Cin must be a multiple of 32 (got " + std::to_string(a.Cin) + ")");
     CTRL_CHECK(a.Ktot == a.taps * a.Cin, "igemm: Ktot != taps*Cin");
+    CTRL_CHECK(a.a_split != 2 || ((a.Cin / 2) % 64 == 0 && a.mode != IG_TEMPORAL), "igemm: the paired split-operand walk needs Cin/2 % 64 == 0");
     CTRL_CHECK(a.lda % 8 == 0, "igemm: lda must be a multiple of 8 (16-byte vector loads)");
     CTRL_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "igemm: A/W must be 16-byte aligned");
     CTRL_CHECK(a.nseg >= 1 && a.nseg <= 3, "igemm: nseg must be 1..3");

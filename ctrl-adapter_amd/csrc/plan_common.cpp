@@ -82,7 +82,7 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
     g.Hin = Hin; g.Win = Win; g.Hout = Hout; g.Wout = Wout; g.stride = o.stride; g.up = o.up;
     g.W = c.w; g.M = N * Hout * Wout; g.Nout = c.Cout; g.Ktot = c.taps * c.Cin;
     g.bias = c.b; g.rowvec = o.rowvec; g.rowvec_ld = o.rowvec_ld; g.rows_per_img = Hout * Wout;
-    g.scale = 1.f; g.act = o.act; g.a_split = c.dup ? 1 : 0;
+    g.scale = 1.f; g.act = o.act; g.a_split = c.paired ? 2 : (c.dup ? 1 : 0);
     set_res(g, o.res, c.Cout);
     set_out(g, y, c.Cout, c.Cout);
     const size_t mk = cx.mark();

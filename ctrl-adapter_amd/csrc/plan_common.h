@@ -16,7 +16,8 @@
 struct Lin { half_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; bool geglu = false; };
 // dup: split-operand convolution -- Cin is the K per tap the kernel walks (2 x the logical width: [hi | lo] halves of the
 // operand rows against the weights repeated twice), see ctrl_igemm_desc::a_split
-struct ConvW { half_t* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, taps = 0; bool dup = false; };
+// paired: the split operand is walked in (hi, lo) pairs against the PLAIN weight pack (ctrl_igemm_desc::a_split == 2)
+struct ConvW { half_t* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, taps = 0; bool dup = false, paired = false; };
 struct ConvD { float* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0; };
 struct Norm { float* g = nullptr; float* b = nullptr; int C = 0; };
 
@@ -79,6 +80,7 @@ struct Packer : ParamSink {
     size_t bytes = 0;
     hipStream_t s;
     int* ovf = nullptr;          // device flag: set by a packer kernel that met a weight outside the fp16 range
+    bool split_paired = true;    // split-operand convs: paired walk on the plain weight pack (false: weights packed twice)
     Packer(const ctrl_tensor_ref* t, int n, hipStream_t stream) : s(stream) {
         for (int i = 0; i < n; ++i) map[t[i].name] = &t[i];
     }
@@ -159,9 +161,11 @@ struct Packer : ParamSink {
         const int taps = temporal ? 3 : k * k;
         if (temporal) TRY(get(name + ".weight", {Cout, Cin, 3, 1, 1}, &t));
         else TRY(get(name + ".weight", {Cout, Cin, k, k}, &t));
-        TRY(dalloc((size_t)Cout * Cin * taps * (dup ? 2 : 1) * sizeof(half_t), (void**)&out->w));
-        if (dup) TRY(op_pack_conv_w_dup(t->data, t->dtype, out->w, Cout, Cin, taps, s, ovf_flag()));
+        const bool paired = dup && split_paired && (Cin % 64 == 0) && !temporal;
+        TRY(dalloc((size_t)Cout * Cin * taps * ((dup && !paired) ? 2 : 1) * sizeof(half_t), (void**)&out->w));
+        if (dup && !paired) TRY(op_pack_conv_w_dup(t->data, t->dtype, out->w, Cout, Cin, taps, s, ovf_flag()));
         else TRY(op_pack_conv_w(t->data, t->dtype, out->w, Cout, Cin, taps, s, ovf_flag()));
+        out->paired = paired;
         TRY(dalloc((size_t)Cout * sizeof(float), (void**)&out->b));
         TRY(vec(name + ".bias", Cout, false, out->b));
         out->Cout = Cout; out->Cin = dup ? 2 * Cin : Cin; out->taps = taps; out->dup = dup;

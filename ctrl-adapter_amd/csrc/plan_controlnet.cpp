@@ -48,6 +48,11 @@ bool cn_split_enabled() {
     const char* e = getenv("CTRL_CN_SPLIT");
     return !(e && e[0] == '0') && stream_f32_enabled();
 }
+// CTRL_CN_SPLIT=dup: the first form of the split (weights packed twice, [hi | lo] walked as one long K) for A/B runs
+bool cn_split_paired() {
+    const char* e = getenv("CTRL_CN_SPLIT");
+    return !(e && e[0] == 'd');
+}
 
 int build_transformer2d(ParamSink& ps, const std::string& pre, int C, int heads, int cross, Norm* n, ConvW* pin,
                         ConvW* pout, BasicTBW* tb, bool dup) {
@@ -338,7 +343,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         const int HW = hh * ww;
         IGemmArgs g = {};
         CTRL_CHECK(cx.dry || (r.lo_off > 0) == z.dup, "controlnet: split-operand zero conv and its input mirror disagree");
-        g.A = r.m16; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1; g.a_split = z.dup ? 1 : 0;
+        g.A = r.m16; g.lda = z.Cin; g.mode = IG_ROWS; g.Cin = z.Cin; g.taps = 1; g.a_split = z.paired ? 2 : (z.dup ? 1 : 0);
         g.W = z.w; g.M = N * HW; g.Nout = z.Cout; g.Ktot = z.Cin; g.bias = z.b; g.scale = sc;
         g.nseg = 1;
         g.seg[0] = IGemmSeg{a.outs[i], HW, 0, z.Cout, SEG_TRANSPOSED, a.out_dt, HW, 0};
@@ -427,6 +432,7 @@ int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_
     TRY(h->init_base(n_tensors > 0 ? tensors[0].data : nullptr));
     DeviceGuard dg(h->device);           // the plan lives on the parameters' device, whatever the current device is
     h->packer.reset(new Packer(tensors, n_tensors, (hipStream_t)stream));
+    h->packer->split_paired = cn_split_paired();
     int rc = build_controlnet(*h->packer, *cfg, &h->w);
     if (rc) return rc;     // ~ctrl_controlnet frees what was packed so far
     TRY(h->init_async());

@@ -83,7 +83,7 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.blend_f32 = int(blend_x is not None and blend_x.dtype == torch.float32)
     d.scale = scale; d.geglu = int(geglu)
     d.scale2 = scale2; d.scale2_from = scale2_from
-    d.a_split = int(a_split); d.out16_lo_off = out16_lo_off
+    d.a_split = int(a_split); d.out16_lo_off = out16_lo_off      # a_split: 0 | 1 (weights packed twice) | 2 (paired walk)
     d.nseg = len(segs)
     for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):
         d.seg[i].out = out.data_ptr(); d.seg[i].ld = ld; d.seg[i].col_begin = cb; d.seg[i].ncols = nc

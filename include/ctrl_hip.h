@@ -81,9 +81,11 @@ typedef struct ctrl_igemm_desc {
     int32_t nseg;
     int32_t act;        /* 0 none, 1 SiLU applied after bias/rowvec (before residual) */
     int32_t res_f32;    /* residual is fp32 (the fp32 residual stream) */
-    int32_t a_split;    /* A rows hold [hi | lo] halves of an fp32 operand along Cin (lo = fp16(x - hi)) and W repeats every
-                           tap's Cin/2 weights twice: the product is exact in A to ~2^-22 at twice the MFMA work (used for
-                           the ControlNet's convolutions).  Only the algorithmic-FLOP accounting reads this flag. */
+    int32_t a_split;    /* split operand: A rows hold [hi | lo] fp16 halves of an fp32 operand along Cin (lo = fp16(x - hi)), so the
+                           product is exact in A to ~2^-22 at twice the MFMA work (the ControlNet's convolutions).
+                           1: W = every tap's Cin/2 weights packed twice ([Cout][taps][Cin]), K walked as one long axis;
+                           2: W = the plain pack [Cout][taps][Cin/2]; k-tiles alternate hi / lo chunk of the same channels and
+                              each weight tile is staged once per pair (Cin/2 % 64 == 0) */
     void* splitk_ws; int64_t splitk_ws_bytes;   /* optional fp32 scratch: enables split-K for small-M / long-K problems */
     void* out16; int64_t ld16;   /* optional fp16 row-major mirror of the (single, row-major) output: GEMM-operand copy of an fp32 stream */
     /* optional AlphaBlender fold (diffusers AlphaBlender, model/adapter_spatial_temporal.py:229,282), row-major outputs

@@ -336,12 +336,14 @@ def test_router(ops, gpu):
         report("router merge %s" % dt, rel_inf(out, ref), 1e-6 if dt == torch.float32 else TOL)
 
 
-@pytest.mark.parametrize("cin,cout,h,taps", [(320, 320, 16, 9), (640, 1280, 8, 9), (320, 320, 16, 1)])
-def test_split_operand_conv(ops, gpu, cin, cout, h, taps):
-    """ctrl_igemm_desc.a_split: GroupNorm+SiLU writes [hi | lo] fp16 halves of its fp32 result, the convolution walks both
-    against the weights packed twice -> the product is exact in A to ~2^-22 (fp16 operand rounding gone).  Reference in
-    fp64 on the un-rounded GroupNorm output; the plain fp16-operand path is printed beside it."""
-    n = 2
+@pytest.mark.parametrize("cin,cout,h,taps,n", [(320, 320, 16, 9, 2), (640, 1280, 8, 9, 2), (320, 320, 16, 1, 2), (1280, 1280, 8, 9, 8),
+                                              (320, 320, 64, 9, 8)])
+def test_split_operand_conv(ops, gpu, cin, cout, h, taps, n):
+    """ctrl_igemm_desc.a_split: GroupNorm+SiLU writes [hi | lo] fp16 halves of its fp32 result and the convolution walks
+    both -> the product is exact in A to ~2^-22 (fp16 operand rounding gone).  Both forms: 1 = weights packed twice, one
+    long K axis; 2 = plain weights, (hi, lo) k-tile pairs sharing one staged weight tile (the default of the ControlNet
+    plan), also through split-K.  Reference in fp64 on the un-rounded GroupNorm output; the plain fp16-operand path is
+    printed beside it."""
     g = torch.Generator().manual_seed(7)
     x = torch.randn(n, h, h, cin, generator=g)                      # fp32 stream (not fp16-representable)
     gam, bet = 1 + 0.1 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g)
@@ -353,17 +355,22 @@ def test_split_operand_conv(ops, gpu, cin, cout, h, taps):
     y2 = ops.groupnorm_split(x.to(gpu), gam.to(gpu), bet.to(gpu), n, h * h, eps=1e-5, silu=True)
     hi, lo = y2[..., :cin].float().cpu(), y2[..., cin:].float().cpu()
     report("gn split hi+lo vs fp64", rel_inf(hi.double() + lo.double(), xn.permute(0, 2, 3, 1)), 2e-6)
-    out = torch.empty(n, h, h, cout, dtype=torch.float32, device=gpu)
-    mir = torch.empty(n, h, h, 2 * cout, dtype=torch.float16, device=gpu)
     geom = dict(Hin=h, Win=h, Hout=h, Wout=h, stride=1, up=1)
-    ops.igemm(y2, 2 * cin, ops.pack_conv_w_dup(w.to(gpu)), n * h * h, cout, 2 * cin, taps=taps, mode=ops.IG_CONV2D, geom=geom,
-              bias=b.to(gpu), rows_per_img=h * h, segs=[(out, cout, 0, cout, ops.SEG_ROW, 1)], a_split=True,
-              out16=mir, ld16=2 * cout, out16_lo_off=cout)
-    report("split-operand conv %dx%d taps%d" % (cin, cout, taps), rel_inf(out.double(), ref), 3e-5)
-    report("split mirror hi+lo", rel_inf(mir[..., :cout].double().cpu() + mir[..., cout:].double().cpu(), ref), 3e-5)
+    M = n * h * h
+    ws = torch.empty(16 * M * cout, dtype=torch.float32, device=gpu)
+    for mode, wp in ((1, ops.pack_conv_w_dup(w.to(gpu))), (2, ops.pack_conv_w(w.to(gpu)))):
+        for use_ws in (False, True):
+            out = torch.empty(n, h, h, cout, dtype=torch.float32, device=gpu)
+            mir = torch.empty(n, h, h, 2 * cout, dtype=torch.float16, device=gpu)
+            ops.igemm(y2, 2 * cin, wp, M, cout, 2 * cin, taps=taps, mode=ops.IG_CONV2D, geom=geom,
+                      bias=b.to(gpu), rows_per_img=h * h, segs=[(out, cout, 0, cout, ops.SEG_ROW, 1)], a_split=mode,
+                      out16=mir, ld16=2 * cout, out16_lo_off=cout, splitk_ws=ws if use_ws else None)
+            tag = "split-operand conv mode %d%s %dx%d taps%d M%d" % (mode, " +splitk scratch" if use_ws else "", cin, cout, taps, M)
+            report(tag, rel_inf(out.double(), ref), 3e-5)
+            report("   mirror hi+lo", rel_inf(mir[..., :cout].double().cpu() + mir[..., cout:].double().cpu(), ref), 3e-5)
     y1 = ops.groupnorm(x.to(gpu), gam.to(gpu), bet.to(gpu), n, h * h, eps=1e-5, silu=True)
     out1 = torch.empty(n, h, h, cout, dtype=torch.float32, device=gpu)
-    ops.igemm(y1, cin, ops.pack_conv_w(w.to(gpu)), n * h * h, cout, cin, taps=taps, mode=ops.IG_CONV2D, geom=geom,
+    ops.igemm(y1, cin, ops.pack_conv_w(w.to(gpu)), M, cout, cin, taps=taps, mode=ops.IG_CONV2D, geom=geom,
               bias=b.to(gpu), rows_per_img=h * h, segs=[(out1, cout, 0, cout, ops.SEG_ROW, 1)])
     print("PARITY   (plain fp16-operand conv beside it: rel_inf=%.3e)" % rel_inf(out1.double(), ref))
 
