@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/${R}_rocprofv3_kernel_stats_${V}.csv
 # the same with the stream lanes OFF and eager launches: kernels do not overlap, so per-symbol durations are the ones
 # bench.py's HIP events see (roofline.avg_launch_ms); summarised per (symbol, grid) + the per-launch dump of the library
-CTRL_ADAPTER_LANES=1 CTRL_PROF_DUMP=$O/${R}_launches_${V}.tsv rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lanes_off -- \
+CTRL_ADAPTER_LANES=1 CTRL_CN_AUX=0 CTRL_PROF_DUMP=$O/${R}_launches_${V}.tsv rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lanes_off -- \
   python bench.py --no-graph --no-cpu-baseline --steps 3 --warmup 1 > $O/stats_lanes_off.log 2>&1
 cp $(ls $O/stats_lanes_off/*/*kernel_stats.csv | head -1) $O/${R}_rocprofv3_kernel_stats_lanes_off_${V}.csv
 LSTEPS=$(grep -h avgpool $O/stats_lanes_off/*/*kernel_trace.csv | wc -l)
@@ -29,7 +29,7 @@ python tools/kernel_trace_summary.py $O/stats_lanes_off $LSTEPS $O/${R}_rocprofv
 rm -f $O/stats_lanes_off/*/*kernel_trace.csv
 # HBM traffic: one counter per pass, nothing but the counter collection; one stream so that counters attribute cleanly
 for c in FETCH_SIZE WRITE_SIZE; do
-  CTRL_ADAPTER_LANES=1 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --no-graph --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_$c.log 2>&1
+  CTRL_ADAPTER_LANES=1 CTRL_CN_AUX=0 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --no-graph --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_$c.log 2>&1
 done
 # warmup 1 + timed 2 + 3 profiled steps + 2 eager steps before capture are all counted: steps = number of avgpool launches
 STEPS=$(grep -h avgpool $O/pmc_FETCH_SIZE/*/*counter_collection.csv | wc -l)
