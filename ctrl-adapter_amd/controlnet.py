@@ -49,7 +49,7 @@ class ControlNetModel(ParamTreeModule):
         if any(v is not None for v in (encoder_hid_dim, encoder_hid_dim_type, class_embed_type, addition_embed_type,
                                         num_class_embeds)):
             unsupported.append("class/addition embeddings")
-        if controlnet_conditioning_channel_order != "rgb" or global_pool_conditions: unsupported.append("channel order / global pool")
+        if controlnet_conditioning_channel_order != "rgb": unsupported.append("channel order")
         if downsample_padding != 1 or mid_block_scale_factor != 1: unsupported.append("padding/scale")
         if unsupported:
             raise ValueError("ControlNetModel (libctrlhip): unsupported configuration: " + ", ".join(unsupported))
@@ -143,11 +143,16 @@ class ControlNetModel(ParamTreeModule):
                     for c, f in zip(self._slot_channels, self._slot_factor)]
             mid = torch.zeros(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device)
             return ControlNetOutput(down, mid) if return_dict else (down, mid)
-        outs, args, _keep = self._launch_args(sample, timestep, ehs, controlnet_cond, conditioning_scale, guess_mode,
+        pool = bool(self.config.get("global_pool_conditions", False))
+        # guess-mode scaling is skipped for globally pooled conditions (controlnet/controlnet.py:861)
+        outs, args, _keep = self._launch_args(sample, timestep, ehs, controlnet_cond, conditioning_scale, guess_mode and not pool,
                                               skip_conv_in, skip_time_emb, out_dtype)
         with torch.cuda.device(sample.device):      # plan, stream and launches follow the tensors' device, not the current one
             self._text_cache_mode(encoder_hidden_states, L.lib().ctrl_controlnet_text_cache)
             L.check(L.lib().ctrl_controlnet_forward(self._ensure_plan(), *args, L.cur_stream()))
+        if pool:       # controlnet/controlnet.py:870-874: torch.mean(sample, dim=(2, 3), keepdim=True) of every output
+            from . import ops
+            outs = [ops.avgpool_nchw(o, 1, 1) for o in outs]
         down, mid = outs[:12], outs[12]
         if not return_dict:
             return (down, mid)

@@ -32,6 +32,15 @@ def controlled_step(controlnet, adapter, sample, timestep, encoder_hidden_states
     at control_guidance_end = 0.6 (note N8).  Off by default: the plain call returns what the two
     modules return."""
     cn_dtype = controlnet._check_inputs(sample, encoder_hidden_states, controlnet_cond)
+    if controlnet.config.get("global_pool_conditions", False):
+        # pooled outputs are produced after the network (a pass over its outputs): nothing for the adapter to start early on
+        down, mid = controlnet(sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, guess_mode=guess_mode,
+                               return_dict=False, skip_conv_in=skip_conv_in, skip_time_emb=skip_time_emb)
+        use_m = adapter.add_adapter_location_M if use_mid is None else use_mid
+        return (down, mid), adapter(down, mid if use_m else None, num_frames=num_frames,
+                                    timestep=timestep if adapter_timestep is None else adapter_timestep,
+                                    encoder_hidden_states=adapter_encoder_hidden_states, scatter_to=scatter_to,
+                                    out_dtype=out_dtype, clip_batch=clip_batch)
     if isinstance(conditioning_scale, (int, float)) and conditioning_scale == 0:
         # control off for this step: the separate calls already skip the ControlNet (note N8); nothing to overlap
         down, mid = controlnet(sample, timestep, encoder_hidden_states, controlnet_cond, 0, guess_mode=guess_mode,

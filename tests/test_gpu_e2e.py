@@ -517,3 +517,22 @@ def test_text_kv_cache_and_discard_when_off(P, controlnet, gpu):
     (zd, zm), (zo, zmid) = P.controlled_step(controlnet, ad, sample, ts[0], ehs, cond, 0, adapter_encoder_hidden_states=ehs_a,
                                              num_frames=1, discard_when_off=True)
     assert zo is None and zmid is None and all(x.abs().max().item() == 0.0 for x in list(zd) + [zm])
+
+
+def test_global_pool_conditions(P, gpu):
+    """controlnet/controlnet.py:861-874: `global_pool_conditions` (shuffle-type ControlNets) -- every output is its
+    spatial mean, and guess-mode scaling is not applied"""
+    from oracle.controlnet import ControlNetOracle
+    torch.set_grad_enabled(False)
+    kw = dict(cases.CONTROLNET_KW, global_pool_conditions=True)
+    inp = cases.controlnet_inputs(N=2, hs=16, seed=1700)
+    cn = seeded_init(P.ControlNetModel(**kw), seed=11).to(gpu)
+    oc = seeded_init(ControlNetOracle(**kw).eval(), seed=11)
+    for guess in (False, True):
+        d, m = cn(inp["sample"].half().to(gpu), inp["timestep"].to(gpu), inp["encoder_hidden_states"].half().to(gpu),
+                  inp["controlnet_cond"].half().to(gpu), conditioning_scale=0.7, guess_mode=guess, return_dict=False)
+        rd, rm = oc(inp["sample"], inp["timestep"], inp["encoder_hidden_states"], inp["controlnet_cond"], conditioning_scale=0.7, guess_mode=guess)
+        assert d[0].shape == (2, 320, 1, 1) and m.shape == (2, 1280, 1, 1)
+        errs = [rel_inf(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm])]
+        print("PARITY global_pool_conditions guess=%d rel_inf max %.2e" % (guess, max(errs)))
+        assert max(errs) <= TOL
