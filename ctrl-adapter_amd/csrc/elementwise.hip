@@ -266,6 +266,19 @@ __global__ void router_softmax_kernel(const float* __restrict__ wg, RouterMask m
     for (int e = 0; e < E; ++e) out[(size_t)r * E + e] = lg[e] / s;
 }
 
+// nearest x2 up-sampling of a channels-last map (F.interpolate(scale_factor=2, mode="nearest"), the adapter's transformer-
+// only SDXL blocks, model/adapter_spatial_temporal.py:235-237): y[n][2h+dy][2w+dx][c] = x[n][h][w][c], 16-byte vectors
+__global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int H, int W, int C8, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        size_t r = i / C8;
+        const int xo = (int)(r % (2 * W)); r /= (2 * W);
+        const int yo = (int)(r % (2 * H));
+        const size_t n = r / (2 * H);
+        ((h8*)y)[i] = ((const h8*)x)[((n * H + (yo >> 1)) * W + (xo >> 1)) * C8 + c];
+    }
+}
+
 // ---------------- weight packers (run once at plan build) ----------------
 // fp16 range guard of the GEMM-weight packers: bf16 / fp32 checkpoints may hold values fp16 cannot (|w| > 65504)
 __device__ __forceinline__ half_t to_h_checked(float v, int* ovf) {
@@ -399,6 +412,13 @@ int op_add_rowvec(const void* x, int x_dt, const float* v, long ldv, void* y, in
     CTRL_CHECK(x_dt != DT_BF16 && y_dt != DT_BF16, "add_rowvec: fp16 / fp32 only");
     const size_t nch = M * (size_t)(C / 8);
     LAUNCH("add_rowvec", add_rowvec_kernel, dim3(grid_for(nch)), dim3(256), 0, s, x, x_dt, v, ldv, y, y_dt, nch, C, rows_per_img, vmod);
+    return 0;
+}
+int op_upsample2x_nhwc(const half_t* x, half_t* y, int N, int H, int W, int C, hipStream_t s) {
+    CTRL_CHECK(C % 8 == 0, "upsample2x: C must be a multiple of 8");
+    const size_t total = (size_t)N * 2 * H * 2 * W * (C / 8);
+    PROF_WORK(0, 2.0 * N * H * W * C * 5);
+    LAUNCH("upsample2x", upsample2x_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, y, H, W, C / 8, total);
     return 0;
 }
 int op_fill_zero(void* p, size_t bytes, hipStream_t s) {

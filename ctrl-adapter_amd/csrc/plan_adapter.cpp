@@ -370,8 +370,17 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             TV y = stream_alloc(cx, (size_t)N * H * up * W * up * C, need16 && !tr);
             TRY(run_resnet(cx, Lw.sres, x, y, N, H, W, up, tp, C, 1e-6f));
             x = y; H *= up; W *= up;
+        } else if (up > 1 && !tr) {
+            // no ResNet to fold the up-sampling into: F.interpolate(scale_factor=2, mode="nearest") (:235-237)
+            CTRL_CHECK(cx.dry || x.m16 != nullptr, "adapter: the up-sampling path needs the fp16 map");
+            half_t* xu = cx.h((size_t)N * H * 2 * W * 2 * C);
+            RUN(cx, op_upsample2x_nhwc(x.m16, xu, N, H, W, C, cx.s));
+            x = tv16(xu); H *= 2; W *= 2;
         } else if (up > 1) {
-            CTRL_FAIL("adapter: up-sampling without a spatial resnet (F.interpolate path, :235-237) is not implemented");
+            // the reference up-samples only `if not add_spatial_resnet and not add_temporal_resnet`: with a temporal ResNet
+            // alone the block keeps the input size while the zero slots ... are input-sized too; the output tensor the
+            // mirror allocates is up-sampled, so refuse rather than return a partly written tensor
+            CTRL_FAIL("adapter: sdxl backbone with temporal but no spatial ResNet leaves the block at the input size (:235); not supported");
         }
         if (tr) {
             // with a spatial ResNet in front the AlphaBlender (:229) is folded into the temporal block's last conv

@@ -65,6 +65,9 @@ ADAPTER_VARIANTS = {
     "video_temporal_only_BM": (_variant(ADAPTER_VIDEO, add_spatial_resnet=False, add_spatial_transformer=False,
                                         add_adapter_location_A=False, add_adapter_location_C=False,
                                         add_adapter_location_D=False, num_frames=3), dict(N=6, frames=3, mid=True, ehs=(1, 1, 1024))),
+    # transformer-only SDXL blocks: no ResNet to fold the x2 up-sampling into -> F.interpolate path (:235-237)
+    "sdxl_transformer_only_BC_x1": (_variant(ADAPTER_SDXL, num_adapters_per_location=1, add_adapter_location_A=False,
+                                             add_spatial_resnet=False), dict(N=2, frames=1, mid=False, ehs=(2, 77, 2048))),
     # 2-D encoder_hidden_states (adapter_spatial_temporal.py:240-241 -> one key per image: the query-independent
     # cross-attention with a PER-IMAGE vector) and per-sample timesteps
     "sdxl_ehs2d_per_sample_t": (dict(ADAPTER_SDXL), dict(N=2, frames=1, mid=False, ehs=(2, 2048), t=[749.0, 249.0])),
