@@ -120,7 +120,8 @@ def pmc_traffic_for(kernel_row):
                 doc = json.load(fh)
         except Exception:
             continue
-        ent = doc.get("kernels", {}).get("%s|%d" % (kernel_row["symbol"], kernel_row["grid"]))
+        ent = (doc.get("kernels_by_shape") or {}).get((kernel_row["symbol"] + " " + kernel_row["shape"]).strip()) or \
+            doc.get("kernels", {}).get("%s|%d" % (kernel_row["symbol"], kernel_row["grid"]))
         if ent:
             return ent.get("hbm_bytes_per_launch_corrected"), os.path.basename(tfile)
     return None, None

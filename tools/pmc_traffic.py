@@ -1,6 +1,6 @@
 """Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py into profiles/<round>_pmc_hbm_traffic.json.
 
-  python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_in_run> <out.json>
+  python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_in_run> <out.json> [<launches.tsv of the same command>]
 
 Each directory holds the *_counter_collection.csv of ONE pass (counters are collected in their own runs, never combined
 with sys/hip/hsa tracing).  Corrections follow MI355X_MICROARCH.md (HBM section): gfx950 reports FETCH_SIZE (KiB) at half
@@ -58,6 +58,70 @@ def collect_kernels(directory, counter):
     return tot, launches
 
 
+def step_sequences(directory, counter):
+    """per denoise step (a step starts with the avgpool launch of bench.py's SDXL workload): the library's kernels in
+    dispatch order as (symbol, counter value)"""
+    rows = []
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == counter and kernel_class(row["Kernel_Name"]) is not None:
+                    rows.append((int(row["Dispatch_Id"]), symbol_of(row["Kernel_Name"]), float(row["Counter_Value"])))
+    rows.sort()
+    steps = []
+    for _, sym, val in rows:
+        if sym == "avgpool_kernel":
+            steps.append([])
+        if steps:
+            steps[-1].append((sym, val))
+    return steps
+
+
+def shapes_from_dump(tsv):
+    """the library's per-launch dump (CTRL_PROF_DUMP) of the same command: per step the (symbol, shape note) sequence"""
+    steps = []
+    with open(tsv) as fh:
+        for line in fh:
+            f = line.rstrip("\n").split("\t")
+            if len(f) < 6 or f[0] == "pack":
+                continue
+            if f[4] == "avgpool_kernel":
+                steps.append([])
+            if steps:
+                steps[-1].append((f[4], f[3]))
+    return steps
+
+
+def collect_by_shape(fetch_dir, write_dir, tsv):
+    """joins the counter rows with the per-launch dump by position inside a step: exact (symbol, shape) attribution --
+    grid size alone cannot tell e.g. the self-attention from the cross-attention launch of one Lq"""
+    ref = shapes_from_dump(tsv)
+    if not ref:
+        return None
+    ref = ref[-1]
+    out = {}
+    for d, cname, scale in ((fetch_dir, "FETCH_SIZE", 2.0), (write_dir, "WRITE_SIZE", 1.0)):
+        n_ok = 0
+        for st in step_sequences(d, cname):
+            if len(st) != len(ref) or any(a[0] != b[0] for a, b in zip(st, ref)):
+                continue                       # a step with another launch sequence (first step: plan build) is skipped
+            n_ok += 1
+            for (sym, val), (_, det) in zip(st, ref):
+                k = (sym + " " + det).strip()
+                e = out.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n_FETCH_SIZE": 0, "n_WRITE_SIZE": 0})
+                e[cname] += val
+                e["n_" + cname] += 1
+        if n_ok == 0:
+            return None
+    res = {}
+    for k, e in out.items():
+        if e["n_FETCH_SIZE"] and e["n_WRITE_SIZE"]:
+            f, w = e["FETCH_SIZE"] / e["n_FETCH_SIZE"], e["WRITE_SIZE"] / e["n_WRITE_SIZE"]
+            res[k] = {"fetch_kb_per_launch": round(f), "write_kb_per_launch": round(w),
+                      "hbm_bytes_per_launch_corrected": round((2.0 * f + w) * 1024.0)}
+    return res
+
+
 def collect(directory, counter):
     tot, launches = {}, {}
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
@@ -75,6 +139,7 @@ def collect(directory, counter):
 
 def main():
     fetch_dir, write_dir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    tsv = sys.argv[5] if len(sys.argv) > 5 else None
     f, fl = collect(fetch_dir, "FETCH_SIZE")
     w, _ = collect(write_dir, "WRITE_SIZE")
     classes = {}
@@ -98,6 +163,9 @@ def main():
                     "reports 1/2 of coalesced 16-B streams); WRITE_SIZE taken as is" % steps,
            "classes": classes,
            "kernels": kernels,       # key = "<symbol>|<grid size in work-items>" (bench.py's per_kernel rows carry both)
+           # key = bench.py's `kernel` string "<symbol> <shape>": counter rows joined with the library's per-launch dump of
+           # the same command by position inside a step (null when the sequences did not line up)
+           "kernels_by_shape": collect_by_shape(fetch_dir, write_dir, tsv) if tsv else None,
            "total_hbm_bytes_per_step_corrected": sum(c["hbm_bytes_per_step_corrected"] for c in classes.values())}
     with open(out, "w") as fh:
         json.dump(doc, fh, indent=1)

@@ -33,6 +33,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # warmup 1 + timed 2 + 3 profiled steps + 2 eager steps before capture are all counted: steps = number of avgpool launches
 STEPS=$(grep -h avgpool $O/pmc_FETCH_SIZE/*/*counter_collection.csv | wc -l)
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $STEPS $O/${R}_pmc_hbm_traffic_${V}.json
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $STEPS $O/${R}_pmc_hbm_traffic_${V}.json $O/${R}_launches_${V}.tsv
 rm -f $O/stats/*/*kernel_trace.csv
 tail -n 2 $O/${R}_op_parity_${V}.log $O/${R}_e2e_parity_${V}.log $O/${R}_smoke_${V}.log; cat $O/${R}_bench_${V}.json | head -c 600
