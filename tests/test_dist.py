@@ -61,3 +61,19 @@ def test_shard_covers_everything():
                 b, e = dp.shard(total, r, world)
                 cover += list(range(b, e))
             assert cover == list(range(total))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (it asserted on WORLD_SIZE).
+    There is no GPU here, so every rank stops at the loud no-GPU error -- which proves N ranks were launched with the
+    torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1) and that the parent relays their failure."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode()
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert p.returncode == 0 and '"n_gpus": 2' in out, out[-2000:]
+    else:
+        assert p.returncode != 0
+        assert out.count("bench.py needs a GPU") >= 2 or out.count("has no GPU") >= 1, out[-2000:]
