@@ -536,3 +536,22 @@ def test_global_pool_conditions(P, gpu):
         errs = [rel_inf(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm])]
         print("PARITY global_pool_conditions guess=%d rel_inf max %.2e" % (guess, max(errs)))
         assert max(errs) <= TOL
+
+
+def test_scatter_with_upsampled_mid_block(P, gpu):
+    """frame scatter with an SDXL backbone AND a mid block -- the mid output is up-sampled x2 like the down
+    slots, so the zero-filled holes of the dense output must span the up-sampled frame size (plan_adapter.cpp)."""
+    torch.set_grad_enabled(False)
+    cfg = dict(cases.ADAPTER_SDXL, add_adapter_location_A=False, add_adapter_location_B=False, add_adapter_location_M=True,
+               num_adapters_per_location=1)
+    ad = seeded_init(P.ControlNetAdapter(**cfg), seed=91).to(gpu)
+    downs, mid = cases.pyramid_inputs(N=2, h0=16, seed=1900, with_mid=True)
+    kw = dict(mid_block_res_sample=mid.half().to(gpu), num_frames=1, timestep=torch.tensor(499.0),
+              encoder_hidden_states=seeded_tensor((2, 77, 2048), 1901).half().to(gpu))
+    ins = [d.half().to(gpu) for d in downs]
+    out, omid = ad(ins, **kw)
+    assert omid.shape == (2, 1280, 4, 4)                          # 2x2 mid input, up-sampled
+    dense, dmid = ad(ins, **kw, scatter_to=([1, 3], 5))
+    for full, ref in list(zip(dense, out)) + [(dmid, omid)]:
+        assert full.shape[0] == 5 and torch.equal(full[1], ref[0]) and torch.equal(full[3], ref[1])
+        assert full[0].abs().max().item() == 0.0 and full[2].abs().max().item() == 0.0 and full[4].abs().max().item() == 0.0
