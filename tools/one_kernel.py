@@ -25,6 +25,6 @@ else:
     B, heads, L = 8, 5, 16384
     Cc = heads * 64
     q, k, vt = R(B * L, Cc), R(B * L, Cc), R(B, Cc, L)
-    for _ in range(3):
-        ops.flash_attn(q, Cc, k, Cc, vt, L, B, heads, 64, L, L)
+    for _ in range(3):      # "attn_fold": the product path's form (K pre-scaled, maximum folded into the accumulator init)
+        ops.flash_attn(q, Cc, k, Cc, vt, L, B, heads, 64, L, L, k_prescaled=(which == "attn_fold"))
 torch.cuda.synchronize()
