@@ -455,10 +455,11 @@ struct ctrl_adapter : PlanBase {
     // Lanes: the adapter blocks are independent of each other (ctrl_adapter.py:181-205), so blocks of different
     // resolutions run on different HIP streams (lane 0 = the caller's stream) and the small low-resolution blocks fill
     // the CUs the big ones leave idle at their tile-wave tails.  Forked / joined with events: hipGraph-capturable.
-    static constexpr int kLanes = 4;
-    hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[kLanes - 1] = {nullptr, nullptr, nullptr};
-    size_t lane_need[kLanes] = {0, 0, 0, 0};
+    static constexpr int kLanes = 6;             // 4 pyramid levels (+ 2 when the three top-level blocks get a lane each)
+    static constexpr int kLevelLanes = 4;
+    hipStream_t side[kLanes - 1] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[kLanes - 1] = {};
+    size_t lane_need[kLanes] = {};
     int init_lanes() {
         for (int i = 0; i < kLanes - 1; ++i) {
             HIP_TRY(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
@@ -570,7 +571,14 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
         HIP_TRY(hipEventRecord(P->fork_ev, main_s));
         for (int l = 1; l < nl; ++l) HIP_TRY(hipStreamWaitEvent(P->side[l - 1], P->fork_ev, 0));
     }
-    auto lane_of = [&](int f) { const int l = f == 1 ? 0 : (f == 2 ? 1 : (f == 4 ? 2 : 3)); return l % nl; };
+    // one lane per pyramid level; with more than kLevelLanes lanes (CTRL_ADAPTER_SPLIT_TOP) the second and third block of the
+    // top level (the three largest, equal-shaped chains of the step) get a lane of their own
+    int top_seen = 0;
+    auto lane_of = [&](int f) {
+        int l = f == 1 ? 0 : (f == 2 ? 1 : (f == 4 ? 2 : 3));
+        if (f == 1 && nl > ctrl_adapter::kLevelLanes) { l = top_seen == 0 ? 0 : ctrl_adapter::kLevelLanes - 1 + top_seen; ++top_seen; }
+        return l % nl;
+    };
     auto run_in_lane = [&](int lane, int slot, const AdapterBlockW& bw, const BlockPre& bp, const void* in, void* out, int h, int wd, size_t frame_elems) -> int {
         cx.s = lane == 0 ? main_s : P->side[lane - 1];
         if (!cx.dry && k.in_ev) HIP_TRY(hipStreamWaitEvent(cx.s, k.in_ev[slot], 0));     // fused step: producer still running
@@ -710,7 +718,9 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
         N_out = N;
     }
     // lanes are off while the per-launch profiler is recording (overlapping kernels make per-kernel times meaningless)
-    static const int env_lanes = getenv("CTRL_ADAPTER_LANES") ? atoi(getenv("CTRL_ADAPTER_LANES")) : ctrl_adapter::kLanes;
+    static const bool split_top = getenv("CTRL_ADAPTER_SPLIT_TOP") && atoi(getenv("CTRL_ADAPTER_SPLIT_TOP")) != 0;
+    static const int env_lanes = getenv("CTRL_ADAPTER_LANES") ? atoi(getenv("CTRL_ADAPTER_LANES"))
+                                                              : (split_top ? (int)ctrl_adapter::kLanes : (int)ctrl_adapter::kLevelLanes);
     // frame-sharded clips run on ONE stream: the exchanges of one communicator must be issued and executed in the same
     // order on every rank
     const int nlanes = (g_prof_on || comm) ? 1 : std::min(std::max(env_lanes, 1), (int)ctrl_adapter::kLanes);
