@@ -86,3 +86,24 @@ def test_temporal_block_is_pointwise_in_space_and_blender():
     v = seeded_tensor((1, 32, 4, 3, 3), 17)
     out = tr(v, seeded_tensor((1, 4, 16), 18))
     assert out.shape == v.shape
+
+
+def test_attention_matches_pytorch_multihead_attention():
+    """an INDEPENDENT implementation of the same operator (PyTorch core's nn.MultiheadAttention: q/k/v projections without
+    bias, 1/sqrt(head_dim) scaling, softmax, output projection with bias) against the restatement of diffusers' Attention,
+    self-attention and cross-attention with a different context width (kdim / vdim)"""
+    for cross in (None, 24):
+        a = seeded_init(B.Attention(64, cross, heads=4, dim_head=16), 21)
+        mha = torch.nn.MultiheadAttention(64, 4, bias=True, batch_first=True, kdim=cross, vdim=cross)
+        with torch.no_grad():
+            if cross is None:
+                mha.in_proj_weight.copy_(torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight]))
+            else:
+                mha.q_proj_weight.copy_(a.to_q.weight); mha.k_proj_weight.copy_(a.to_k.weight); mha.v_proj_weight.copy_(a.to_v.weight)
+            mha.in_proj_bias.zero_()
+            mha.out_proj.weight.copy_(a.to_out[0].weight); mha.out_proj.bias.copy_(a.to_out[0].bias)
+        x = seeded_tensor((3, 11, 64), 22)
+        ctx = x if cross is None else seeded_tensor((3, 7, cross), 23)
+        ref, _ = mha(x, ctx, ctx, need_weights=False)
+        got = a(x, encoder_hidden_states=None if cross is None else ctx)
+        assert torch.allclose(got, ref, atol=2e-5), (cross, (got - ref).abs().max())
