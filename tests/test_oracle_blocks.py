@@ -107,3 +107,32 @@ def test_attention_matches_pytorch_multihead_attention():
         ref, _ = mha(x, ctx, ctx, need_weights=False)
         got = a(x, encoder_hidden_states=None if cross is None else ctx)
         assert torch.allclose(got, ref, atol=2e-5), (cross, (got - ref).abs().max())
+
+
+def test_basic_transformer_block_matches_pytorch_prenorm_decoder_layer():
+    """structure check against PyTorch core's pre-norm nn.TransformerDecoderLayer (self-attention, cross-attention,
+    feed-forward, each `x + f(norm(x))`), with the feed-forward activation replaced by the GEGLU gate.  The layer's
+    cross-attention has no kdim, so the context width equals the model width here."""
+    d, heads, inner = 64, 4, 256
+    blk = seeded_init(B.BasicTransformerBlock(d, heads, d // heads, cross_attention_dim=d), 31)
+
+    def geglu(h):
+        a, g = h.chunk(2, dim=-1)
+        return a * torch.nn.functional.gelu(g)
+    ref = torch.nn.TransformerDecoderLayer(d, heads, dim_feedforward=2 * inner, dropout=0.0, activation=geglu,
+                                           layer_norm_eps=1e-5, batch_first=True, norm_first=True)
+    ref.linear2 = torch.nn.Linear(inner, d)
+    with torch.no_grad():
+        for mha, a in ((ref.self_attn, blk.attn1), (ref.multihead_attn, blk.attn2)):
+            mha.in_proj_weight.copy_(torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight]))
+            mha.in_proj_bias.zero_()
+            mha.out_proj.weight.copy_(a.to_out[0].weight); mha.out_proj.bias.copy_(a.to_out[0].bias)
+        for n_ref, n in ((ref.norm1, blk.norm1), (ref.norm2, blk.norm2), (ref.norm3, blk.norm3)):
+            n_ref.weight.copy_(n.weight); n_ref.bias.copy_(n.bias)
+        ref.linear1.weight.copy_(blk.ff.net[0].proj.weight); ref.linear1.bias.copy_(blk.ff.net[0].proj.bias)
+        ref.linear2.weight.copy_(blk.ff.net[2].weight); ref.linear2.bias.copy_(blk.ff.net[2].bias)
+    ref.train()          # keeps PyTorch on the plain (non-fused) path; dropout is 0
+    x, ctx = seeded_tensor((2, 9, d), 32), seeded_tensor((2, 5, d), 33)
+    want = ref(x, ctx)
+    got = blk(x, encoder_hidden_states=ctx)
+    assert torch.allclose(got, want, atol=5e-5), (got - want).abs().max()
