@@ -10,6 +10,13 @@ int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream) {
     CTRL_CHECK(d != nullptr, "igemm: null descriptor");
     return op_igemm(*d, S(stream));
 }
+int ctrl_igemm_set_order(const char* spec) { return igemm_set_order(spec); }
+int ctrl_igemm_set_persist(int on) { return igemm_set_persist(on); }
+int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n) {
+    CTRL_CHECK(tile_m && tile_n && ntm > 0 && ntn > 0 && bid >= 0 && bid < ntm * ntn, "igemm_tile_of: bad arguments");
+    igemm_tile_of(bid, ntm, ntn, mode, group, tile_m, tile_n);
+    return 0;
+}
 int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream) {
     CTRL_CHECK(d != nullptr, "flash_attn: null descriptor");
     return op_flash_attn(*d, S(stream));

@@ -21,6 +21,8 @@
 // fuses bias, per-image channel vector (time embedding), GEGLU, residual add, scale and the output
 // layout (row-major slice, or transposed [img][C][tokens] for NCHW results / the V^T attention operand).
 #include "ops.h"
+#include "tile_order.h"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -39,8 +41,19 @@ __device__ __forceinline__ int chunk_swz(int row) {
 // workgroup's epilogue (HBM-bound fp32 stream traffic, GEGLU math) overlaps the other one's k-loop
 template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (NW == 8 && (BM * BN == 128 * 256 || BM * BN == 128 * 320)) ? 4 : 1; };
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk) {
+template <bool P>
+__device__ __forceinline__ const IGemmArgs& epi_desc(const IGemmArgs& a, const IGemmArgs* lds) {
+    if constexpr (P) return *lds;
+    else return a;
+}
+
+// PERSIST: one workgroup per CU walks a list of output tiles (workgroup b: tiles b, b + gridDim.x, ... of the walk order)
+// with ONE LDS ring running across them: the first k-tiles of the next output tile are already streaming into LDS while
+// the last MFMAs and the epilogue of the current one run, so only the very first tile pays the cold fill of the ring
+// (measured: 0.20 of the 0.33 ms fixed cost of an M = 131072 launch is that fill, profiles/r02_gemm_k_sweep.txt).  The
+// epilogue's staging area then lives beside the ring instead of on top of it.  No split-K in this form.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP, bool PERSIST = false>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk, int order) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // per-wave tile
@@ -59,19 +72,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // XCD-aware bijective remap: each XCD (blockIdx % 8) walks a contiguous range of tiles so the
-    // A rows / weight panels it re-reads stay in that XCD's private L2.
-    const int nblk = ntm * ntn;
+    // XCD-aware bijective walk of the tile grid (tile_order.h): what the workgroups resident on one XCD share in its L2.
     // split-K: blockIdx.x = split * nblk + tile; every split accumulates a contiguous range of k-tiles and writes its
     // fp32 partial tile to slab `split` of the scratch buffer (reduced + finished by splitk_finish_kernel)
-    const int split = blockIdx.x / nblk;
-    int bid = blockIdx.x - split * nblk;
+    const int nblk = ntm * ntn;
+    const int split = PERSIST ? 0 : blockIdx.x / nblk;
+    const int first_bid = blockIdx.x - split * nblk;
+    int m0, n0;                          // origin of the output tile being ACCUMULATED (the epilogue's tile)
     {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        int tile_m, tile_n;
+        tileorder::tile_of(first_bid, ntm, ntn, order, &tile_m, &tile_n);
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
     }
-    const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-lane staging coordinates: pass i, this wave writes rows [(i*NW+wave)*RPW, +RPW) of the tile ----
     const int lrow = lane / CPR, lpos = lane % CPR;
@@ -80,51 +93,54 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
     bool a_ok[APASS];
     int a_c8[APASS];                     // source chunk (halfs) after the swizzle
     const int pad = (a.taps == 9) ? 1 : 0;
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-        const int trow = (i * NW + wave) * RPW + lrow;
-        a_c8[i] = (lpos ^ chunk_swz<BK>(trow)) * 8;
-        const int m = m0 + trow;
-        a_ok[i] = m < a.M;
-        const int mm = a_ok[i] ? m : 0;
-        if (MODE == IG_ROWS) {
-            a_off[i] = (size_t)mm * a.lda;
-            a_y[i] = a_x[i] = 0;
-        } else if (MODE == IG_CONV2D) {
-            const int hw = a.Hout * a.Wout;
-            const int n = mm / hw, rem = mm - n * hw;
-            const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
-            a_off[i] = (size_t)n * a.Hin * a.Win;
-            a_y[i] = oy * a.stride - pad;
-            a_x[i] = ox * a.stride - pad;
-        } else {
-            const int fr = mm / a.HW;
-            if (a.t_pad) {
-                // frame-sharded clip: A is the padded operand [clip][F + 2][HW][lda] whose frame slots 0 and F + 1 hold the
-                // neighbour ranks' halo frames (zeros at the clip's ends), so no tap is ever masked
-                a_off[i] = ((size_t)mm + (size_t)(2 * (fr / a.F) + 1) * a.HW) * a.lda;
-                a_y[i] = 1;
-            } else {
-                a_off[i] = (size_t)mm * a.lda;
-                a_y[i] = fr % a.F;
-            }
-            a_x[i] = 0;
-        }
-    }
-    const int VH = a.Hin * a.up, VW = a.Win * a.up;   // virtual (up-sampled) input grid
-    const int ushift = (a.up == 2) ? 1 : 0;
-
     size_t b_off[BPASS];
     bool b_ok[BPASS];
     int b_c8[BPASS];
+    const int VH = a.Hin * a.up, VW = a.Win * a.up;   // virtual (up-sampled) input grid
+    const int ushift = (a.up == 2) ? 1 : 0;
+    // coordinates of the output tile whose operands are being STAGED (PERSIST: runs ahead of the accumulated tile)
+    auto set_stage_tile = [&](const int sm0, const int sn0) {
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-        const int trow = (i * NW + wave) * RPW + lrow;
-        b_c8[i] = (lpos ^ chunk_swz<BK>(trow)) * 8;
-        const int n = n0 + trow;
-        b_ok[i] = (n < a.Nout) && (trow < BN);
-        b_off[i] = (size_t)(b_ok[i] ? n : 0) * (a.a_split == 2 ? a.Ktot / 2 : a.Ktot);
-    }
+        for (int i = 0; i < APASS; ++i) {
+            const int trow = (i * NW + wave) * RPW + lrow;
+            a_c8[i] = (lpos ^ chunk_swz<BK>(trow)) * 8;
+            const int m = sm0 + trow;
+            a_ok[i] = m < a.M;
+            const int mm = a_ok[i] ? m : 0;
+            if (MODE == IG_ROWS) {
+                a_off[i] = (size_t)mm * a.lda;
+                a_y[i] = a_x[i] = 0;
+            } else if (MODE == IG_CONV2D) {
+                const int hw = a.Hout * a.Wout;
+                const int n = mm / hw, rem = mm - n * hw;
+                const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+                a_off[i] = (size_t)n * a.Hin * a.Win;
+                a_y[i] = oy * a.stride - pad;
+                a_x[i] = ox * a.stride - pad;
+            } else {
+                const int fr = mm / a.HW;
+                if (a.t_pad) {
+                    // frame-sharded clip: A is the padded operand [clip][F + 2][HW][lda] whose frame slots 0 and F + 1 hold the
+                    // neighbour ranks' halo frames (zeros at the clip's ends), so no tap is ever masked
+                    a_off[i] = ((size_t)mm + (size_t)(2 * (fr / a.F) + 1) * a.HW) * a.lda;
+                    a_y[i] = 1;
+                } else {
+                    a_off[i] = (size_t)mm * a.lda;
+                    a_y[i] = fr % a.F;
+                }
+                a_x[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int trow = (i * NW + wave) * RPW + lrow;
+            b_c8[i] = (lpos ^ chunk_swz<BK>(trow)) * 8;
+            const int n = sn0 + trow;
+            b_ok[i] = (n < a.Nout) && (trow < BN);
+            b_off[i] = (size_t)(b_ok[i] ? n : 0) * (a.a_split == 2 ? a.Ktot / 2 : a.Ktot);
+        }
+    };
+    set_stage_tile(m0, n0);
 
     const half_t* Aptr = (const half_t*)a.A;
     const half_t* Wptr = (const half_t*)a.W;
@@ -143,10 +159,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
     const int kt_begin = split * nk_per_;
 
     // asynchronous global -> LDS staging of k-tile kt into buffer buf (no VGPR round trip)
-    auto stage = [&](int kt, int buf) {
+    // (kt = k-tile of the staged output tile, f = running tile count that picks the ring slot: f == kt unless PERSIST)
+    auto stage = [&](int kt, int f) {
         int k0 = (kt_begin + kt) * BK;                 // K offset of the tile in W rows
         int tap = 0, c0 = k0;
         bool stage_b = true;
+        const int buf = f % NSTAGE;
         int bbuf = buf;
         if (paired) {
             const int tpt = a.Cin / BK;                // k-tiles per tap (hi and lo chunks)
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
             c0 = pr * BK + hl * Cw;
             k0 = tap * Cw + pr * BK;
             stage_b = (hl == 0);
-            bbuf = (kt >> 1) % NSTAGE;
+            bbuf = (f >> 1) % NSTAGE;
         } else if (MODE != IG_ROWS) { tap = k0 / a.Cin; c0 = k0 - tap * a.Cin; }
         int ky = 0, kx = 0;
         if (MODE == IG_CONV2D && a.taps == 9) { ky = tap / 3; kx = tap - 3 * ky; }
@@ -203,9 +221,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
     constexpr int D = NSTAGE - 1;
     constexpr int LPT = APASS + BPASS;       // global_load_lds instructions per lane per tile
     static_assert((D - 1) * LPT <= 63, "vmcnt immediate overflow");
+    if constexpr (!PERSIST) {
 #pragma unroll
-    for (int t = 0; t < D; ++t)
-        if (t < nk) stage(t, t);
+        for (int t = 0; t < D; ++t)
+            if (t < nk) stage(t, t);
+    }
 
     // fragment read coordinates: row (lane&15) of a 16-row fragment, logical chunk (lane>>4) + 4*kk
     const int frow = lane & 15, fch = lane >> 4;
@@ -244,8 +264,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
     };
     // wait until this wave's LDS-DMA share of tile t has landed, leaving the D-1 younger tiles in flight.  Paired walk:
     // only the even tiles of the window t+1 .. t+D-1 carried a weight tile, so the count of younger loads alternates
+    int nk_flat = nk;                        // PERSIST: k-tiles of ALL output tiles of this workgroup
     auto wait_tile = [&](int t) {
-        if (t + D - 1 >= nk) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        if (t + D - 1 >= nk_flat) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
         if (!paired) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPT) : "memory"); return; }
         // evens among t+1 .. t+D-1 (local tile indices; the range of a workgroup starts at an even global tile)
         const int nb = ((t + D - 1) >> 1) - (t >> 1);
@@ -257,323 +278,465 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
     auto slot_of = [&](int t) { return t % NSTAGE; };
     auto bslot_of = [&](int t) { return paired ? (t >> 1) % NSTAGE : t % NSTAGE; };
 
-    if constexpr (NW == 8 && (BM / WAVES_M) * (BN / WAVES_N) >= 128 * 64) {
-        // (only for 128x64 per-wave tiles: with 64x64 wave tiles the LOAD phase outlasts the MFMAs and staggering loses)
-        // Two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD) run half a tile apart: in every barrier
-        // interval one group issues its fragment reads + LDS-DMA while the other one issues MFMAs, so the LDS pipe and
-        // the matrix pipe are busy at the same time instead of alternating.
-        //   interval 2k   : group 0 LOAD(k)      group 1 COMPUTE(k-1)
-        //   interval 2k+1 : group 0 COMPUTE(k)   group 1 LOAD(k)
-        // Tile k is complete (every wave waited for its own share) before the barrier that opens interval 2k; its ring
-        // slot is re-filled from interval 2k+2 on (tile k+NSTAGE-1 is issued during LOAD(k)... of the NEXT tile).
-        const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;
-        if (grp == 0) {
-            for (int k = 0; k < nk; ++k) {
-                wait_tile(k);
-                __builtin_amdgcn_s_barrier();                     // interval 2k
-                if (k + D < nk) stage(k + D, slot_of(k + D));
-                load_frags(slot_of(k), bslot_of(k));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();                     // interval 2k+1
-                __builtin_amdgcn_s_setprio(1);
-                compute();
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
+    constexpr size_t RING_BYTES = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
+    char* const epi_smem = smem_raw + (PERSIST ? RING_BYTES : 0);     // PERSIST: the ring stays live under the epilogue
+    constexpr size_t EPI_STAGE_BYTES = (size_t)NW * 16 * (WN + 4) * sizeof(float);
+    const IGemmArgs* lds_desc = (const IGemmArgs*)(epi_smem + EPI_STAGE_BYTES);
+    if constexpr (PERSIST) {           // descriptor -> LDS (read back by the epilogues), straight from the kernarg segment
+        typedef const unsigned __attribute__((address_space(4)))* kptr_t;
+        const kptr_t kargs = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        if (tid < (int)(sizeof(IGemmArgs) / 4)) ((unsigned*)lds_desc)[tid] = kargs[tid];
+        __syncthreads();
+    }
+    // PERSIST: flat walk over (output tile, k-tile).  f counts k-tiles across this workgroup's output tiles, the ring slot is
+    // f % NSTAGE, and the staging cursor runs D k-tiles ahead of the MFMAs, crossing into the next output tile on its own.
+    const int gstep = (int)gridDim.x;
+    const int ntile = PERSIST ? (nblk - first_bid + gstep - 1) / gstep : 1;     // >= 1: the grid never exceeds nblk
+    const int nf = ntile * nk;
+    int s_k = 0, s_f = 0, s_bid = first_bid;                                    // staging cursor
+    auto stage_next = [&]() {
+        stage(s_k, s_f);
+        ++s_f;
+        if (++s_k == nk) {
+            s_k = 0;
+            s_bid += gstep;
+            if (s_bid < nblk) {
+                int tile_m, tile_n;
+                tileorder::tile_of(s_bid, ntm, ntn, order, &tile_m, &tile_n);
+                set_stage_tile(tile_m * BM, tile_n * BN);
             }
-            __builtin_amdgcn_s_barrier();                         // pairs with group 1's last barrier
-        } else {
+        }
+    };
+    const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;                  // the two staggered wave groups (8-wave tiles)
+    if constexpr (PERSIST) {
+        static_assert(!PERSIST || (NW == 8 && (BM / WAVES_M) * (BN / WAVES_N) >= 128 * 64 && SWAP), "persistent form: staggered 8-wave tiles, vector epilogue");
+        nk_flat = nf;
+#pragma unroll
+        for (int t = 0; t < D; ++t)
+            if (t < nf) stage_next();
+        if (grp == 1) {
             wait_tile(0);
-            __builtin_amdgcn_s_barrier();                         // interval 0 (group 0 loads tile 0)
-            for (int k = 0; k < nk; ++k) {
-                __builtin_amdgcn_s_barrier();                     // interval 2k+1
-                if (k + D < nk) stage(k + D, slot_of(k + D));
-                load_frags(slot_of(k), bslot_of(k));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                if (k + 1 < nk) wait_tile(k + 1);
-                __builtin_amdgcn_s_barrier();                     // interval 2k+2
-                __builtin_amdgcn_s_setprio(1);
-                compute();
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_s_barrier();                                       // interval 0 (group 0 loads tile 0)
         }
     } else {
-        for (int kt = 0; kt < nk; ++kt) {
-            wait_tile(kt);
-            __builtin_amdgcn_s_barrier();               // every wave's part of tile kt is visible; slot of tile kt-1 is free
-            if (kt + D < nk) stage(kt + D, slot_of(kt + D));  // streams into LDS under the MFMAs below
-            load_frags(slot_of(kt), bslot_of(kt));
-            __builtin_amdgcn_sched_barrier(0);
-            compute();
-            __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NW == 8 && (BM / WAVES_M) * (BN / WAVES_N) >= 128 * 64) {
+            // (only for 128x64 per-wave tiles: with 64x64 wave tiles the LOAD phase outlasts the MFMAs and staggering loses)
+            // Two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD) run half a tile apart: in every barrier
+            // interval one group issues its fragment reads + LDS-DMA while the other one issues MFMAs, so the LDS pipe and
+            // the matrix pipe are busy at the same time instead of alternating.
+            //   interval 2k   : group 0 LOAD(k)      group 1 COMPUTE(k-1)
+            //   interval 2k+1 : group 0 COMPUTE(k)   group 1 LOAD(k)
+            // Tile k is complete (every wave waited for its own share) before the barrier that opens interval 2k; its ring
+            // slot is re-filled from interval 2k+2 on (tile k+NSTAGE-1 is issued during LOAD(k)... of the NEXT tile).
+            if (grp == 0) {
+                for (int k = 0; k < nk; ++k) {
+                    wait_tile(k);
+                    __builtin_amdgcn_s_barrier();                     // interval 2k
+                    if (k + D < nk) stage(k + D, k + D);
+                    load_frags(slot_of(k), bslot_of(k));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();                     // interval 2k+1
+                    __builtin_amdgcn_s_setprio(1);
+                    compute();
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_barrier();                         // pairs with group 1's last barrier
+            } else {
+                wait_tile(0);
+                __builtin_amdgcn_s_barrier();                         // interval 0 (group 0 loads tile 0)
+                for (int k = 0; k < nk; ++k) {
+                    __builtin_amdgcn_s_barrier();                     // interval 2k+1
+                    if (k + D < nk) stage(k + D, k + D);
+                    load_frags(slot_of(k), bslot_of(k));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 1 < nk) wait_tile(k + 1);
+                    __builtin_amdgcn_s_barrier();                     // interval 2k+2
+                    __builtin_amdgcn_s_setprio(1);
+                    compute();
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                wait_tile(kt);
+                __builtin_amdgcn_s_barrier();               // every wave's part of tile kt is visible; slot of tile kt-1 is free
+                if (kt + D < nk) stage(kt + D, kt + D);  // streams into LDS under the MFMAs below
+                load_frags(slot_of(kt), bslot_of(kt));
+                __builtin_amdgcn_sched_barrier(0);
+                compute();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+
     }
 
-    // ---------------- epilogue ----------------
-    if constexpr (SWAP) {
-        // Operands were swapped (D = W.A^T): a lane owns ONE output row (lane&15) and FOUR consecutive columns
-        // (lane>>4)*4+i of each 16x16 fragment.  Bias / time vector / GEGLU / SiLU are applied in registers; the
-        // 16-row slab of the wave tile then goes through a wave-private LDS staging area (the k-loop ring is dead) and
-        // leaves as whole 16-byte pieces of full output rows: residual reads and result writes are coalesced 128-byte+
-        // row segments instead of 8-byte fragments scattered over 16 rows.
-        __syncthreads();                                   // every wave is done with the ring
-        if (a.seg[0].fmt == SEG_TRANSPOSED) {
-            // One transposed segment (NCHW result / V^T operand): out[(img*ncols + c)*ld + tok].  Everything that is
-            // indexed by (row, column) -- bias, time vector, SiLU, residual, scale -- is applied in the fragment layout;
-            // a 16-channel slab of the wave tile (16 x WM tokens) is then transposed through the wave's LDS area and
-            // leaves as 16-byte pieces of WM-token runs of one channel (256 B contiguous for WM = 128) instead of the
-            // natural orientation's isolated 8-byte stores.
-            constexpr int SLT = WM + 4;                    // 4*SLT = 16 (mod 64 banks): the 4 channel groups of a write hit distinct banks
-            float* stg = (float*)smem_raw + wave * (16 * SLT);
-            const IGemmSeg sg = a.seg[0];
-            const int erow = lane & 15, ecol = (lane >> 4) * 4;
-            const int wrow0 = m0 + wm * WM;
+    // One epilogue site for every form.  PERSIST runs the two-group schedule of the one-tile form above as a flat loop:
+    //   group 0:  [wait f] B(2f)   *   stage, LOAD(f)                 B(2f+1)  COMPUTE(f)
+    //   group 1:                   *   B(2f+1)  stage, LOAD(f) [wait f+1]  B(2f+2)  COMPUTE(f)
+    // and * is where a finished output tile leaves: group 0 right AFTER the barrier that lets group 1 start its last
+    // COMPUTE of that tile (epilogue under the other group's MFMAs), group 1 right after that COMPUTE, while group 0 is
+    // already loading the next tile's fragments -- the two epilogues never wait for each other.
+    bool pending = !PERSIST;                 // accumulators hold a finished output tile
+    int c_k = 0, c_ti = 0;
+    for (int f = 0;; ++f) {
+        if constexpr (PERSIST) {
+            if (grp == 0) {
+                if (f < nf) wait_tile(f);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (pending) {
+        // ---------------- epilogue of the accumulated tile (m0, n0) ----------------
+            // (PERSIST reads the descriptor from its LDS copy: ~60 epilogue-only scalars would otherwise stay live -- and
+            // spilled -- across the k-loop)
+            const IGemmArgs& e = epi_desc<PERSIST>(a, lds_desc);
+            if constexpr (SWAP) {
+                // Operands were swapped (D = W.A^T): a lane owns ONE output row (lane&15) and FOUR consecutive columns
+                // (lane>>4)*4+i of each 16x16 fragment.  Bias / time vector / GEGLU / SiLU are applied in registers; the
+                // 16-row slab of the wave tile then goes through a wave-private LDS staging area (the k-loop ring is dead) and
+                // leaves as whole 16-byte pieces of full output rows: residual reads and result writes are coalesced 128-byte+
+                // row segments instead of 8-byte fragments scattered over 16 rows.
+                if constexpr (!PERSIST) __syncthreads();           // every wave is done with the ring
+                if (e.seg[0].fmt == SEG_TRANSPOSED) {
+                    // One transposed segment (NCHW result / V^T operand): out[(img*ncols + c)*ld + tok].  Everything that is
+                    // indexed by (row, column) -- bias, time vector, SiLU, residual, scale -- is applied in the fragment layout;
+                    // a 16-channel slab of the wave tile (16 x WM tokens) is then transposed through the wave's LDS area and
+                    // leaves as 16-byte pieces of WM-token runs of one channel (256 B contiguous for WM = 128) instead of the
+                    // natural orientation's isolated 8-byte stores.
+                    constexpr int SLT = WM + 4;                    // 4*SLT = 16 (mod 64 banks): the 4 channel groups of a write hit distinct banks
+                    float* stg = (float*)epi_smem + wave * (16 * SLT);
+                    const IGemmSeg sg = e.seg[0];
+                    const int erow = lane & 15, ecol = (lane >> 4) * 4;
+                    const int wrow0 = m0 + wm * WM;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int pcb = n0 + wn * WN + ni * 16;
-                if (pcb < a.Nout) {
-                    const int pcol = pcb + ecol;
-                    f4 b4 = f4{0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) b4 = *(const f4*)(a.bias + pcol);
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int pcb = n0 + wn * WN + ni * 16;
+                        if (pcb < e.Nout) {
+                            const int pcol = pcb + ecol;
+                            f4 b4 = f4{0.f, 0.f, 0.f, 0.f};
+                            if (e.bias) b4 = *(const f4*)(e.bias + pcol);
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) {
+                                const int row_w = wrow0 + mi * 16 + erow;
+                                f4 x = acc[mi][ni] + b4;
+                                if (row_w < e.M) {
+                                    if (e.rowvec) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcol);
+                                    if (e.act == 1) {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
+                                    }
+                                    if (Rptr) {
+                                        if (e.res_f32) {
+                                            x += *(const f4*)((const float*)e.res + (size_t)row_w * e.ldres + pcol);
+                                        } else {
+                                            const h4 rr = *(const h4*)(Rptr + (size_t)row_w * e.ldres + pcol);
+#pragma unroll
+                                            for (int i = 0; i < 4; ++i) x[i] += (float)rr[i];
+                                        }
+                                    }
+                                }
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) stg[(ecol + i) * SLT + mi * 16 + erow] = x[i] * e.scale;
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            constexpr int CH8 = WM / 8;
+                            for (int idx = lane; idx < 16 * CH8; idx += 64) {
+                                const int ch = idx / CH8, c8 = idx - ch * CH8;
+                                const int row = wrow0 + c8 * 8;
+                                if (row >= e.M) continue;
+                                int img = row / sg.L;
+                                const int tok = row - img * sg.L;
+                                if (sg.img_map) img = sg.img_map[img];
+                                const size_t o = ((size_t)img * sg.ncols + (pcb - sg.col_begin) + ch) * sg.ld + tok;
+                                const f4 v0 = *(const f4*)(stg + ch * SLT + c8 * 8), v1 = *(const f4*)(stg + ch * SLT + c8 * 8 + 4);
+                                if (sg.dtype == DT_F16) {
+                                    h8 pk = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
+                                             (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
+                                    *(h8*)((half_t*)sg.out + o) = pk;
+                                } else if (sg.dtype == DT_F32) {
+                                    *(f4*)((float*)sg.out + o) = v0;
+                                    *(f4*)((float*)sg.out + o + 4) = v1;
+                                } else {
+                                    typedef u16 us8 __attribute__((ext_vector_type(8)));
+                                    us8 pk = {f32_to_bf16(v0[0]), f32_to_bf16(v0[1]), f32_to_bf16(v0[2]), f32_to_bf16(v0[3]),
+                                              f32_to_bf16(v1[0]), f32_to_bf16(v1[1]), f32_to_bf16(v1[2]), f32_to_bf16(v1[3])};
+                                    *(us8*)((u16*)sg.out + o) = pk;
+                                }
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                    }
+                } else {
+                    constexpr int OWMAX = WN;                          // output columns of the wave tile (half of it with GEGLU)
+                    constexpr int SLD = OWMAX + 4;                     // floats; +16 B keeps the b128 accesses conflict-light
+                    float* stg = (float*)epi_smem + wave * (16 * SLD);
+                    const int erow = lane & 15, ecol = (lane >> 4) * 4;
+                    const int OW = e.geglu ? WN / 2 : WN;
+                    const int OWC = OW >> 3;                           // 8-column chunks per row
+                    const int wcol0 = e.geglu ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN);     // first output column of the wave tile
+                    const int nout_eff = e.geglu ? (e.Nout >> 1) : e.Nout;
+                    // the bias depends on the column only: one load per fragment column, issued together up front -- fetched
+                    // inside the mi loop, every 16-row slab stalled on its own load (and on every store before it: one vmcnt)
+                    f4 bias_v[NI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int pcb = n0 + wn * WN + ni * 16;
+                        bias_v[ni] = (e.bias && pcb < e.Nout) ? *(const f4*)(e.bias + pcb + ecol) : f4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    // fp32 residual (the fp32 stream updates, HBM-bound): the 8-column pieces a lane adds are fetched one slab
+                    // AHEAD, each refill issued before the stores of its own slab, so that waiting for it never means waiting
+                    // for a store (loads and stores share one in-order counter)
+                    constexpr int RT = (16 * (OWMAX / 8) + 63) / 64;       // pieces per lane per 16-row slab
+                    // ... fetched ahead: the wide one-workgroup-per-CU tiles only (256 registers per wave; the two-workgroup
+                    // tiles live in 128 and overlap their epilogue with the other workgroup's k-loop instead), and at most two
+                    // pieces (the 80-wide wave tile has no registers for a third)
+                    constexpr bool RES_AHEAD = (WM * WN >= 128 * 64) && (MinWaves<BM, BN, NW>::v == 1 || PERSIST);
+                    constexpr int RTP = !RES_AHEAD ? 0 : (RT > 2 ? 2 : RT);
+                    f4 rf0[RTP ? RTP : 1], rf1[RTP ? RTP : 1];
+#pragma unroll
+                    for (int t = 0; t < RTP; ++t) {
+                        rf0[t] = rf1[t] = f4{0.f, 0.f, 0.f, 0.f};
+                        const int idx = lane + 64 * t;
+                        if (Rptr && e.res_f32 && idx < 16 * OWC) {
+                            const int r = idx / OWC, c8 = idx - r * OWC;
+                            const int row = m0 + wm * WM + r, ocol = wcol0 + c8 * 8;
+                            if (row < e.M && ocol < nout_eff) {
+                                const float* rp = (const float*)e.res + (size_t)row * e.ldres + ocol;
+                                rf0[t] = *(const f4*)rp;
+                                rf1[t] = *(const f4*)(rp + 4);
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
-                        const int row_w = wrow0 + mi * 16 + erow;
-                        f4 x = acc[mi][ni] + b4;
-                        if (row_w < a.M) {
-                            if (a.rowvec) x += *(const f4*)(a.rowvec + (size_t)(row_w / a.rows_per_img) * a.rowvec_ld + pcol);
-                            if (a.act == 1) {
+                        const int row_w = m0 + wm * WM + mi * 16 + erow;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            if (e.geglu && (ni & 1)) continue;
+                            const int pcb = n0 + wn * WN + ni * 16;
+                            if (pcb >= e.Nout) continue;
+                            const int pcol = pcb + ecol;
+                            f4 x = acc[mi][ni];
+                            if (e.bias) x += bias_v[ni];
+                            if (e.rowvec && row_w < e.M) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcol);
+                            if (e.geglu) {
+                                f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)];
+                                if (e.bias) g += bias_v[ni + 1 < NI ? ni + 1 : ni];      // the gate's columns = the next fragment's
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
+                            }
+                            if (e.act == 1) {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
                             }
-                            if (Rptr) {
-                                if (a.res_f32) {
-                                    x += *(const f4*)((const float*)a.res + (size_t)row_w * a.ldres + pcol);
-                                } else {
-                                    const h4 rr = *(const h4*)(Rptr + (size_t)row_w * a.ldres + pcol);
+                            const int lcol = (e.geglu ? (ni >> 1) * 16 : ni * 16) + ecol;
+                            *(f4*)(stg + erow * SLD + lcol) = x;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are in order; pin compiler order
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i) x[i] += (float)rr[i];
+                        for (int t = 0; t < RT; ++t) {
+                            const int idx = lane + 64 * t;
+                            if (idx >= 16 * OWC) continue;
+                            const int r = idx / OWC, c8 = idx - r * OWC;
+                            const int row = m0 + wm * WM + mi * 16 + r;
+                            const int ocol = wcol0 + c8 * 8;
+                            if (row >= e.M || ocol >= nout_eff) continue;
+                            const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
+                            float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            if (Rptr) {
+                                if (e.res_f32) {
+                                    if (t < RTP) {
+                                        const int tp = t < RTP ? t : 0;
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) { x[i] += rf0[tp][i]; x[4 + i] += rf1[tp][i]; }
+                                        if (mi + 1 < MI && row + 16 < e.M) {       // refill for the same piece of the next slab
+                                            const float* rp = (const float*)e.res + (size_t)(row + 16) * e.ldres + ocol;
+                                            rf0[tp] = *(const f4*)rp;
+                                            rf1[tp] = *(const f4*)(rp + 4);
+                                        }
+                                    } else {
+                                        const float* rp = (const float*)e.res + (size_t)row * e.ldres + ocol;
+                                        const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) { x[i] += r0[i]; x[4 + i] += r1[i]; }
+                                    }
+                                } else {
+                                    const h8 rr = *(const h8*)(Rptr + (size_t)row * e.ldres + ocol);
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
+                                }
+                            }
+                            {
+                                // an 8-column chunk never straddles scale2_from (a multiple of 8, checked by op_igemm)
+                                const float sc = (e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) x[i] *= sc;
+                            }
+                            if (e.blend_mix) {   // AlphaBlender fold: (1-a) * this branch + a * the other branch
+                                const float al = __builtin_amdgcn_rcpf(1.0f + __expf(-e.blend_mix[0]));
+                                float bx[8];
+                                if (e.blend_f32) {
+                                    const float* bp = (const float*)e.blend_x + (size_t)row * e.ld_blend + ocol;
+                                    const f4 b0 = *(const f4*)bp, b1 = *(const f4*)(bp + 4);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) { bx[i] = b0[i]; bx[4 + i] = b1[i]; }
+                                } else {
+                                    const h8 bb = *(const h8*)((const half_t*)e.blend_x + (size_t)row * e.ld_blend + ocol);
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) bx[i] = (float)bb[i];
+                                }
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
+                            }
+                            if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
+                                h8 pk;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
+                                *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + ocol) = pk;
+                                if (e.out16_lo_off) {      // split operand: the rounding residual rides along (hi + lo == x to ~2^-22)
+                                    h8 lo;
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) lo[i] = (half_t)(x[i] - (float)pk[i]);
+                                    *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + e.out16_lo_off + ocol) = lo;
+                                }
+                            }
+                            int si = 0;
+#pragma unroll
+                            for (int k = 1; k < 3; ++k)
+                                if (k < e.nseg && ocol >= e.seg[k].col_begin) si = k;
+                            const IGemmSeg sg = si == 0 ? e.seg[0] : (si == 1 ? e.seg[1] : e.seg[2]);   // (constant indices: a dynamic one pins the whole descriptor in scratch)
+                            const size_t o = (size_t)row * sg.ld + (ocol - sg.col_begin) + (size_t)split * e.M * e.Nout;   // split > 0 only for fp32 slabs
+                            if (sg.dtype == DT_F16) {
+                                h8 pk;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
+                                *(h8*)((half_t*)sg.out + o) = pk;
+                            } else if (sg.dtype == DT_F32) {
+                                *(f4*)((float*)sg.out + o) = f4{x[0], x[1], x[2], x[3]};
+                                *(f4*)((float*)sg.out + o + 4) = f4{x[4], x[5], x[6], x[7]};
+                            } else {
+                                typedef u16 us8 __attribute__((ext_vector_type(8)));
+                                us8 pk;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
+                                *(us8*)((u16*)sg.out + o) = pk;
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
+                    }
+                }
+            } else {
+                // C/D fragment map of v_mfma_f32_16x16x32: row = (lane>>4)*4 + i, col = lane&15
+                const int erow = (lane >> 4) * 4, ecol = lane & 15;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (e.geglu && (ni & 1)) continue;           // odd fragments are the gates of the even ones
+                    const int pcb = n0 + wn * WN + ni * 16;      // packed column block start
+                    if (pcb >= e.Nout) continue;
+                    const int pcol = pcb + ecol;                 // packed column (bias index)
+                    const int ocol = e.geglu ? ((pcb >> 5) << 4) + ecol : pcol;   // output column
+                    const int ocb = ocol - ecol;
+                    // segment lookup (segment boundaries are multiples of 16 -> uniform per fragment)
+                    int si = 0;
+#pragma unroll
+                    for (int k = 1; k < 3; ++k)
+                        if (k < e.nseg && ocb >= e.seg[k].col_begin) si = k;
+                    const IGemmSeg sg = si == 0 ? e.seg[0] : (si == 1 ? e.seg[1] : e.seg[2]);   // (constant indices: a dynamic one pins the whole descriptor in scratch)
+                    const int scol = ocol - sg.col_begin;
+                    const float bh = e.bias ? e.bias[pcol] : 0.f;
+                    const float bg = (e.geglu && e.bias) ? e.bias[pcol + 16] : 0.f;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int rbase = m0 + wm * WM + mi * 16 + erow;
+                        if (rbase >= e.M) continue;
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = rbase + i;
+                            float x = acc[mi][ni][i] + bh;
+                            if (e.rowvec && row < e.M) x += e.rowvec[(size_t)(row / e.rows_per_img) * e.rowvec_ld + pcol];
+                            if (e.geglu) {
+                                const float g = acc[mi][ni + (NI > 1 ? 1 : 0)][i] + bg;
+                                x = x * gelu_erf_f(g);
+                            }
+                            if (e.act == 1) x = silu_f(x);
+                            if (Rptr && row < e.M)
+                                x += e.res_f32 ? ((const float*)e.res)[(size_t)row * e.ldres + ocol] : (float)Rptr[(size_t)row * e.ldres + ocol];
+                            v[i] = x * ((e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale);
+                        }
+                        if (sg.fmt == SEG_ROW) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int row = rbase + i;
+                                if (row < e.M) store_from_f32(sg.out, (size_t)row * sg.ld + scol, sg.dtype, v[i]);
+                            }
+                        } else {
+                            const int img = rbase / sg.L, tok = rbase - img * sg.L;
+                            const int dimg = sg.img_map ? sg.img_map[img] : img;
+                            const size_t base = ((size_t)dimg * sg.ncols + scol) * sg.ld + tok;
+                            const bool vec = ((sg.L & 3) == 0) && ((sg.ld & 3) == 0) && (rbase + 3 < e.M);
+                            if (vec) {
+                                if (sg.dtype == DT_F16) {
+                                    h4 p = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                                    *(h4*)((half_t*)sg.out + base) = p;
+                                } else if (sg.dtype == DT_F32) {
+                                    *(f4*)((float*)sg.out + base) = f4{v[0], v[1], v[2], v[3]};
+                                } else {
+                                    typedef u16 us4 __attribute__((ext_vector_type(4)));
+                                    us4 p = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+                                    *(us4*)((u16*)sg.out + base) = p;
+                                }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int row = rbase + i;
+                                    if (row >= e.M) break;
+                                    const int im = row / sg.L, tk = row - im * sg.L;
+                                    const int dm = sg.img_map ? sg.img_map[im] : im;
+                                    store_from_f32(sg.out, ((size_t)dm * sg.ncols + scol) * sg.ld + tk, sg.dtype, v[i]);
                                 }
                             }
                         }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) stg[(ecol + i) * SLT + mi * 16 + erow] = x[i] * a.scale;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    constexpr int CH8 = WM / 8;
-                    for (int idx = lane; idx < 16 * CH8; idx += 64) {
-                        const int ch = idx / CH8, c8 = idx - ch * CH8;
-                        const int row = wrow0 + c8 * 8;
-                        if (row >= a.M) continue;
-                        int img = row / sg.L;
-                        const int tok = row - img * sg.L;
-                        if (sg.img_map) img = sg.img_map[img];
-                        const size_t o = ((size_t)img * sg.ncols + (pcb - sg.col_begin) + ch) * sg.ld + tok;
-                        const f4 v0 = *(const f4*)(stg + ch * SLT + c8 * 8), v1 = *(const f4*)(stg + ch * SLT + c8 * 8 + 4);
-                        if (sg.dtype == DT_F16) {
-                            h8 pk = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
-                                     (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
-                            *(h8*)((half_t*)sg.out + o) = pk;
-                        } else if (sg.dtype == DT_F32) {
-                            *(f4*)((float*)sg.out + o) = v0;
-                            *(f4*)((float*)sg.out + o + 4) = v1;
-                        } else {
-                            typedef u16 us8 __attribute__((ext_vector_type(8)));
-                            us8 pk = {f32_to_bf16(v0[0]), f32_to_bf16(v0[1]), f32_to_bf16(v0[2]), f32_to_bf16(v0[3]),
-                                      f32_to_bf16(v1[0]), f32_to_bf16(v1[1]), f32_to_bf16(v1[2]), f32_to_bf16(v1[3])};
-                            *(us8*)((u16*)sg.out + o) = pk;
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
-            return;
+
+            if constexpr (PERSIST) {                   // next output tile of this workgroup
+                pending = false;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+                const int c_bid = first_bid + (++c_ti) * gstep;
+                if (c_bid < nblk) {
+                    int tile_m, tile_n;
+                    tileorder::tile_of(c_bid, ntm, ntn, order, &tile_m, &tile_n);
+                    m0 = tile_m * BM;
+                    n0 = tile_n * BN;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        constexpr int OWMAX = WN;                          // output columns of the wave tile (half of it with GEGLU)
-        constexpr int SLD = OWMAX + 4;                     // floats; +16 B keeps the b128 accesses conflict-light
-        float* stg = (float*)smem_raw + wave * (16 * SLD);
-        const int erow = lane & 15, ecol = (lane >> 4) * 4;
-        const int OW = a.geglu ? WN / 2 : WN;
-        const int OWC = OW >> 3;                           // 8-column chunks per row
-        const int wcol0 = a.geglu ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN);     // first output column of the wave tile
-        const int nout_eff = a.geglu ? (a.Nout >> 1) : a.Nout;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int row_w = m0 + wm * WM + mi * 16 + erow;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                if (a.geglu && (ni & 1)) continue;
-                const int pcb = n0 + wn * WN + ni * 16;
-                if (pcb >= a.Nout) continue;
-                const int pcol = pcb + ecol;
-                f4 x = acc[mi][ni];
-                if (a.bias) x += *(const f4*)(a.bias + pcol);
-                if (a.rowvec && row_w < a.M) x += *(const f4*)(a.rowvec + (size_t)(row_w / a.rows_per_img) * a.rowvec_ld + pcol);
-                if (a.geglu) {
-                    f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)];
-                    if (a.bias) g += *(const f4*)(a.bias + pcol + 16);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
-                }
-                if (a.act == 1) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
-                }
-                const int lcol = (a.geglu ? (ni >> 1) * 16 : ni * 16) + ecol;
-                *(f4*)(stg + erow * SLD + lcol) = x;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are in order; pin compiler order
-            for (int idx = lane; idx < 16 * OWC; idx += 64) {
-                const int r = idx / OWC, c8 = idx - r * OWC;
-                const int row = m0 + wm * WM + mi * 16 + r;
-                const int ocol = wcol0 + c8 * 8;
-                if (row >= a.M || ocol >= nout_eff) continue;
-                const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
-                float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if (Rptr) {
-                    if (a.res_f32) {
-                        const float* rp = (const float*)a.res + (size_t)row * a.ldres + ocol;
-                        const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { x[i] += r0[i]; x[4 + i] += r1[i]; }
-                    } else {
-                        const h8 rr = *(const h8*)(Rptr + (size_t)row * a.ldres + ocol);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
-                    }
-                }
-                {
-                    // an 8-column chunk never straddles scale2_from (a multiple of 8, checked by op_igemm)
-                    const float sc = (a.scale2_from > 0 && ocol >= a.scale2_from) ? a.scale2 : a.scale;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] *= sc;
-                }
-                if (a.blend_mix) {   // AlphaBlender fold: (1-a) * this branch + a * the other branch
-                    const float al = __builtin_amdgcn_rcpf(1.0f + __expf(-a.blend_mix[0]));
-                    float bx[8];
-                    if (a.blend_f32) {
-                        const float* bp = (const float*)a.blend_x + (size_t)row * a.ld_blend + ocol;
-                        const f4 b0 = *(const f4*)bp, b1 = *(const f4*)(bp + 4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { bx[i] = b0[i]; bx[4 + i] = b1[i]; }
-                    } else {
-                        const h8 bb = *(const h8*)((const half_t*)a.blend_x + (size_t)row * a.ld_blend + ocol);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) bx[i] = (float)bb[i];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
-                }
-                if (a.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
-                    h8 pk;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
-                    *(h8*)((half_t*)a.out16 + (size_t)row * a.ld16 + ocol) = pk;
-                    if (a.out16_lo_off) {      // split operand: the rounding residual rides along (hi + lo == x to ~2^-22)
-                        h8 lo;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) lo[i] = (half_t)(x[i] - (float)pk[i]);
-                        *(h8*)((half_t*)a.out16 + (size_t)row * a.ld16 + a.out16_lo_off + ocol) = lo;
-                    }
-                }
-                int si = 0;
-#pragma unroll
-                for (int k = 1; k < 3; ++k)
-                    if (k < a.nseg && ocol >= a.seg[k].col_begin) si = k;
-                const IGemmSeg sg = a.seg[si];
-                const size_t o = (size_t)row * sg.ld + (ocol - sg.col_begin) + (size_t)split * a.M * a.Nout;   // split > 0 only for fp32 slabs
-                if (sg.dtype == DT_F16) {
-                    h8 pk;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
-                    *(h8*)((half_t*)sg.out + o) = pk;
-                } else if (sg.dtype == DT_F32) {
-                    *(f4*)((float*)sg.out + o) = f4{x[0], x[1], x[2], x[3]};
-                    *(f4*)((float*)sg.out + o + 4) = f4{x[4], x[5], x[6], x[7]};
-                } else {
-                    typedef u16 us8 __attribute__((ext_vector_type(8)));
-                    us8 pk;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
-                    *(us8*)((u16*)sg.out + o) = pk;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
-        }
-        return;
-    }
-    // C/D fragment map of v_mfma_f32_16x16x32: row = (lane>>4)*4 + i, col = lane&15
-    const int erow = (lane >> 4) * 4, ecol = lane & 15;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        if (a.geglu && (ni & 1)) continue;           // odd fragments are the gates of the even ones
-        const int pcb = n0 + wn * WN + ni * 16;      // packed column block start
-        if (pcb >= a.Nout) continue;
-        const int pcol = pcb + ecol;                 // packed column (bias index)
-        const int ocol = a.geglu ? ((pcb >> 5) << 4) + ecol : pcol;   // output column
-        const int ocb = ocol - ecol;
-        // segment lookup (segment boundaries are multiples of 16 -> uniform per fragment)
-        int si = 0;
-#pragma unroll
-        for (int k = 1; k < 3; ++k)
-            if (k < a.nseg && ocb >= a.seg[k].col_begin) si = k;
-        const IGemmSeg sg = a.seg[si];
-        const int scol = ocol - sg.col_begin;
-        const float bh = a.bias ? a.bias[pcol] : 0.f;
-        const float bg = (a.geglu && a.bias) ? a.bias[pcol + 16] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int rbase = m0 + wm * WM + mi * 16 + erow;
-            if (rbase >= a.M) continue;
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = rbase + i;
-                float x = acc[mi][ni][i] + bh;
-                if (a.rowvec && row < a.M) x += a.rowvec[(size_t)(row / a.rows_per_img) * a.rowvec_ld + pcol];
-                if (a.geglu) {
-                    const float g = acc[mi][ni + (NI > 1 ? 1 : 0)][i] + bg;
-                    x = x * gelu_erf_f(g);
-                }
-                if (a.act == 1) x = silu_f(x);
-                if (Rptr && row < a.M)
-                    x += a.res_f32 ? ((const float*)a.res)[(size_t)row * a.ldres + ocol] : (float)Rptr[(size_t)row * a.ldres + ocol];
-                v[i] = x * ((a.scale2_from > 0 && ocol >= a.scale2_from) ? a.scale2 : a.scale);
-            }
-            if (sg.fmt == SEG_ROW) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = rbase + i;
-                    if (row < a.M) store_from_f32(sg.out, (size_t)row * sg.ld + scol, sg.dtype, v[i]);
-                }
-            } else {
-                const int img = rbase / sg.L, tok = rbase - img * sg.L;
-                const int dimg = sg.img_map ? sg.img_map[img] : img;
-                const size_t base = ((size_t)dimg * sg.ncols + scol) * sg.ld + tok;
-                const bool vec = ((sg.L & 3) == 0) && ((sg.ld & 3) == 0) && (rbase + 3 < a.M);
-                if (vec) {
-                    if (sg.dtype == DT_F16) {
-                        h4 p = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *(h4*)((half_t*)sg.out + base) = p;
-                    } else if (sg.dtype == DT_F32) {
-                        *(f4*)((float*)sg.out + base) = f4{v[0], v[1], v[2], v[3]};
-                    } else {
-                        typedef u16 us4 __attribute__((ext_vector_type(4)));
-                        us4 p = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
-                        *(us4*)((u16*)sg.out + base) = p;
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int row = rbase + i;
-                        if (row >= a.M) break;
-                        const int im = row / sg.L, tk = row - im * sg.L;
-                        const int dm = sg.img_map ? sg.img_map[im] : im;
-                        store_from_f32(sg.out, ((size_t)dm * sg.ncols + scol) * sg.ld + tk, sg.dtype, v[i]);
-                    }
-                }
-            }
+        if constexpr (!PERSIST) {
+            break;
+        } else {
+            if (f == nf) break;
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            if (s_f < nf) stage_next();
+            load_frags(slot_of(f), bslot_of(f));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 1 && f + 1 < nf) wait_tile(f + 1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            compute();
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (++c_k == nk) { c_k = 0; pending = true; }
         }
     }
 }
@@ -656,6 +819,44 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmArgs a, const f
 
 const half_t* zero_page() { return (const half_t*)device_zero_page(); }
 
+// ---- tile walk order (tile_order.h) ----
+// CTRL_IGEMM_ORDER / ctrl_igemm_set_order(): "auto" (default, below), "legacy", or a forced "m,G" / "n,G".
+struct OrderSpec { int kind; int mode; int group; };       // kind 0 legacy, 1 auto, 2 forced
+OrderSpec g_order_spec = {-1, 0, 0};
+
+OrderSpec parse_order(const char* t) {
+    if (!t || !*t || !strcmp(t, "legacy") || !strcmp(t, "0")) return {0, 0, 0};
+    if (!strcmp(t, "auto")) return {1, 0, 0};
+    if ((t[0] == 'm' || t[0] == 'n') && t[1] == ',') {
+        const int g = atoi(t + 2);
+        if (g >= 0 && g < 65536) return {2, t[0] == 'm' ? tileorder::ORDER_XCD_M : tileorder::ORDER_XCD_N, g};
+    }
+    return {-2, 0, 0};
+}
+
+// "auto" = what was measured (tools/gemm_order_bench.cpp -> profiles/r02_tile_order_experiment.txt): a token GEMM whose
+// weights do not fit in an XCD's L2 beside the activation / output streams (the 512 -> 4096 GEGLU projection, 4 MiB) walks
+// its weight panels in groups of <= 1 MiB under the legacy XCD split of the rows: 0.844 -> 0.786 ms at M = 131072, results
+// bit-identical; the same walk is neutral on the other wide GEMMs of the path (M = 32768 and the ControlNet's GEGLUs), and
+// splitting the weight panels over the XCDs instead ("n,G") never won.  Everything else keeps the legacy walk.
+int plan_order(const IGemmArgs& a, int BM, int BN, int ntm, int ntn) {
+    if (g_order_spec.kind == -1) {
+        const char* e = getenv("CTRL_IGEMM_ORDER");
+        g_order_spec = e ? parse_order(e) : OrderSpec{1, 0, 0};
+        if (g_order_spec.kind == -2) { fprintf(stderr, "ctrl: CTRL_IGEMM_ORDER not understood, using auto\n"); g_order_spec = {1, 0, 0}; }
+    }
+    (void)BM;
+    const OrderSpec sp = g_order_spec;
+    if (sp.kind == 0) return 0;
+    if (sp.kind == 2) return tileorder::make_order(sp.mode, sp.group);
+    if (a.mode != IG_ROWS || (ntm & 7) != 0) return 0;
+    const double panel = (double)BN * a.Ktot * 2.0, weights = (double)a.Nout * a.Ktot * 2.0;      // bytes
+    if (weights <= 2.0 * 1024 * 1024) return 0;
+    int G = (int)(1024.0 * 1024.0 / panel);
+    if (G < 1) G = 1;
+    return G < ntn ? tileorder::make_order(tileorder::ORDER_XCD_M, G) : 0;
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
 int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
@@ -674,12 +875,13 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     const half_t* zeros = zero_page();
     CTRL_CHECK(zeros != nullptr, "igemm: could not allocate the zero page");
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
+    const int order = plan_order(a, BM, BN, ntm, ntn);
     // algorithmic work = the reference op's: a split operand doubles the K the kernel walks, not the FLOPs that count
     const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
     PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
-    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
+    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s, false>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
     if (splitk > 1) {
         // partial sums go to fp32 slabs [splitk][M][Nout]; every epilogue term is applied once, by the finish kernel
         IGemmArgs p = a;
@@ -690,7 +892,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         prof_detail("M%d N%d K%d taps%d%s splitk%d", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
         sym();
         LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn * splitk),
-               dim3(WAVES_M * WAVES_N * 64), smem, s, p, ntm, ntn, zeros, splitk);
+               dim3(WAVES_M * WAVES_N * 64), smem, s, p, ntm, ntn, zeros, splitk, order);
         const size_t total = (size_t)a.M * (a.Nout / 8);
         size_t blocks = (total + 255) / 256;
         if (blocks > 4096) blocks = 4096;
@@ -701,7 +903,46 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     }
     sym();
     LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
-           a, ntm, ntn, zeros, 1);
+           a, ntm, ntn, zeros, 1, order);
+    return 0;
+}
+
+// Persistent form (igemm_persist_kernel): one workgroup per CU, ring + epilogue staging side by side in LDS.
+int g_persist = -1;                 // -1 = read CTRL_IGEMM_PERSIST on first use
+bool persist_enabled() {
+    if (g_persist < 0) { const char* e = getenv("CTRL_IGEMM_PERSIST"); g_persist = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    return g_persist > 0;
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE>
+int launch_persist(const IGemmArgs& a, hipStream_t s) {
+    constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
+    constexpr int BNP = (BN + PASSROWS - 1) / PASSROWS * PASSROWS;
+    constexpr size_t ring = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
+    constexpr size_t stage_bytes = (size_t)WAVES_M * WAVES_N * 16 * (BN / WAVES_N + 4) * sizeof(float);     // row-major outputs only
+    constexpr size_t smem = ring + stage_bytes + ((sizeof(IGemmArgs) + 15) & ~(size_t)15);       // + the descriptor copy the epilogues read
+    static_assert(smem <= 160 * 1024, "persistent tile does not fit the 160 KiB LDS");
+    static bool attr_done[kMaxDevices] = {};
+    static int cus[kMaxDevices] = {};
+    const int dev = cur_device();
+    if (!attr_done[dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done[dev] = true;
+    }
+    const half_t* zeros = zero_page();
+    CTRL_CHECK(zeros != nullptr, "igemm: could not allocate the zero page");
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
+    const int order = plan_order(a, BM, BN, ntm, ntn);
+    const int nblk = ntm * ntn, grid = nblk < cus[dev] ? nblk : cus[dev];
+    const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
+    PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
+    prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
+    const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
+    prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, true, true>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE);
+    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, true, true>), dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s,
+           a, ntm, ntn, zeros, 1, order);
     return 0;
 }
 
@@ -728,7 +969,21 @@ bool can_swap(const IGemmArgs& a) {
 }
 
 }  // namespace
+int igemm_set_persist(int on) { g_persist = on > 0 ? on : 0; return 0; }
+
 // number of K splits op_igemm will use for this problem (1 = none); callers size splitk_ws = factor*M*Nout*4 bytes
+
+int igemm_set_order(const char* spec) {
+    const OrderSpec sp = parse_order(spec);
+    if (sp.kind < 0) return 1;
+    g_order_spec = sp;
+    return 0;
+}
+
+void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n) {
+    tileorder::tile_of(bid, ntm, ntn, tileorder::make_order(mode, group), tile_m, tile_n);
+}
+
 int igemm_splitk_factor(const IGemmArgs& a) {
     if (a.geglu || a.nseg != 1 || a.seg[0].fmt != SEG_ROW || a.Nout % 64 != 0 || a.Cin % 32 != 0 || a.mode == IG_TEMPORAL) return 1;
     const int bn = (a.Nout % 320 == 0) ? 320 : 256;
@@ -766,6 +1021,8 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
             return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
         }
     }
+    if (persist_enabled() && can_swap(a) && a.seg[0].fmt == SEG_ROW && a.a_split != 2 && tiles(256, 256) >= 256 && eff(256) > 0.9)
+        return launch_persist<256, 256, 32, 2, 4, 3, MODE>(a, s);       // opt-in (CTRL_IGEMM_PERSIST / ctrl_igemm_set_persist)
     if (const char* f = getenv("CTRL_IGEMM_FORCE")) {      // tile experiments (tools/tile_experiment.py), row outputs only
         if (can_swap(a) && MODE == IG_ROWS) {
             if (!strcmp(f, "128x256")) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);

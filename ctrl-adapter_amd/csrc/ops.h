@@ -17,6 +17,10 @@ typedef ctrl_igemm_desc IGemmArgs;
 int op_igemm(const IGemmArgs& a, hipStream_t s);
 // K-split factor op_igemm would use given scratch (1 = no split); scratch needed = factor * M * Nout * sizeof(float)
 int igemm_splitk_factor(const IGemmArgs& a);
+// tile walk order of the implicit GEMM (tile_order.h): "legacy" | "auto" | "m,G" | "n,G"; 0 = accepted
+int igemm_set_order(const char* spec);
+int igemm_set_persist(int on);      // persistent workgroups for the wide tiles (0 off, 1 on); also CTRL_IGEMM_PERSIST
+void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
 // convenience: plain linear out[M][N] (fp16 row-major) = A[M][K] * W[N][K]^T + bias
 int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, half_t* out, long ldo,
               int M, int N, int K, const half_t* res, long ldres, hipStream_t s);

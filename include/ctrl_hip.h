@@ -98,6 +98,17 @@ typedef struct ctrl_igemm_desc {
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
+/* Walk order of the GEMM's output tiles over the 8 XCDs (csrc/tile_order.h; performance only, results are identical):
+   "auto" (default; also CTRL_IGEMM_ORDER: grouped walk for row GEMMs whose weights exceed an XCD's L2 share), "legacy", or
+   forced "m,G" / "n,G" (XCDs split the activation panels / the weight panels, weight panels walked in groups of G tiles).
+   0 = accepted.
+   ctrl_igemm_tile_of: the (tile_m, tile_n) workgroup `bid` of an ntm x ntn grid computes under (mode 0|1|2, group) --
+   a diagnostic the host tests use to prove every order is a bijection. */
+int ctrl_igemm_set_order(const char* spec);
+/* persistent-workgroup form of the wide GEMM tiles (one workgroup per CU walks its tiles with one LDS ring running across
+   them); performance only, bit-identical results.  0 = off, 1 = on; default from CTRL_IGEMM_PERSIST */
+int ctrl_igemm_set_persist(int on);
+int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
 
 typedef struct ctrl_attn_desc {
     const void* Q; int64_t ldq;      /* [B*Lq][ldq] fp16, head h at column h*D */

@@ -29,10 +29,12 @@ def kernel_class(name):
 
 def symbol_of(name):
     """rocprofv3 kernel name (mangled or demangled) -> the symbol spelling the library's profiler / bench.py uses"""
-    m = re.search(r"igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
+    m = re.search(r"igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E(?:Lb([01])E)?", name)
     if m:
         g = m.groups()
-        return "igemm_kernel<%s, %s, %s, %s, %s, %s, %s, %s>" % (g[:7] + ("true" if g[7] == "1" else "false",))
+        tf = lambda v: "true" if v == "1" else "false"
+        # (the 9th argument -- persistent-workgroup form -- exists from round 2's last build on; older traces lack it)
+        return "igemm_kernel<%s, %s, %s, %s, %s, %s, %s, %s%s>" % (g[:7] + (tf(g[7]), ", " + tf(g[8]) if g[8] is not None else ""))
     m = re.search(r"flash_attn_kernelILi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
     if m:
         tf = lambda v: "true" if v == "1" else "false"
