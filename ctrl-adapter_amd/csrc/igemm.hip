@@ -1021,7 +1021,7 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
             return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
         }
     }
-    if (persist_enabled() && can_swap(a) && a.seg[0].fmt == SEG_ROW && a.a_split != 2 && tiles(256, 256) >= 256 && eff(256) > 0.9)
+    if (MODE == IG_ROWS && persist_enabled() && can_swap(a) && a.seg[0].fmt == SEG_ROW && a.a_split != 2 && tiles(256, 256) >= 256 && eff(256) > 0.9)
         return launch_persist<256, 256, 32, 2, 4, 3, MODE>(a, s);       // opt-in (CTRL_IGEMM_PERSIST / ctrl_igemm_set_persist)
     if (const char* f = getenv("CTRL_IGEMM_FORCE")) {      // tile experiments (tools/tile_experiment.py), row outputs only
         if (can_swap(a) && MODE == IG_ROWS) {

@@ -91,6 +91,18 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     L.check(L.lib().ctrl_op_igemm(C.byref(d), L.cur_stream()))
 
 
+def set_igemm_order(spec):
+    """tile walk of the implicit GEMM over the XCDs: "auto" (default) | "legacy" | "m,G" | "n,G" (csrc/tile_order.h); results
+    do not depend on it"""
+    if L.lib().ctrl_igemm_set_order(spec.encode()) != 0:
+        raise ValueError("unknown tile walk order %r" % (spec,))
+
+
+def set_igemm_persist(on):
+    """persistent-workgroup form of the wide row-GEMM tiles (opt-in; bit-identical results)"""
+    L.lib().ctrl_igemm_set_persist(int(bool(on)))
+
+
 def linear(x, w_packed, bias=None, res=None, geglu=False):
     """x [M][K] fp16 -> [M][N] fp16 (N/2 for GEGLU)"""
     M, K = x.shape

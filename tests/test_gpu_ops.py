@@ -430,3 +430,40 @@ def test_two_workgroup_tiles_at_large_m(ops, gpu, K, geglu, f32):
         ops.igemm(x.half().to(gpu), K, wp, M, N, K, bias=bp, res=r.to(gpu), ldres=N, segs=[(out, N, 0, N, ops.SEG_ROW, 1)], out16=mirror, ld16=N)
         report("2-WG tile f32 stream K%d master" % K, rel_inf(out, ref), 2e-5)
         report("2-WG tile f32 stream K%d mirror" % K, rel_inf(mirror, ref))
+
+
+def test_tile_walk_orders_and_persistent_form_are_bit_identical(ops, gpu):
+    """csrc/tile_order.h only decides WHICH workgroup computes a tile, and the persistent-workgroup form only how many tiles
+    a workgroup walks: every order and both forms must give the same bits (GEGLU with bias; fp32 stream update with fp32
+    residual + fp16 mirror; a ragged M), and the fp32 result matches the fp32 reference"""
+    try:
+        for (M, N, K, geglu) in [(16384, 4096, 512, True), (16384 - 24, 2048, 320, False)]:
+            x, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.05), rnd(N, seed=13)
+            wp, bp = ops.pack_linear_w(w.to(gpu), geglu=geglu), ops.pack_vec(b.to(gpu), geglu=geglu)
+            xg = x.half().to(gpu)
+            r = torch.randn(M, N, generator=torch.Generator().manual_seed(14)).to(gpu)
+
+            def run():
+                if geglu:
+                    return (ops.linear(xg, wp, bias=bp, geglu=True),)
+                out = torch.empty(M, N, dtype=torch.float32, device=gpu)
+                mirror = torch.empty(M, N, dtype=torch.float16, device=gpu)
+                ops.igemm(xg, K, wp, M, N, K, bias=bp, res=r, ldres=N, segs=[(out, N, 0, N, ops.SEG_ROW, 1)], out16=mirror, ld16=N)
+                return out, mirror
+            ops.set_igemm_order("legacy")
+            ops.set_igemm_persist(False)
+            base = run()
+            for spec, persist in [("auto", False), ("m,1", False), ("m,3", False), ("n,0", False), ("n,2", False), ("legacy", True), ("m,4", True)]:
+                ops.set_igemm_order(spec)
+                ops.set_igemm_persist(persist)
+                got = run()
+                for g, want in zip(got, base):
+                    assert torch.equal(g, want), (M, N, K, spec, persist)
+            if not geglu:
+                ref = x.half().float() @ w.half().float().t() + b + r.cpu()
+                report("tile walk / persistent form, fp32 stream", rel_inf(base[0], ref), 2e-5)
+        with pytest.raises(ValueError):
+            ops.set_igemm_order("sideways")
+    finally:
+        ops.set_igemm_order("auto")
+        ops.set_igemm_persist(False)
