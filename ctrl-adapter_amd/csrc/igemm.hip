@@ -604,26 +604,30 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
                                     *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + e.out16_lo_off + ocol) = lo;
                                 }
                             }
-                            int si = 0;
-#pragma unroll
-                            for (int k = 1; k < 3; ++k)
-                                if (k < e.nseg && ocol >= e.seg[k].col_begin) si = k;
-                            const IGemmSeg sg = si == 0 ? e.seg[0] : (si == 1 ? e.seg[1] : e.seg[2]);   // (constant indices: a dynamic one pins the whole descriptor in scratch)
-                            const size_t o = (size_t)row * sg.ld + (ocol - sg.col_begin) + (size_t)split * e.M * e.Nout;   // split > 0 only for fp32 slabs
-                            if (sg.dtype == DT_F16) {
+                            // Segment of this 8-column piece (the last one whose first column is <= ocol).  The descriptors are
+                            // kernel arguments, i.e. scalars: selected FIELD by FIELD they stay in scalar registers.  Selecting the
+                            // struct (`seg[si]`, si per lane) made every lane load its copy from memory and wait for it -- and, the
+                            // counter being shared and in order, for every store issued before it -- once per 16-byte piece.
+                            const bool in1 = e.nseg > 1 && ocol >= e.seg[1].col_begin, in2 = e.nseg > 2 && ocol >= e.seg[2].col_begin;
+                            void* const sg_out = in2 ? e.seg[2].out : (in1 ? e.seg[1].out : e.seg[0].out);
+                            const int64_t sg_ld = in2 ? e.seg[2].ld : (in1 ? e.seg[1].ld : e.seg[0].ld);
+                            const int sg_cb = in2 ? e.seg[2].col_begin : (in1 ? e.seg[1].col_begin : e.seg[0].col_begin);
+                            const int sg_dt = in2 ? e.seg[2].dtype : (in1 ? e.seg[1].dtype : e.seg[0].dtype);
+                            const size_t o = (size_t)row * sg_ld + (ocol - sg_cb) + (size_t)split * e.M * e.Nout;   // split > 0 only for fp32 slabs
+                            if (sg_dt == DT_F16) {
                                 h8 pk;
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
-                                *(h8*)((half_t*)sg.out + o) = pk;
-                            } else if (sg.dtype == DT_F32) {
-                                *(f4*)((float*)sg.out + o) = f4{x[0], x[1], x[2], x[3]};
-                                *(f4*)((float*)sg.out + o + 4) = f4{x[4], x[5], x[6], x[7]};
+                                *(h8*)((half_t*)sg_out + o) = pk;
+                            } else if (sg_dt == DT_F32) {
+                                *(f4*)((float*)sg_out + o) = f4{x[0], x[1], x[2], x[3]};
+                                *(f4*)((float*)sg_out + o + 4) = f4{x[4], x[5], x[6], x[7]};
                             } else {
                                 typedef u16 us8 __attribute__((ext_vector_type(8)));
                                 us8 pk;
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
-                                *(us8*)((u16*)sg.out + o) = pk;
+                                *(us8*)((u16*)sg_out + o) = pk;
                             }
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
