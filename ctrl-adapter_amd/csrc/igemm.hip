@@ -492,10 +492,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
                     // for a store (loads and stores share one in-order counter)
                     constexpr int RT = (16 * (OWMAX / 8) + 63) / 64;       // pieces per lane per 16-row slab
                     // ... fetched ahead: the wide one-workgroup-per-CU tiles only (256 registers per wave; the two-workgroup
-                    // tiles live in 128 and overlap their epilogue with the other workgroup's k-loop instead), and at most two
-                    // pieces (the 80-wide wave tile has no registers for a third)
+                    // tiles live in 128 and overlap their epilogue with the other workgroup's k-loop instead); the 80-wide wave
+                    // tile (three pieces per lane, 160 accumulator registers) has room for one
                     constexpr bool RES_AHEAD = (WM * WN >= 128 * 64) && (MinWaves<BM, BN, NW>::v == 1 || PERSIST);
-                    constexpr int RTP = !RES_AHEAD ? 0 : (RT > 2 ? 2 : RT);
+                    constexpr int RTP = !RES_AHEAD ? 0 : (RT > 2 ? 1 : RT);
                     f4 rf0[RTP ? RTP : 1], rf1[RTP ? RTP : 1];
 #pragma unroll
                     for (int t = 0; t < RTP; ++t) {
