@@ -11,13 +11,15 @@ weights of the real architectures (361 M + 184 M / 587 M parameters).
 `--gpus N` with N > 1 launches the N ranks itself (re-executes under `python -m torch.distributed.run`, one rank per
 GPU over RCCL, 127.0.0.1 rendezvous); started under a launcher already (RANK / WORLD_SIZE in the environment) it joins it.
 
-Prints ONE JSON line (rank 0).  Besides the driver contract it carries:
+Rank 0 prints the headline as the LAST stdout line, ONE JSON object of < 2 KB.  Besides the driver contract it carries:
   roofline      ONE kernel (symbol with template arguments + shape): algorithmic FLOPs per launch / HIP-event time per
                 launch on the launch stream, vs the dense fp16 MFMA peak; `traffic` = PMC HBM bytes per launch of that
                 kernel from the committed rocprofv3 passes (profiles/, tools/profile_round.sh)
-  per_kernel    the same for every (template instantiation, shape) of the step, sorted by time
-  kernels       per kernel class (what the library's profiler tags)
-  cpu_baseline  the pure-PyTorch fp32 oracle on the host cores: the whole step of this workload, 1 warm-up + 3 repetitions
+  cpu_baseline  the pure-PyTorch fp32 oracle on the host cores: ONE pass over the whole step of this workload (the same
+                inputs the HIP step was timed on); its outputs are kept and compared with the HIP step's:
+  parity_at_bench_config   worst rel-inf over the 13 ControlNet + 12 (+ mid) adapter tensors, HIP step vs oracle
+The per-kernel table (every template instantiation x shape of the step, sorted by time) and the per-class table go to a
+FILE (`--per-kernel-out`, default bench_per_kernel.json next to this script), never to stdout.
 """
 import argparse
 import glob
@@ -136,6 +138,8 @@ def main():
     ap.add_argument("--workload", default="sdxl", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-kernel-out", default=os.path.join(ROOT, "bench_per_kernel.json"),
+                    help="where rank 0 writes the per-kernel / per-class tables (they are too long for the headline line)")
     ap.add_argument("--fused", action="store_true",
                     help="time the fused controlled_step(controlnet, adapter, ...) instead of the pipelines' two calls "
                          "controlnet(...) ; adapter(...) (same arithmetic, bit-identical results)")
@@ -182,12 +186,12 @@ def main():
     def step_separate():
         s = P.pool_latents(x["latents"], (64, 64))
         down, mid = controlnets(s)
-        return ad(down, mid_block_res_sample=mid, num_frames=nf, timestep=t, encoder_hidden_states=x["ehs_a"])
+        return (down, mid), ad(down, mid_block_res_sample=mid, num_frames=nf, timestep=t, encoder_hidden_states=x["ehs_a"])
 
     def step_fused():
         s = P.pool_latents(x["latents"], (64, 64))
         return P.controlled_step(cns[0], ad, s, t, x["ehs_c"], x["cond0"], 1.0, skip_conv_in=w["skip_conv_in"], num_frames=nf,
-                                 adapter_encoder_hidden_states=x["ehs_a"])[1]
+                                 adapter_encoder_hidden_states=x["ehs_a"])
 
     if args.fused and w["n_cn"] != 1:
         raise SystemExit("--fused covers one ControlNet")
@@ -235,7 +239,7 @@ def main():
             for _ in range(args.warmup):
                 g2.replay()
             el2 = dp.timed_region(g2.replay, args.steps, device=dev)
-            fused = {"call_form": "controlled_step(controlnet, adapter, ...)", "ms_per_step": round(el2 / args.steps * 1e3, 3),
+            fused = {"ms_per_step": round(el2 / args.steps * 1e3, 3),
                      "value": round(dp.aggregate_throughput(1, args.steps, el2, world), 3)}
         except Exception as e:
             print("bench: fused leg skipped (%s)" % str(e).split("\n")[0], file=sys.stderr)
@@ -284,14 +288,20 @@ def main():
                         "bytes_per_launch": r["bytes_per_launch"], "avg_launch_ms": r["avg_launch_ms"],
                         "launches_per_step": r["launches_per_step"], "ms_per_step": round(r["ms_per_step"], 4)}
 
-    # ---- cpu_baseline leg: the fp32 oracle on the host cores, the whole step of this workload (rank 0, N=1 only) ----
-    cpu = None
+    # ---- cpu_baseline leg: the fp32 oracle on the host cores, ONE pass over the whole step of this workload (rank 0, N=1
+    #      only) on the very inputs the HIP step was timed on; its outputs are the parity check of the benched configuration ----
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import cases  # noqa: F401
         from oracle.init import seeded_init
         from oracle.controlnet import ControlNetOracle
         from oracle.adapter import ControlNetAdapterOracle
         from oracle.router import RouterOracle, merge_inference
+        (hd, hm), (ha, ham) = step()                 # the HIP step, eager, same plans / inputs as the timed graph
+        torch.cuda.synchronize()
+        hip_out = [("controlnet.down%d" % i, v.float().cpu()) for i, v in enumerate(hd)] + [("controlnet.mid", hm.float().cpu())] + \
+                  [("adapter.down%d" % i, v.float().cpu()) for i, v in enumerate(ha)] + \
+                  ([("adapter.mid", ham.float().cpu())] if ham is not None else [])
         cores = min(os.cpu_count() or 1, 32)        # more threads than this slow the fp32 oracle down (NUMA / oversubscription)
         torch.set_num_threads(cores)
         ocs = [seeded_init(ControlNetOracle(cross_attention_dim=768).eval(), seed=11 + 100 * k) for k in range(w["n_cn"])]
@@ -308,34 +318,58 @@ def main():
             else:
                 dw, mw = orr(sparse_mask=masks)
                 d, m = merge_inference([o[0] for o in outs], [o[1] for o in outs], dw, mw, masks, nf)
-            return oa(d, mid_block_res_sample=m if w["video"] else None, num_frames=nf, timestep=tc, encoder_hidden_states=xc["ehs_a"])
-        cpu_step()                                  # warm-up
-        reps = 3
+            return (d, m), oa(d, mid_block_res_sample=m if w["video"] else None, num_frames=nf, timestep=tc, encoder_hidden_states=xc["ehs_a"])
         c0 = time.perf_counter()
-        for _ in range(reps):
-            cpu_step()
-        per_step = (time.perf_counter() - c0) / reps
+        (od, om), (oad, oam) = cpu_step()
+        per_step = time.perf_counter() - c0
         cpu = {"value": round(1.0 / per_step, 5), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-               "sample": "the whole step of this workload (N=%d), 1 warm-up + %d repetitions, fp32 PyTorch oracle on %d threads: "
-                         "%.2f s per step" % (n, reps, cores, per_step)}
+               "sample": "one pass over the whole step of this workload (N=%d, the timed inputs), fp32 PyTorch oracle on %d "
+                         "threads: %.2f s" % (n, cores, per_step)}
+        ref_out = list(od) + [om] + list(oad) + ([oam] if oam is not None else [])
+        worst, worst_name, zeros_ok, ntens = 0.0, None, True, 0
+        for (name, a), b in zip(hip_out, ref_out):
+            ntens += 1
+            den = b.abs().max().item()
+            if den == 0.0:                           # non-selected adapter slots are zeros_like (model/ctrl_adapter.py:193)
+                zeros_ok = zeros_ok and a.abs().max().item() == 0.0
+                continue
+            e = ((a - b).abs().max() / den).item()
+            if not (e <= worst):                     # NaN-propagating maximum
+                worst, worst_name = e, name
+        parity = {"rel_inf_worst": float("%.3e" % worst), "tensor": worst_name, "tensors": ntens, "zero_slots_exact": zeros_ok,
+                  "bound": 1e-3, "ok": bool(worst <= 1e-3 and zeros_ok),
+                  "what": "HIP step (these plans, these %d distinct inputs) vs fp32 oracle -> oracle chain" % n}
 
     if rank == 0:
         flops_step = step_flops(w, n)
+        if kernels or per_kernel:
+            try:
+                with open(args.per_kernel_out, "w") as fh:
+                    json.dump({"workload": args.workload, "batch_per_gpu": n, "ms_per_step": round(ms_per_step, 3),
+                               "kernels": kernels, "per_kernel": per_kernel}, fh, indent=0)
+            except OSError as e:
+                print("bench: per-kernel table not written (%s)" % e, file=sys.stderr)
+        top = [{"kernel": r["kernel"][:96], "ms_per_step": r["ms_per_step"], "frac": r["frac"]} for r in per_kernel[1:4]]
         line = {
             "metric": w["metric"], "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f16",    # MFMA operands fp16; fp32 accumulate / statistics / softmax / residual streams
             "data": "synthetic latents, prompts, condition images; seeded random weights",
-            "config": {"workload": (w["what"] % (n, n)) if "%d" in w["what"] else w["what"], "baseline_config": w["config"],
-                       "batch_per_gpu": n, "parallelism": "dp%d (images / whole clips sharded, no collective)" % world, "launch": mode,
-                       "call_form": "controlnet(...) ; adapter(...)" if not args.fused else
-                                    "controlled_step(controlnet, adapter, ...) = both forwards, overlapped (bit-identical results)"},
+            "config": {"workload": args.workload + ": " + ((w["what"] % (n, n)) if "%d" in w["what"] else w["what"])[:150],
+                       "baseline_config": w["config"], "batch_per_gpu": n, "parallelism": "dp%d, no collective" % world,
+                       "launch": mode, "call_form": "controlnet(...) ; adapter(...)" if not args.fused else "controlled_step(...)"},
             "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
             "mfma_frac_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "fused_step": fused, "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "per_kernel": per_kernel,
+            "fused_step": fused, "roofline": roof, "cpu_baseline": cpu, "parity_at_bench_config": parity,
+            "next_kernels": top, "per_kernel_file": os.path.basename(args.per_kernel_out) if (kernels or per_kernel) else None,
         }
-        print(json.dumps(line))
+        out = json.dumps(line)
+        if len(out) > 2000:                          # the driver keeps an 8 KB tail of stdout: the headline must fit
+            line.pop("next_kernels", None)
+            out = json.dumps(line)
+        sys.stdout.flush()
+        print(out, flush=True)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
