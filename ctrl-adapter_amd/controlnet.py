@@ -139,9 +139,12 @@ class ControlNetModel(ParamTreeModule):
         if isinstance(conditioning_scale, (int, float)) and conditioning_scale == 0:
             # control switched off for this step (controlnet_keep == 0, sdxl pipeline :1262-1266): every output of the
             # reference is `conv(x) * 0`; return the zeros without running the network (SURVEY.md note N8)
-            down = [torch.zeros(N, c, max(Hs // f, 1), max(Ws // f, 1), dtype=out_dtype, device=sample.device)
+            # (global_pool_conditions: the reference's outputs are the [N, C, 1, 1] spatial means, controlnet.py:870-874)
+            pooled = bool(self.config.get("global_pool_conditions", False))
+            down = [torch.zeros(N, c, 1 if pooled else max(Hs // f, 1), 1 if pooled else max(Ws // f, 1), dtype=out_dtype, device=sample.device)
                     for c, f in zip(self._slot_channels, self._slot_factor)]
-            mid = torch.zeros(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device)
+            mid = torch.zeros(N, self._slot_channels[-1], 1 if pooled else max(Hs // 8, 1), 1 if pooled else max(Ws // 8, 1),
+                              dtype=out_dtype, device=sample.device)
             return ControlNetOutput(down, mid) if return_dict else (down, mid)
         pool = bool(self.config.get("global_pool_conditions", False))
         # guess-mode scaling is skipped for globally pooled conditions (controlnet/controlnet.py:861)

@@ -11,7 +11,6 @@ int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream) {
     return op_igemm(*d, S(stream));
 }
 int ctrl_igemm_set_order(const char* spec) { return igemm_set_order(spec); }
-int ctrl_igemm_set_persist(int on) { return igemm_set_persist(on); }
 int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n) {
     CTRL_CHECK(tile_m && tile_n && ntm > 0 && ntn > 0 && bid >= 0 && bid < ntm * ntn, "igemm_tile_of: bad arguments");
     igemm_tile_of(bid, ntm, ntn, mode, group, tile_m, tile_n);
@@ -20,6 +19,10 @@ int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile
 int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream) {
     CTRL_CHECK(d != nullptr, "flash_attn: null descriptor");
     return op_flash_attn(*d, S(stream));
+}
+int ctrl_attn_set_variant(int v) {
+    CTRL_CHECK(v >= -1 && v <= 32, "attn_set_variant: variant out of range (-1 = default, 0 = round-2 kernel, 1.. = attention_d64.hip)");
+    return attn_set_variant(v);
 }
 int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream) {
     CTRL_CHECK(d != nullptr, "temporal_attn: null descriptor");

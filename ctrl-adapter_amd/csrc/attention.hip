@@ -447,6 +447,11 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs a) {
 
 }  // namespace
 
+// attention_d64.hip: the head_dim-64 long-sequence kernel family (variant 0 = the kernel above)
+bool flash_attn_d64_applies(const AttnArgs& a);
+int op_flash_attn_d64(const AttnArgs& a, hipStream_t s, int variant);
+int attn_variant();
+
 int op_flash_attn(const AttnArgs& a, hipStream_t s) {
     CTRL_CHECK(a.B > 0 && a.heads > 0 && a.Lq > 0 && a.Lk > 0, "flash_attn: empty problem");
     CTRL_CHECK(a.kvB == 1 || a.kvB == a.B, "flash_attn: kvB must be 1 or B");
@@ -456,6 +461,7 @@ int op_flash_attn(const AttnArgs& a, hipStream_t s) {
                "flash_attn: pointers must be 16-byte aligned");
     switch (a.D) {
         case 64:
+            if (attn_variant() > 0 && flash_attn_d64_applies(a)) return op_flash_attn_d64(a, s, attn_variant());
             // long sequences: 256 queries per workgroup halve the K/V LDS-DMA traffic per FLOP (the limiter at L = 16384)
             if (a.Lq >= 2048 && !getenv("CTRL_ATTN_NW4")) return launch_attn<64, 8, false>(a, s);
             return launch_attn<64, 4, true>(a, s);

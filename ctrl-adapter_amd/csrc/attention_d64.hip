@@ -1,0 +1,325 @@
+// Flash attention, head_dim 64, long sequences (the adapter's spatial self-attention at 128x128 / 64x64 latents:
+// model/adapter_spatial_temporal.py:108-116 called :271 -> diffusers Attention / F.scaled_dot_product_attention;
+// 16384 / 4096 tokens, heads = C/64).  Same algorithm and data flow as flash_attn_kernel<64, 8, false, true> in
+// attention.hip (swapped QK^T so a lane owns one query, P fed to P.V straight from registers, K pre-scaled by
+// softmax_scale*log2(e), running maximum folded into the QK^T accumulator, 3-deep LDS-DMA ring of 64-key K / V^T tiles) --
+// rebuilt around what the round-2 counters showed: that loop issues ~170 VALU instructions against 16 MFMAs per 64-key
+// tile and wave (VALU pipe ~1.6x the matrix pipe), 47 of them integer address arithmetic for the 16 fragment reads.
+//   * the ring is unrolled by its depth, so the slot of a tile is a compile-time constant that lands in the
+//     ds_read_b128 offset field; the XOR swizzle of a fragment address is `base ^ (k-step << 5)` of ONE per-lane base
+//     (rows r and r + 32 share their swizzle and differ by an immediate): 8 loop-invariant address registers, no
+//     integer VALU in the loop;
+//   * the -m accumulator initialisation is a 16-register tuple handed to the first MFMA of a block as its C operand,
+//     rewritten only when the running maximum moves (no v_mov per tile);
+//   * the row-max exchange between the two half-waves is v_permlane32_swap (VALU) instead of ds_bpermute (an LDS
+//     round trip that also waits for the fragment reads in flight);
+//   * row sums of P are taken from the packed fp16 probabilities with v_dot2c_f32_f16 (16 instead of 32 adds; the
+//     denominator then sums exactly the values the numerator multiplies);
+//   * QB = 2: a wave owns two 32-query blocks, every K / V^T fragment read feeds two MFMAs (half the LDS read traffic
+//     per FLOP -- at one block per wave the LDS pipe is as busy as the matrix pipe) and the two blocks' independent
+//     softmax / MFMA chains give the scheduler work to overlap inside one wave.
+// Requirements (checked by the dispatcher): D == 64, K pre-scaled, Lk % 64 == 0, kvB == B.
+#include "ops.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+enum { AO_NEGM = 1, AO_DOT2 = 2, AO_PRIO = 4, AO_DEFER = 8, AO_MINI = 16 };
+
+template <int QB, int NW, int OPT>
+__global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_kernel(AttnArgs a, const half_t* zeros) {
+    constexpr int NSTAGE = 3;
+    constexpr int TILEB = 64 * 64 * 2;                 // bytes of one K (or V^T) tile
+    constexpr int VOFF = NSTAGE * TILEB;               // V^T ring behind the K ring
+    constexpr int PASSES = 512 / (NW * 64);            // 16-byte chunks of a tile per lane
+    constexpr int LPT = 2 * PASSES;
+    constexpr int QPW = 32 * QB;                       // queries per wave
+    static_assert(PASSES >= 1, "workgroup too large for the tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, lq = lane & 31;
+    // XCD-aware work map, see flash_attn_kernel: every XCD owns whole (batch, head) pairs
+    const int qtiles = (a.Lq + NW * QPW - 1) / (NW * QPW);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pair = (j / qtiles) * 8 + xcd;
+    if (pair >= a.B * a.heads) return;
+    const int b = pair / a.heads, h = pair - b * a.heads;
+    const int q0 = (j % qtiles) * (NW * QPW) + wave * QPW;
+    const int Lq = a.Lq, Lk = a.Lk;
+
+    // ---- Q fragments (B operand: column = query, k = hi*8 + j) ----
+    h8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int q = q0 + qb * 32 + lq;
+        if (q > Lq - 1) q = Lq - 1;
+        const half_t* qp = (const half_t*)a.Q + ((size_t)b * Lq + q) * a.ldq + (size_t)h * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const h8*)(qp + ks * 16 + hi * 8);
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));      // retire the loads before the loop (see attention.hip)
+
+    const half_t* Kbase = (const half_t*)a.K + (size_t)b * Lk * a.ldk + (size_t)h * 64;
+    const half_t* Vbase = (const half_t*)a.Vt + ((size_t)b * a.heads + h) * 64 * (size_t)a.Lkpad;
+
+    // ---- staging: chunk ci of a tile -> K row ci/8, 16-byte piece (ci%8) ^ swizzle; V^T row ci/8 likewise ----
+    unsigned k_off[PASSES], v_off[PASSES];      // bytes from the (batch, head) base: < 4 GiB by the size of the operands
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int ci = (i * NW + wave) * 64 + lane;
+        const int r = ci >> 3, p = ci & 7;
+        const int src = p ^ ((r >> 1) & 7);
+        k_off[i] = (unsigned)(((size_t)r * a.ldk + src * 8) * sizeof(half_t));
+        v_off[i] = (unsigned)(((size_t)r * a.Lkpad + src * 8) * sizeof(half_t));
+    }
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+    auto stage = [&](int t, int slot) {
+        const int kt0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)(Kbase + (size_t)kt0 * a.ldk) + k_off[i]),
+                                             (lptr_t)(smem_raw + slot * TILEB + (i * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)(Vbase + kt0) + v_off[i]),
+                                             (lptr_t)(smem_raw + VOFF + slot * TILEB + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+    (void)zeros;
+
+    // ---- fragment read addresses (bytes inside a tile), loop invariant ----
+    // K row of lane: krow (bits 2 <-> 3 of lq swapped, so that the lane's scores are its own P^T B-operand); rows krow
+    // and krow + 32 (the two 32-key blocks) share the swizzle (r >> 1) & 7 and differ by 4096 bytes.
+    const int krow = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
+    const int kA = krow * 128 + ((hi ^ ((krow >> 1) & 7)) << 4);
+    const int vA = lq * 128 + ((hi ^ ((lq >> 1) & 7)) << 4);
+
+    f16v o[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
+    float m_run[QB], l_run[QB];
+    f16v negm[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = 0.f; l_run[qb] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
+    }
+
+    const int ntiles = Lk >> 6;
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t)
+        if (t < ntiles) stage(t, t);
+
+    if constexpr (OPT & AO_PRIO) {
+        // the second-dispatched half of the workgroup loses every VALU arbitration at equal priority (MI355X_MICROARCH.md)
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+    }
+
+    auto tile = [&](auto slot_c, const int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        if (t + NSTAGE - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // tile t visible to every wave; the slot of tile t-1 is free
+        if (t + NSTAGE - 1 < ntiles) stage(t + NSTAGE - 1, (SLOT + NSTAGE - 1) % NSTAGE);
+        const char* Kb = smem_raw + SLOT * TILEB;
+        const char* Vb = smem_raw + VOFF + SLOT * TILEB;
+
+        // One softmax step covers KB 32-key blocks: 2 = the whole tile (scores of 64 keys live at once), 1 (AO_MINI) = a
+        // block at a time -- 16 fewer live score registers, which is what lets the -m tuple stay resident at 128
+        // registers per wave (2 workgroups of 8 waves per CU); the price is a second max exchange per tile.
+        constexpr int KB = (OPT & AO_MINI) ? 1 : 2;
+#pragma unroll
+        for (int m0 = 0; m0 < 2; m0 += KB) {
+            // ---- S^T = K . Q^T - m ----
+            f16v sacc[QB][KB];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < KB; ++mi) {
+                    const h8 kf = *(const h8*)(Kb + (kA ^ (ks << 5)) + (m0 + mi) * 4096);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        if (ks == 0) {
+                            if constexpr (OPT & AO_NEGM) {
+                                sacc[qb][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][0], negm[qb], 0, 0, 0);
+                            } else {
+                                f16v c0;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) c0[r] = -m_run[qb];
+                                sacc[qb][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][0], c0, 0, 0, 0);
+                            }
+                        } else {
+                            sacc[qb][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], sacc[qb][mi], 0, 0, 0);
+                        }
+                    }
+                }
+            // register r of block mb holds key  kt0 + 32*mb + 16*(r>>3) + 8*hi + (r&7)
+            // ---- online softmax (exp2 domain; sacc = s - m_run already) ----
+            h8 pf[QB][KB][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = sacc[qb][0][0];
+#pragma unroll
+                for (int mi = 0; mi < KB; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][mi][r]);
+                {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                }
+                // mx > 0 <=> the row maximum moved (first step: m_run = 0 stands for "none yet" and the update is forced).
+                // AO_DEFER: the reference point is only moved when a score exceeds it by more than 2^4 -- p <= 16 is as exact
+                // in fp16 / fp32 as p <= 1, and a slowly creeping maximum no longer costs a rescale per tile
+                constexpr float THR = (OPT & AO_DEFER) ? 4.f : 0.f;
+                const bool first = (t == 0 && m0 == 0);
+                if (first || __any(mx > THR)) {        // wave-uniform
+                    const float d = first ? mx : fmaxf(mx, 0.f);
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-d);
+                    l_run[qb] *= alpha;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+                    m_run[qb] += d;
+#pragma unroll
+                    for (int mi = 0; mi < KB; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[qb][mi][r] -= d;
+                    if constexpr (OPT & AO_NEGM) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) negm[qb][r] = -m_run[qb];
+                    }
+                }
+                // probabilities are packed to fp16 pairs ONCE; the row sum (v_dot2c) and the P^T operand read the same registers
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                float psum = 0.f;
+#pragma unroll
+                for (int mi = 0; mi < KB; ++mi)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u4v w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = s2 * 8 + i * 2;
+                            const float p0 = __builtin_amdgcn_exp2f(sacc[qb][mi][r]), p1 = __builtin_amdgcn_exp2f(sacc[qb][mi][r + 1]);
+                            const h2 pk = {(half_t)p0, (half_t)p1};
+                            w[i] = __builtin_bit_cast(unsigned, pk);
+                            if constexpr (OPT & AO_DOT2) {
+                                const h2 one = {(half_t)1.f, (half_t)1.f};
+                                psum = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w[i]), one, psum, false);
+                            } else {
+                                psum += p0 + p1;
+                            }
+                        }
+                        pf[qb][mi][s2] = __builtin_bit_cast(h8, w);
+                    }
+                l_run[qb] += psum;
+            }
+
+            // ---- O^T += V^T . P^T ----
+#pragma unroll
+            for (int mi = 0; mi < KB; ++mi)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const h8 vf = *(const h8*)(Vb + (vA ^ (((m0 + mi) * 2 + s2) << 5)) + db * 4096);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+                            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][mi][s2], o[qb][db], 0, 0, 0);
+                    }
+        }
+    };
+
+    int t = 0;
+    for (; t + 3 <= ntiles; t += 3) {
+        tile(std::integral_constant<int, 0>{}, t);
+        tile(std::integral_constant<int, 1>{}, t + 1);
+        tile(std::integral_constant<int, 2>{}, t + 2);
+    }
+    if (t < ntiles) { tile(std::integral_constant<int, 0>{}, t); ++t; }
+    if (t < ntiles) { tile(std::integral_constant<int, 1>{}, t); ++t; }
+
+    // ---- finalize: O[q][d] = O^T[d][q] / l ----
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + qb * 32 + lq;
+        if (q < Lq) {
+            half_t* op = (half_t*)a.O + ((size_t)b * Lq + q) * a.ldo + (size_t)h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // rows (r&3) + 8*(r>>2) + 4*hi of the 32x32 C/D fragment: r = 4g..4g+3 -> 4 consecutive d
+                    const int d0 = db * 32 + 8 * g + 4 * hi;
+                    h4 v = {(half_t)(o[qb][db][4 * g] * inv), (half_t)(o[qb][db][4 * g + 1] * inv),
+                            (half_t)(o[qb][db][4 * g + 2] * inv), (half_t)(o[qb][db][4 * g + 3] * inv)};
+                    *(h4*)(op + d0) = v;
+                }
+        }
+    }
+}
+
+template <int QB, int NW, int OPT>
+int launch_d64(const AttnArgs& a, hipStream_t s) {
+    constexpr size_t smem = (size_t)3 * 2 * 64 * 64 * sizeof(half_t);
+    static bool attr_done[kMaxDevices] = {};
+    const int dev = cur_device();
+    if (!attr_done[dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_d64_kernel<QB, NW, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done[dev] = true;
+    }
+    const half_t* zeros = (const half_t*)device_zero_page();
+    const int qtiles = (a.Lq + NW * 32 * QB - 1) / (NW * 32 * QB), pairs = a.B * a.heads;
+    dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
+    PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
+    prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
+    prof_symbol("flash_attn_d64_kernel<%d, %d, %d>", QB, NW, OPT);
+    LAUNCH("flash_attn", (flash_attn_d64_kernel<QB, NW, OPT>), grid, dim3(NW * 64), smem, s, a, zeros);
+    return 0;
+}
+
+int g_variant = -1;
+
+}  // namespace
+
+bool flash_attn_d64_applies(const AttnArgs& a) {
+    return a.D == 64 && a.k_prescaled && a.Lk % 64 == 0 && a.Lk >= 128 && a.kvB == a.B && a.Lq >= 2048;
+}
+
+// variant: performance only (every variant computes the same function; they differ in instruction selection and in
+// how many queries a wave owns).  0 = the round-2 kernel in attention.hip; default = CTRL_ATTN_VARIANT or the best measured.
+int attn_set_variant(int v) { g_variant = v; return 0; }
+int attn_variant() {
+    if (g_variant < 0) { const char* e = getenv("CTRL_ATTN_VARIANT"); g_variant = e ? atoi(e) : 1; }
+    return g_variant;
+}
+
+int op_flash_attn_d64(const AttnArgs& a, hipStream_t s, int variant) {
+    switch (variant) {
+        case 1: return launch_d64<1, 8, 0>(a, s);
+        case 2: return launch_d64<1, 8, AO_DOT2>(a, s);
+        case 3: return launch_d64<1, 8, AO_MINI | AO_DOT2>(a, s);
+        case 4: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DOT2>(a, s);
+        case 5: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DOT2 | AO_PRIO>(a, s);
+        case 6: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DOT2 | AO_DEFER>(a, s);
+        case 7: return launch_d64<2, 4, AO_DOT2>(a, s);
+        case 8: return launch_d64<2, 4, AO_NEGM | AO_DOT2>(a, s);
+        case 9: return launch_d64<2, 4, AO_MINI | AO_NEGM | AO_DOT2>(a, s);
+        case 10: return launch_d64<2, 8, AO_MINI | AO_NEGM | AO_DOT2>(a, s);
+        default: CTRL_FAIL("flash_attn: unknown variant " + std::to_string(variant));
+    }
+}

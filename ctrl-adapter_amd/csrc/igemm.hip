@@ -39,21 +39,13 @@ __device__ __forceinline__ int chunk_swz(int row) {
 
 // 128x256 / 256x128 tiles of 8 waves keep two workgroups resident per CU (72 KiB of LDS ring, <= 128 VGPRs per wave): one
 // workgroup's epilogue (HBM-bound fp32 stream traffic, GEGLU math) overlaps the other one's k-loop
-template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (NW == 8 && (BM * BN == 128 * 256 || BM * BN == 128 * 320)) ? 4 : 1; };
+template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (NW == 8 && BM * BN == 128 * 256) ? 4 : 1; };
 
-template <bool P>
-__device__ __forceinline__ const IGemmArgs& epi_desc(const IGemmArgs& a, const IGemmArgs* lds) {
-    if constexpr (P) return *lds;
-    else return a;
-}
-
-// PERSIST: one workgroup per CU walks a list of output tiles (workgroup b: tiles b, b + gridDim.x, ... of the walk order)
-// with ONE LDS ring running across them: the first k-tiles of the next output tile are already streaming into LDS while
-// the last MFMAs and the epilogue of the current one run, so only the very first tile pays the cold fill of the ring
-// (measured: 0.20 of the 0.33 ms fixed cost of an M = 131072 launch is that fill, profiles/r02_gemm_k_sweep.txt).  The
-// epilogue's staging area then lives beside the ring instead of on top of it.  No split-K in this form.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP, bool PERSIST = false>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk, int order) {
+// (A persistent-workgroup form -- one workgroup per CU walking its tiles with one LDS ring running across them -- was built
+// in round 2 and measured again at the start of round 3 after the epilogue fetch hoisting: 0.72-1.03x the one-tile form on
+// every shape of the path, profiles/r03_gemm_persistent_form.txt.  It is gone from the product.)
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk, int order) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // per-wave tile
@@ -76,7 +68,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
     // split-K: blockIdx.x = split * nblk + tile; every split accumulates a contiguous range of k-tiles and writes its
     // fp32 partial tile to slab `split` of the scratch buffer (reduced + finished by splitk_finish_kernel)
     const int nblk = ntm * ntn;
-    const int split = PERSIST ? 0 : blockIdx.x / nblk;
+    const int split = blockIdx.x / nblk;
     const int first_bid = blockIdx.x - split * nblk;
     int m0, n0;                          // origin of the output tile being ACCUMULATED (the epilogue's tile)
     {
@@ -98,7 +90,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
     int b_c8[BPASS];
     const int VH = a.Hin * a.up, VW = a.Win * a.up;   // virtual (up-sampled) input grid
     const int ushift = (a.up == 2) ? 1 : 0;
-    // coordinates of the output tile whose operands are being STAGED (PERSIST: runs ahead of the accumulated tile)
     auto set_stage_tile = [&](const int sm0, const int sn0) {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
@@ -159,7 +150,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
     const int kt_begin = split * nk_per_;
 
     // asynchronous global -> LDS staging of k-tile kt into buffer buf (no VGPR round trip)
-    // (kt = k-tile of the staged output tile, f = running tile count that picks the ring slot: f == kt unless PERSIST)
+    // (kt = k-tile of the output tile, f = tile count that picks the ring slot: f == kt)
     auto stage = [&](int kt, int f) {
         int k0 = (kt_begin + kt) * BK;                 // K offset of the tile in W rows
         int tap = 0, c0 = k0;
@@ -221,11 +212,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
     constexpr int D = NSTAGE - 1;
     constexpr int LPT = APASS + BPASS;       // global_load_lds instructions per lane per tile
     static_assert((D - 1) * LPT <= 63, "vmcnt immediate overflow");
-    if constexpr (!PERSIST) {
 #pragma unroll
-        for (int t = 0; t < D; ++t)
-            if (t < nk) stage(t, t);
-    }
+    for (int t = 0; t < D; ++t)
+        if (t < nk) stage(t, t);
 
     // fragment read coordinates: row (lane&15) of a 16-row fragment, logical chunk (lane>>4) + 4*kk
     const int frow = lane & 15, fch = lane >> 4;
@@ -264,9 +253,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
     };
     // wait until this wave's LDS-DMA share of tile t has landed, leaving the D-1 younger tiles in flight.  Paired walk:
     // only the even tiles of the window t+1 .. t+D-1 carried a weight tile, so the count of younger loads alternates
-    int nk_flat = nk;                        // PERSIST: k-tiles of ALL output tiles of this workgroup
     auto wait_tile = [&](int t) {
-        if (t + D - 1 >= nk_flat) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        if (t + D - 1 >= nk) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
         if (!paired) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPT) : "memory"); return; }
         // evens among t+1 .. t+D-1 (local tile indices; the range of a workgroup starts at an even global tile)
         const int nb = ((t + D - 1) >> 1) - (t >> 1);
@@ -278,47 +266,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
     auto slot_of = [&](int t) { return t % NSTAGE; };
     auto bslot_of = [&](int t) { return paired ? (t >> 1) % NSTAGE : t % NSTAGE; };
 
-    constexpr size_t RING_BYTES = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
-    char* const epi_smem = smem_raw + (PERSIST ? RING_BYTES : 0);     // PERSIST: the ring stays live under the epilogue
-    constexpr size_t EPI_STAGE_BYTES = (size_t)NW * 16 * (WN + 4) * sizeof(float);
-    const IGemmArgs* lds_desc = (const IGemmArgs*)(epi_smem + EPI_STAGE_BYTES);
-    if constexpr (PERSIST) {           // descriptor -> LDS (read back by the epilogues), straight from the kernarg segment
-        typedef const unsigned __attribute__((address_space(4)))* kptr_t;
-        const kptr_t kargs = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-        if (tid < (int)(sizeof(IGemmArgs) / 4)) ((unsigned*)lds_desc)[tid] = kargs[tid];
-        __syncthreads();
-    }
-    // PERSIST: flat walk over (output tile, k-tile).  f counts k-tiles across this workgroup's output tiles, the ring slot is
-    // f % NSTAGE, and the staging cursor runs D k-tiles ahead of the MFMAs, crossing into the next output tile on its own.
-    const int gstep = (int)gridDim.x;
-    const int ntile = PERSIST ? (nblk - first_bid + gstep - 1) / gstep : 1;     // >= 1: the grid never exceeds nblk
-    const int nf = ntile * nk;
-    int s_k = 0, s_f = 0, s_bid = first_bid;                                    // staging cursor
-    auto stage_next = [&]() {
-        stage(s_k, s_f);
-        ++s_f;
-        if (++s_k == nk) {
-            s_k = 0;
-            s_bid += gstep;
-            if (s_bid < nblk) {
-                int tile_m, tile_n;
-                tileorder::tile_of(s_bid, ntm, ntn, order, &tile_m, &tile_n);
-                set_stage_tile(tile_m * BM, tile_n * BN);
-            }
-        }
-    };
+    char* const epi_smem = smem_raw;          // the k-loop ring is dead when the epilogue runs
     const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;                  // the two staggered wave groups (8-wave tiles)
-    if constexpr (PERSIST) {
-        static_assert(!PERSIST || (NW == 8 && (BM / WAVES_M) * (BN / WAVES_N) >= 128 * 64 && SWAP), "persistent form: staggered 8-wave tiles, vector epilogue");
-        nk_flat = nf;
-#pragma unroll
-        for (int t = 0; t < D; ++t)
-            if (t < nf) stage_next();
-        if (grp == 1) {
-            wait_tile(0);
-            __builtin_amdgcn_s_barrier();                                       // interval 0 (group 0 loads tile 0)
-        }
-    } else {
+    {
         if constexpr (NW == 8 && (BM / WAVES_M) * (BN / WAVES_N) >= 128 * 64) {
             // (only for 128x64 per-wave tiles: with 64x64 wave tiles the LOAD phase outlasts the MFMAs and staggering loses)
             // Two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD) run half a tile apart: in every barrier
@@ -374,33 +324,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
 
     }
 
-    // One epilogue site for every form.  PERSIST runs the two-group schedule of the one-tile form above as a flat loop:
-    //   group 0:  [wait f] B(2f)   *   stage, LOAD(f)                 B(2f+1)  COMPUTE(f)
-    //   group 1:                   *   B(2f+1)  stage, LOAD(f) [wait f+1]  B(2f+2)  COMPUTE(f)
-    // and * is where a finished output tile leaves: group 0 right AFTER the barrier that lets group 1 start its last
-    // COMPUTE of that tile (epilogue under the other group's MFMAs), group 1 right after that COMPUTE, while group 0 is
-    // already loading the next tile's fragments -- the two epilogues never wait for each other.
-    bool pending = !PERSIST;                 // accumulators hold a finished output tile
-    int c_k = 0, c_ti = 0;
-    for (int f = 0;; ++f) {
-        if constexpr (PERSIST) {
-            if (grp == 0) {
-                if (f < nf) wait_tile(f);
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-        if (pending) {
+    {
+        {
         // ---------------- epilogue of the accumulated tile (m0, n0) ----------------
-            // (PERSIST reads the descriptor from its LDS copy: ~60 epilogue-only scalars would otherwise stay live -- and
-            // spilled -- across the k-loop)
-            const IGemmArgs& e = epi_desc<PERSIST>(a, lds_desc);
+            const IGemmArgs& e = a;
             if constexpr (SWAP) {
                 // Operands were swapped (D = W.A^T): a lane owns ONE output row (lane&15) and FOUR consecutive columns
                 // (lane>>4)*4+i of each 16x16 fragment.  Bias / time vector / GEGLU / SiLU are applied in registers; the
                 // 16-row slab of the wave tile then goes through a wave-private LDS staging area (the k-loop ring is dead) and
                 // leaves as whole 16-byte pieces of full output rows: residual reads and result writes are coalesced 128-byte+
                 // row segments instead of 8-byte fragments scattered over 16 rows.
-                if constexpr (!PERSIST) __syncthreads();           // every wave is done with the ring
+                __syncthreads();           // every wave is done with the ring
                 if (e.seg[0].fmt == SEG_TRANSPOSED) {
                     // One transposed segment (NCHW result / V^T operand): out[(img*ncols + c)*ld + tok].  Everything that is
                     // indexed by (row, column) -- bias, time vector, SiLU, residual, scale -- is applied in the fragment layout;
@@ -494,7 +428,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
                     // ... fetched ahead: the wide one-workgroup-per-CU tiles only (256 registers per wave; the two-workgroup
                     // tiles live in 128 and overlap their epilogue with the other workgroup's k-loop instead); the 80-wide wave
                     // tile (three pieces per lane, 160 accumulator registers) has room for one
-                    constexpr bool RES_AHEAD = (WM * WN >= 128 * 64) && (MinWaves<BM, BN, NW>::v == 1 || PERSIST);
+                    constexpr bool RES_AHEAD = (WM * WN >= 128 * 64) && MinWaves<BM, BN, NW>::v == 1;
                     constexpr int RTP = !RES_AHEAD ? 0 : (RT > 2 ? 1 : RT);
                     f4 rf0[RTP ? RTP : 1], rf1[RTP ? RTP : 1];
 #pragma unroll
@@ -709,38 +643,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (PERSIST ? 1 : MinWaves<BM,
                 }
             }
 
-            if constexpr (PERSIST) {                   // next output tile of this workgroup
-                pending = false;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
-                const int c_bid = first_bid + (++c_ti) * gstep;
-                if (c_bid < nblk) {
-                    int tile_m, tile_n;
-                    tileorder::tile_of(c_bid, ntm, ntn, order, &tile_m, &tile_n);
-                    m0 = tile_m * BM;
-                    n0 = tile_n * BN;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if constexpr (!PERSIST) {
-            break;
-        } else {
-            if (f == nf) break;
-            if (grp == 1) __builtin_amdgcn_s_barrier();
-            if (s_f < nf) stage_next();
-            load_frags(slot_of(f), bslot_of(f));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (grp == 1 && f + 1 < nf) wait_tile(f + 1);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_setprio(1);
-            compute();
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (++c_k == nk) { c_k = 0; pending = true; }
         }
     }
 }
@@ -885,7 +787,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
-    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s, false>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
+    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
     if (splitk > 1) {
         // partial sums go to fp32 slabs [splitk][M][Nout]; every epilogue term is applied once, by the finish kernel
         IGemmArgs p = a;
@@ -907,45 +809,6 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     }
     sym();
     LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
-           a, ntm, ntn, zeros, 1, order);
-    return 0;
-}
-
-// Persistent form (igemm_persist_kernel): one workgroup per CU, ring + epilogue staging side by side in LDS.
-int g_persist = -1;                 // -1 = read CTRL_IGEMM_PERSIST on first use
-bool persist_enabled() {
-    if (g_persist < 0) { const char* e = getenv("CTRL_IGEMM_PERSIST"); g_persist = (e && atoi(e) > 0) ? atoi(e) : 0; }
-    return g_persist > 0;
-}
-
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE>
-int launch_persist(const IGemmArgs& a, hipStream_t s) {
-    constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
-    constexpr int BNP = (BN + PASSROWS - 1) / PASSROWS * PASSROWS;
-    constexpr size_t ring = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
-    constexpr size_t stage_bytes = (size_t)WAVES_M * WAVES_N * 16 * (BN / WAVES_N + 4) * sizeof(float);     // row-major outputs only
-    constexpr size_t smem = ring + stage_bytes + ((sizeof(IGemmArgs) + 15) & ~(size_t)15);       // + the descriptor copy the epilogues read
-    static_assert(smem <= 160 * 1024, "persistent tile does not fit the 160 KiB LDS");
-    static bool attr_done[kMaxDevices] = {};
-    static int cus[kMaxDevices] = {};
-    const int dev = cur_device();
-    if (!attr_done[dev]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, true, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
-        attr_done[dev] = true;
-    }
-    const half_t* zeros = zero_page();
-    CTRL_CHECK(zeros != nullptr, "igemm: could not allocate the zero page");
-    const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
-    const int order = plan_order(a, BM, BN, ntm, ntn);
-    const int nblk = ntm * ntn, grid = nblk < cus[dev] ? nblk : cus[dev];
-    const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
-    PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
-    prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
-    const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
-    prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, true, true>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE);
-    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, true, true>), dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s,
            a, ntm, ntn, zeros, 1, order);
     return 0;
 }
@@ -973,7 +836,6 @@ bool can_swap(const IGemmArgs& a) {
 }
 
 }  // namespace
-int igemm_set_persist(int on) { g_persist = on > 0 ? on : 0; return 0; }
 
 // number of K splits op_igemm will use for this problem (1 = none); callers size splitk_ws = factor*M*Nout*4 bytes
 
@@ -1025,13 +887,10 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
             return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
         }
     }
-    if (MODE == IG_ROWS && persist_enabled() && can_swap(a) && a.seg[0].fmt == SEG_ROW && a.a_split != 2 && tiles(256, 256) >= 256 && eff(256) > 0.9)
-        return launch_persist<256, 256, 32, 2, 4, 3, MODE>(a, s);       // opt-in (CTRL_IGEMM_PERSIST / ctrl_igemm_set_persist)
     if (const char* f = getenv("CTRL_IGEMM_FORCE")) {      // tile experiments (tools/tile_experiment.py), row outputs only
         if (can_swap(a) && MODE == IG_ROWS) {
             if (!strcmp(f, "128x256")) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
             if (!strcmp(f, "256x128")) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
-            if (!strcmp(f, "128x320") && a.Nout % 320 == 0 && !a.geglu) return launch_cfg2<128, 320, 32, 2, 4, 2, MODE, true>(a, s);
         }
     }
     // Epilogue-heavy token GEMMs at large M (measured, tools/tile_experiment.py -> profiles/r02_tile_experiment.log): two

@@ -19,7 +19,6 @@ int op_igemm(const IGemmArgs& a, hipStream_t s);
 int igemm_splitk_factor(const IGemmArgs& a);
 // tile walk order of the implicit GEMM (tile_order.h): "legacy" | "auto" | "m,G" | "n,G"; 0 = accepted
 int igemm_set_order(const char* spec);
-int igemm_set_persist(int on);      // persistent workgroups for the wide tiles (0 off, 1 on); also CTRL_IGEMM_PERSIST
 void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
 // convenience: plain linear out[M][N] (fp16 row-major) = A[M][K] * W[N][K]^T + bias
 int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, half_t* out, long ldo,
@@ -32,6 +31,8 @@ int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, hal
 // ------------------------------------------------------------------------------------------
 typedef ctrl_attn_desc AttnArgs;
 int op_flash_attn(const AttnArgs& a, hipStream_t s);
+// instruction-selection variant of the head_dim-64 long-sequence kernel (attention_d64.hip); performance only
+int attn_set_variant(int v);
 
 // temporal attention over the frame axis: tokens X [(b*F+f)*HW + p][...]; seq = F (<= 32)
 typedef ctrl_tattn_desc TAttnArgs;

@@ -63,6 +63,10 @@ def controlled_step(controlnet, adapter, sample, timestep, encoder_hidden_states
     frame_pos, n_out = (tail[0], tail[1]) if tail is not None else (None, N)
     import torch
     with torch.cuda.device(sample.device):
+        # the plans' text K/V cache modes are sticky: set them for THIS call from the tensors of THIS call (a separate
+        # controlnet(...) / adapter(...) call of an earlier request may have left REUSE behind -- ADVICE r2)
+        controlnet._text_cache_mode(encoder_hidden_states, L.lib().ctrl_controlnet_text_cache)
+        adapter._text_cache_mode(adapter_encoder_hidden_states, L.lib().ctrl_adapter_text_cache)
         L.check(L.lib().ctrl_step_forward(
             controlnet._ensure_plan(), adapter._ensure_plan(), *cn_args,
             ad_args[3], *ad_args[4:10], int(use_m and mid_out is not None), ad_args[10], ad_args[11], frame_pos, n_out, L.cur_stream()))

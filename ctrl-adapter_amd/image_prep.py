@@ -74,6 +74,12 @@ def _as_u8_hwc(img):
             raise ValueError("tensor images must be uint8 [H, W, 3] (RGB)")
         return a
     if hasattr(img, "convert"):                 # PIL image: do_convert_rgb
+        # bit-exactness with the reference recipe is established for RGB sources; diffusers' VaeImageProcessor resizes
+        # BEFORE convert("RGB"), so palette ("P": nearest-neighbour resize) and alpha ("RGBA"/"LA": premultiplied
+        # resampling) images would come out differently there -- refuse them instead of returning other pixels
+        if getattr(img, "mode", "RGB") not in ("RGB", "L"):
+            raise ValueError("prepare_images: PIL mode %r is not supported (convert to RGB first; only RGB / L sources "
+                             "resample identically to the reference)" % (img.mode,))
         img = np.asarray(img.convert("RGB"))
     a = np.asarray(img)
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
@@ -88,6 +94,10 @@ def prepare_images(images, width, height, batch_size, num_images_per_prompt, dev
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("prepare_images (libctrlhip) runs on the GPU only; there is no CPU fallback")
+    if width % 8 or height % 8:
+        # diffusers' get_default_height_width rounds both down to a multiple of the VAE scale factor (8); every size the
+        # reference uses (512, 1024) already is one -- anything else would silently differ from it
+        raise ValueError("prepare_images: width and height must be multiples of 8 (got %dx%d)" % (width, height))
     frames = [_as_u8_hwc(i) for i in images]
     if not frames or any(f.shape != frames[0].shape for f in frames):
         raise ValueError("prepare_images needs at least one image and all images of one size")

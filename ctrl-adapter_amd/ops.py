@@ -98,9 +98,10 @@ def set_igemm_order(spec):
         raise ValueError("unknown tile walk order %r" % (spec,))
 
 
-def set_igemm_persist(on):
-    """persistent-workgroup form of the wide row-GEMM tiles (opt-in; bit-identical results)"""
-    L.lib().ctrl_igemm_set_persist(int(bool(on)))
+def set_attn_variant(v):
+    """instruction-selection variant of the head_dim-64 long-sequence attention kernel (0 = the round-2 kernel); every
+    variant computes the same function (csrc/attention_d64.hip)"""
+    check(L.lib().ctrl_attn_set_variant(int(v)))
 
 
 def linear(x, w_packed, bias=None, res=None, geglu=False):

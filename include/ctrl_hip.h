@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTRL_ABI_VERSION 3
+#define CTRL_ABI_VERSION 4
 
 /* element types of boundary tensors */
 enum { CTRL_F32 = 0, CTRL_F16 = 1, CTRL_BF16 = 2 };
@@ -105,9 +105,6 @@ int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
    ctrl_igemm_tile_of: the (tile_m, tile_n) workgroup `bid` of an ntm x ntn grid computes under (mode 0|1|2, group) --
    a diagnostic the host tests use to prove every order is a bijection. */
 int ctrl_igemm_set_order(const char* spec);
-/* persistent-workgroup form of the wide GEMM tiles (one workgroup per CU walks its tiles with one LDS ring running across
-   them); performance only, bit-identical results.  0 = off, 1 = on; default from CTRL_IGEMM_PERSIST */
-int ctrl_igemm_set_persist(int on);
 int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
 
 typedef struct ctrl_attn_desc {
@@ -123,6 +120,10 @@ typedef struct ctrl_attn_desc {
     int32_t pad0_;
 } ctrl_attn_desc;
 int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream);
+/* Instruction-selection variant of the head_dim-64 long-sequence kernel (csrc/attention_d64.hip): 0 = the round-2 kernel,
+   > 0 = the round-3 family (what each number selects is listed in that file); performance only, every variant computes the
+   same function.  -1 = back to the default (CTRL_ATTN_VARIANT or the best measured).  Used by tools/attn_bench.cpp. */
+int ctrl_attn_set_variant(int v);
 
 typedef struct ctrl_tattn_desc {
     const void* Q; int64_t ld;       /* [(b*Fq+f)*HW + p][ld], head h at column h*64; unsharded: rows are q | k | v, 3*C wide */

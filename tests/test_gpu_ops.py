@@ -222,6 +222,30 @@ def test_flash_attn(ops, gpu, D, heads, Lq, Lk):
     report("flash_attn folded D%d h%d Lq%d Lk%d" % (D, heads, Lq, Lk), rel_inf(out2.reshape(B, Lq, Cc), ref))
 
 
+def test_flash_attn_d64_variants(ops, gpu):
+    """csrc/attention_d64.hip: every instruction-selection variant of the head_dim-64 long-sequence kernel (and variant 0, the
+    round-2 kernel) computes softmax(QK^T/sqrt(d))V -- a spiked key mid-sequence forces the rescale path, a spike in the very
+    first tile the forced first update, Lq not a multiple of the workgroup's queries the clamped tail"""
+    B, heads, D, L = 2, 3, 64, 2240          # 35 key tiles (not a multiple of the ring depth), 2240 = 8.75 x 256 queries
+    Cc = heads * D
+    q, k, v = rnd(B, L, Cc, seed=1), rnd(B, L, Cc, seed=2), rnd(B, L, Cc, seed=3)
+    k[0, L - 70] = q[0, 5] * 4.0
+    k[1, 3] = q[1, 100] * 6.0
+    ref = _attn_ref(q, k, v, heads)
+    vt = v.half().permute(0, 2, 1).contiguous()
+    ks = (k * (1.4426950408889634 / math.sqrt(D))).half()
+    try:
+        for variant in range(0, 11):
+            ops.set_attn_variant(variant)
+            out = ops.flash_attn(q.half().reshape(B * L, Cc).to(gpu), Cc, ks.reshape(B * L, Cc).to(gpu), Cc, vt.to(gpu), L,
+                                 B, heads, D, L, L, k_prescaled=True)
+            report("flash_attn d64 variant %d" % variant, rel_inf(out.reshape(B, L, Cc), ref))
+        with pytest.raises((ValueError, RuntimeError)):
+            ops.set_attn_variant(99)
+    finally:
+        ops.set_attn_variant(-1)          # back to the default (CTRL_ATTN_VARIANT or the best measured)
+
+
 def test_temporal_attn(ops, gpu):
     for Fr in (16, 14, 24):
         Bc, HW, heads = 2, 12, 5
@@ -432,10 +456,9 @@ def test_two_workgroup_tiles_at_large_m(ops, gpu, K, geglu, f32):
         report("2-WG tile f32 stream K%d mirror" % K, rel_inf(mirror, ref))
 
 
-def test_tile_walk_orders_and_persistent_form_are_bit_identical(ops, gpu):
-    """csrc/tile_order.h only decides WHICH workgroup computes a tile, and the persistent-workgroup form only how many tiles
-    a workgroup walks: every order and both forms must give the same bits (GEGLU with bias; fp32 stream update with fp32
-    residual + fp16 mirror; a ragged M), and the fp32 result matches the fp32 reference"""
+def test_tile_walk_orders_are_bit_identical(ops, gpu):
+    """csrc/tile_order.h only decides WHICH workgroup computes a tile: every order must give the same bits (GEGLU with bias;
+    fp32 stream update with fp32 residual + fp16 mirror; a ragged M), and the fp32 result matches the fp32 reference"""
     try:
         for (M, N, K, geglu) in [(16384, 4096, 512, True), (16384 - 24, 2048, 320, False)]:
             x, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.05), rnd(N, seed=13)
@@ -451,19 +474,16 @@ def test_tile_walk_orders_and_persistent_form_are_bit_identical(ops, gpu):
                 ops.igemm(xg, K, wp, M, N, K, bias=bp, res=r, ldres=N, segs=[(out, N, 0, N, ops.SEG_ROW, 1)], out16=mirror, ld16=N)
                 return out, mirror
             ops.set_igemm_order("legacy")
-            ops.set_igemm_persist(False)
             base = run()
-            for spec, persist in [("auto", False), ("m,1", False), ("m,3", False), ("n,0", False), ("n,2", False), ("legacy", True), ("m,4", True)]:
+            for spec in ["auto", "m,1", "m,3", "n,0", "n,2", "m,4"]:
                 ops.set_igemm_order(spec)
-                ops.set_igemm_persist(persist)
                 got = run()
                 for g, want in zip(got, base):
-                    assert torch.equal(g, want), (M, N, K, spec, persist)
+                    assert torch.equal(g, want), (M, N, K, spec)
             if not geglu:
                 ref = x.half().float() @ w.half().float().t() + b + r.cpu()
-                report("tile walk / persistent form, fp32 stream", rel_inf(base[0], ref), 2e-5)
+                report("tile walk orders, fp32 stream", rel_inf(base[0], ref), 2e-5)
         with pytest.raises(ValueError):
             ops.set_igemm_order("sideways")
     finally:
         ops.set_igemm_order("auto")
-        ops.set_igemm_persist(False)

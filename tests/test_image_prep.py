@@ -52,3 +52,7 @@ def test_hip_prepare_images_is_bit_exact(gpu, h, w, oh, ow, dt):
     flat = P.prepare_images([torch.from_numpy(i) for i in imgs], ow, oh, 1, 1, gpu, dt)          # uint8 tensors in, no CFG
     assert torch.equal(flat.cpu(), O.prepare_images(imgs, ow, oh, 1, 1, dtype=dt))
     print("PARITY prepare_images %dx%d -> %dx%d %s: bit-exact" % (h, w, oh, ow, dt))
+    with pytest.raises(ValueError):                   # sizes diffusers would round down to a multiple of 8
+        P.prepare_images([torch.from_numpy(imgs[0])], 100, 96, 1, 1, gpu, dt)
+    with pytest.raises(ValueError):                   # palette / alpha sources resample differently in the reference's recipe
+        P.prepare_images([PIL.fromarray(imgs[0], "RGB").convert("RGBA")], ow, oh, 1, 1, gpu, dt)

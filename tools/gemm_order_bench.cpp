@@ -4,7 +4,7 @@
 //
 //   build:  hipcc -O2 -std=c++17 -Iinclude tools/gemm_order_bench.cpp -o tools/bin/gemm_order_bench \
 //                 -Lctrl-adapter_amd -lctrlhip -Wl,-rpath,'$ORIGIN/../../ctrl-adapter_amd'
-//   run:    tools/bin/gemm_order_bench [out.txt [ksweep|persist|stores|check]]        (on the GPU box, from the repo root)
+//   run:    tools/bin/gemm_order_bench [out.txt [ksweep|stores|check]]        (on the GPU box, from the repo root)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -119,86 +119,6 @@ static int ksweep() {
     return 0;
 }
 
-// Persistent-workgroup form against the one-tile-per-workgroup form: bit-identical results (checksums) and time.
-static int persist_cmp() {
-    hipStream_t st;
-    CK(hipStreamCreate(&st));
-    hipEvent_t e0, e1;
-    CK(hipEventCreate(&e0));
-    CK(hipEventCreate(&e1));
-    struct P { const char* name; int M, N, K; bool geglu, stream; };
-    const P ps[] = {
-        {"plain K256", 131072, 2048, 256, false, false},   {"plain K512", 131072, 2048, 512, false, false},
-        {"plain K1024", 131072, 2048, 1024, false, false}, {"plain K2048", 131072, 2048, 2048, false, false},
-        {"geglu 512->4096", 131072, 4096, 512, true, false}, {"geglu 512->4096 @64^2", 32768, 4096, 512, true, false},
-        {"stream 2048->512", 131072, 512, 2048, false, true}, {"stream 320->512", 131072, 512, 320, false, true},
-        {"qkv 512->960", 131072, 960, 512, false, false},    {"ragged M, 512->1024", 131072 - 100, 1024, 512, false, false},
-        {"few tiles 2048x5120x640 geglu", 2048 * 4, 5120, 640, true, false}, {"one tile row 256x2048x512", 256, 2048 * 8, 512, false, false},
-    };
-    for (const P& sh : ps) {
-        const int on = sh.geglu ? sh.N / 2 : sh.N;
-        void* A = dev_half((size_t)sh.M * sh.K, 1);
-        void* W = dev_half((size_t)sh.N * sh.K, 2);
-        std::vector<float> hb(sh.N);
-        for (int i = 0; i < sh.N; ++i) hb[i] = 0.001f * (i % 97);
-        float* bias = nullptr;
-        CK(hipMalloc((void**)&bias, sh.N * 4));
-        CK(hipMemcpy(bias, hb.data(), sh.N * 4, hipMemcpyHostToDevice));
-        const size_t out_bytes = (size_t)sh.M * on * (sh.stream ? 4 : 2);
-        void *out = nullptr, *res = nullptr, *mirror = nullptr;
-        CK(hipMalloc(&out, out_bytes));
-        if (sh.stream) {
-            res = dev_half((size_t)sh.M * on * 2, 3);            // any bit pattern of finite floats-ish: halves reinterpreted
-            CK(hipMemset(res, 0x3c, out_bytes));                   // 0x3c3c3c3c = 0.0115 as fp32
-            CK(hipMalloc(&mirror, (size_t)sh.M * on * 2));
-        }
-        ctrl_igemm_desc d;
-        memset(&d, 0, sizeof d);
-        d.A = A; d.lda = sh.K; d.mode = 0; d.Cin = sh.K; d.taps = 1;
-        d.Hin = d.Win = d.Hout = d.Wout = d.stride = d.up = 1;
-        d.W = W; d.M = sh.M; d.Nout = sh.N; d.Ktot = sh.K;
-        d.bias = bias; d.rows_per_img = 1; d.scale = 0.5f; d.geglu = sh.geglu;
-        if (sh.stream) { d.res = res; d.ldres = on; d.res_f32 = 1; d.out16 = mirror; d.ld16 = on; }
-        d.nseg = 1;
-        d.seg[0].out = out; d.seg[0].ld = on; d.seg[0].ncols = on; d.seg[0].dtype = sh.stream ? CTRL_F32 : CTRL_F16; d.seg[0].L = 1;
-        say("\n%s   M%d N%d K%d\n", sh.name, sh.M, sh.N, sh.K);
-        uint64_t sums[2] = {0, 0}, msum[2] = {0, 0};
-        float med[2] = {0, 0};
-        for (int round = 0; round < 2; ++round)
-            for (int pz = 0; pz < 2; ++pz) {
-                ctrl_igemm_set_persist(pz);
-                CK(hipMemsetAsync(out, 0xff, out_bytes, st));
-                std::vector<float> t;
-                for (int i = 0; i < 2; ++i)
-                    if (ctrl_op_igemm(&d, st) != 0) { say("  launch failed: %s\n", ctrl_last_error()); return 3; }
-                for (int i = 0; i < 8; ++i) {
-                    CK(hipEventRecord(e0, st));
-                    ctrl_op_igemm(&d, st);
-                    CK(hipEventRecord(e1, st));
-                    CK(hipEventSynchronize(e1));
-                    float ms = 0;
-                    CK(hipEventElapsedTime(&ms, e0, e1));
-                    t.push_back(ms);
-                }
-                std::sort(t.begin(), t.end());
-                med[pz] = t[t.size() / 2];
-                if (round == 0) {
-                    sums[pz] = checksum(out, out_bytes);
-                    if (mirror) msum[pz] = checksum(mirror, (size_t)sh.M * on * 2);
-                }
-            }
-        const double flops = 2.0 * sh.M * sh.N * sh.K;
-        say("  one-tile   %.4f ms (%.0f TFLOP/s)   persistent %.4f ms (%.0f TFLOP/s)   x%.3f   %s\n", med[0], flops / med[0] * 1e-9, med[1],
-            flops / med[1] * 1e-9, med[0] / med[1], (sums[0] == sums[1] && msum[0] == msum[1]) ? "bit-identical" : "RESULTS DIFFER");
-        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(out));
-        if (res) CK(hipFree(res));
-        if (mirror) CK(hipFree(mirror));
-    }
-    ctrl_igemm_set_persist(0);
-    say("\ndone\n");
-    return 0;
-}
-
 // Where the fixed cost of a short-K launch goes: the same plain GEMM with the output rows aliased (ld = 0: every store hits
 // one 4 KB row, nothing reaches HBM), the activation rows aliased (lda = 0), both, and the chip's plain fill / copy rates.
 static int stores() {
@@ -242,15 +162,11 @@ static int stores() {
             d.W = W; d.M = M; d.Nout = N; d.Ktot = K; d.rows_per_img = 1; d.scale = 1.f;
             d.nseg = 1;
             d.seg[0].out = out; d.seg[0].ld = (variant & 2) ? 0 : N; d.seg[0].ncols = N; d.seg[0].dtype = CTRL_F16; d.seg[0].L = 1;
-            for (int pz = 0; pz < 2; ++pz) {
-                ctrl_igemm_set_persist(pz);
-                ms = timeit([&] { ctrl_op_igemm(&d, st); });
-                say("K %d  A rows %-8s out rows %-8s %-10s %.4f ms  %.0f TFLOP/s\n", K, (variant & 1) ? "aliased" : "distinct",
-                    (variant & 2) ? "aliased" : "distinct", pz ? "persistent" : "one-tile", ms, 2.0 * M * N * K / ms * 1e-9);
-            }
+            ms = timeit([&] { ctrl_op_igemm(&d, st); });
+            say("K %d  A rows %-8s out rows %-8s %.4f ms  %.0f TFLOP/s\n", K, (variant & 1) ? "aliased" : "distinct",
+                (variant & 2) ? "aliased" : "distinct", ms, 2.0 * M * N * K / ms * 1e-9);
         }
     }
-    ctrl_igemm_set_persist(0);
     say("\ndone\n");
     return 0;
 }
@@ -265,7 +181,7 @@ static float h2f(uint16_t h) {
 static int check() {
     hipStream_t st;
     CK(hipStreamCreate(&st));
-    struct C { const char* name; int M, N, K; bool geglu; int res; bool rowvec; int persist; };   // res: 0 none, 1 fp32 stream (+ mirror), 2 fp16
+    struct C { const char* name; int M, N, K; bool geglu; int res; bool rowvec; int unused; };   // res: 0 none, 1 fp32 stream (+ mirror), 2 fp16
     const C cs[] = {
         {"plain + bias, 256x256", 8192, 2048, 64, false, 0, false, 0},
         {"geglu + bias, 256x256", 8192, 4096, 64, true, 0, false, 0},
@@ -277,8 +193,6 @@ static int check() {
         {"fp32 stream, 256x320 (N = 640)", 32768, 640, 64, false, 1, false, 0},
         {"rowvec + SiLU, 256x256", 8192, 2048, 64, false, 0, true, 0},
         {"small tile, M 1000 N 512 K 96", 1000, 512, 96, false, 1, false, 0},
-        {"fp32 stream, persistent form", 8192, 2048, 64, false, 1, false, 1},
-        {"geglu + bias, persistent form", 8192, 4096, 64, true, 0, false, 1},
     };
     int bad = 0;
     for (const C& c : cs) {
@@ -324,7 +238,6 @@ static int check() {
         if (c.res == 1) { d.out16 = mirror; d.ld16 = on; }
         d.nseg = 1;
         d.seg[0].out = out; d.seg[0].ld = on; d.seg[0].ncols = on; d.seg[0].dtype = f32out ? CTRL_F32 : CTRL_F16; d.seg[0].L = 1;
-        ctrl_igemm_set_persist(c.persist);
         if (ctrl_op_igemm(&d, st) != 0) { say("%s: launch failed: %s\n", c.name, ctrl_last_error()); return 3; }
         CK(hipStreamSynchronize(st));
         std::vector<uint8_t> ho(ob), hm;
@@ -377,7 +290,6 @@ static int check() {
         if (mirror) CK(hipFree(mirror));
         if (rowvec) CK(hipFree(rowvec));
     }
-    ctrl_igemm_set_persist(0);
     say(bad ? "\n%d case(s) FAILED\n" : "\nall cases ok\n", bad);
     return bad ? 4 : 0;
 }
@@ -386,7 +298,6 @@ int main(int argc, char** argv) {
     if (argc > 1) g_out = fopen(argv[1], "w");
     say("abi %d\n", ctrl_abi_version());
     if (argc > 2 && !strcmp(argv[2], "ksweep")) return ksweep();
-    if (argc > 2 && !strcmp(argv[2], "persist")) return persist_cmp();
     if (argc > 2 && !strcmp(argv[2], "stores")) return stores();
     if (argc > 2 && !strcmp(argv[2], "check")) return check();
     std::vector<Shape> shapes = {
