@@ -13,8 +13,7 @@
 //     rewritten only when the running maximum moves (no v_mov per tile);
 //   * the row-max exchange between the two half-waves is v_permlane32_swap (VALU) instead of ds_bpermute (an LDS
 //     round trip that also waits for the fragment reads in flight);
-//   * row sums of P are taken from the packed fp16 probabilities with v_dot2c_f32_f16 (16 instead of 32 adds; the
-//     denominator then sums exactly the values the numerator multiplies);
+//     (row sums of P through v_dot2c_f32_f16 on the packed probabilities were tried as well: no faster, dropped);
 //   * QB = 2: a wave owns two 32-query blocks, every K / V^T fragment read feeds two MFMAs (half the LDS read traffic
 //     per FLOP -- at one block per wave the LDS pipe is as busy as the matrix pipe) and the two blocks' independent
 //     softmax / MFMA chains give the scheduler work to overlap inside one wave.
@@ -25,7 +24,7 @@
 
 namespace {
 
-enum { AO_NEGM = 1, AO_DOT2 = 2, AO_PRIO = 4, AO_DEFER = 8, AO_MINI = 16 };
+enum { AO_NEGM = 1, AO_SGB = 2, AO_PRIO = 4, AO_DEFER = 8, AO_MINI = 16 };
 
 template <int QB, int NW, int OPT>
 __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_kernel(AttnArgs a, const half_t* zeros) {
@@ -201,7 +200,6 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
                         for (int r = 0; r < 16; ++r) negm[qb][r] = -m_run[qb];
                     }
                 }
-                // probabilities are packed to fp16 pairs ONCE; the row sum (v_dot2c) and the P^T operand read the same registers
                 typedef unsigned u4v __attribute__((ext_vector_type(4)));
                 float psum = 0.f;
 #pragma unroll
@@ -215,12 +213,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
                             const float p0 = __builtin_amdgcn_exp2f(sacc[qb][mi][r]), p1 = __builtin_amdgcn_exp2f(sacc[qb][mi][r + 1]);
                             const h2 pk = {(half_t)p0, (half_t)p1};
                             w[i] = __builtin_bit_cast(unsigned, pk);
-                            if constexpr (OPT & AO_DOT2) {
-                                const h2 one = {(half_t)1.f, (half_t)1.f};
-                                psum = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w[i]), one, psum, false);
-                            } else {
-                                psum += p0 + p1;
-                            }
+                            psum += p0 + p1;
                         }
                         pf[qb][mi][s2] = __builtin_bit_cast(h8, w);
                     }
@@ -273,6 +266,342 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Software-pipelined form: a wave owns TWO 32-query blocks A and B that run half a tile apart, so that inside ONE wave's
+// instruction stream the matrix work of one block always has the other block's softmax beside it:
+//     phase 1 of tile t:   MFMA  P.V of B (tile t-1), then QK^T of B (tile t)      VALU  exp2 / pack / row sums of A (tile t)
+//     phase 2 of tile t:   MFMA  P.V of A (tile t),   then QK^T of A (tile t+1)    VALU  exp2 / pack / row sums of B (tile t)
+// (between the phases: the row-maximum reduction of the block whose scores just finished and -- rarely -- its rescale).
+// Each phase is one basic block of 16 MFMAs (512 matrix-pipe cycles) and ~100 independent VALU instructions, which the
+// scheduler can interleave; the round-2 kernel left this overlap to chance (waves of a workgroup are phase-locked by the
+// per-tile barrier: its counters showed 38 % of the wave cycles waiting behind the matrix pipe and 36 % at waits).
+// 4 waves x 64 queries per workgroup, two workgroups per CU (<= 256 registers); K and V^T rings of 3 tiles each: phase 2 of
+// tile t needs V(t) and K(t+1), which are waited for once per tile, before ONE barrier.
+template <int OPT>
+__global__ __launch_bounds__(256, 2) void flash_attn_d64p_kernel(AttnArgs a) {
+    constexpr int NW = 4, NSTAGE = 3;
+    constexpr int TILEB = 64 * 64 * 2;
+    constexpr int VOFF = NSTAGE * TILEB;
+    constexpr int PASSES = 512 / (NW * 64);            // 2
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, lq = lane & 31;
+    const int qtiles = (a.Lq + 255) / 256;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pair = (j / qtiles) * 8 + xcd;
+    if (pair >= a.B * a.heads) return;
+    const int b = pair / a.heads, h = pair - b * a.heads;
+    const int q0 = (j % qtiles) * 256 + wave * 64;
+    const int Lq = a.Lq, Lk = a.Lk;
+
+    h8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int q = q0 + qb * 32 + lq;
+        if (q > Lq - 1) q = Lq - 1;
+        const half_t* qp = (const half_t*)a.Q + ((size_t)b * Lq + q) * a.ldq + (size_t)h * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const h8*)(qp + ks * 16 + hi * 8);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));
+
+    const half_t* Kbase = (const half_t*)a.K + (size_t)b * Lk * a.ldk + (size_t)h * 64;
+    const half_t* Vbase = (const half_t*)a.Vt + ((size_t)b * a.heads + h) * 64 * (size_t)a.Lkpad;
+    unsigned k_off[PASSES], v_off[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int ci = (i * NW + wave) * 64 + lane;
+        const int r = ci >> 3, p = ci & 7;
+        const int src = p ^ ((r >> 1) & 7);
+        k_off[i] = (unsigned)(((size_t)r * a.ldk + src * 8) * sizeof(half_t));
+        v_off[i] = (unsigned)(((size_t)r * a.Lkpad + src * 8) * sizeof(half_t));
+    }
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+    auto stage_k = [&](int t, int slot) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)(Kbase + (size_t)t * 64 * a.ldk) + k_off[i]),
+                                             (lptr_t)(smem_raw + slot * TILEB + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+    auto stage_v = [&](int t, int slot) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)(Vbase + t * 64) + v_off[i]),
+                                             (lptr_t)(smem_raw + VOFF + slot * TILEB + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+
+    const int krow = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
+    const int kA = krow * 128 + ((hi ^ ((krow >> 1) & 7)) << 4);
+    const int vA = lq * 128 + ((hi ^ ((lq >> 1) & 7)) << 4);
+
+    f16v o[2][2], sc[2][2];
+    h8 pf[2][2][2];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        m_run[qb] = 0.f; l_run[qb] = 0.f;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[qb][x][r] = 0.f; sc[qb][x][r] = 0.f; }
+#pragma unroll
+            for (int y = 0; y < 2; ++y) pf[qb][x][y] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    const int ntiles = Lk >> 6;
+    // the first P.V of block B multiplies an all-zero P with V^T slot 2: that slot must hold finite values
+    {
+        const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < TILEB / 16; i += 256) *(h8*)(smem_raw + VOFF + 2 * TILEB + i * 16) = z;
+    }
+    stage_k(0, 0);
+    if (ntiles > 1) stage_k(1, 1);
+    stage_v(0, 0);
+
+    // QK^T of block qb against the K tile at byte offset kb of LDS; acc starts at -m (scores arrive referenced to it)
+    auto qk = [&](const int qb, const int kb) {
+        f16v c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = -m_run[qb];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const h8 kf = *(const h8*)(smem_raw + kb + (kA ^ (ks << 5)) + mb * 4096);
+                sc[qb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], ks == 0 ? c0 : sc[qb][mb], 0, 0, 0);
+            }
+    };
+    auto pv = [&](const int qb, const int vb) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const h8 vf = *(const h8*)(smem_raw + VOFF + vb + (vA ^ (c4 << 5)) + db * 4096);
+                o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][c4 >> 1][c4 & 1], o[qb][db], 0, 0, 0);
+            }
+    };
+    // row maximum of the finished scores of block qb; moves the reference point (rarely) -- ends a basic block
+    auto smax = [&](const int qb, const bool first) {
+        float mx = sc[qb][0][0];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[qb][mb][r]);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        constexpr float THR = (OPT & AO_DEFER) ? 4.f : 0.f;
+        if (first || __any(mx > THR)) {
+            const float d = first ? mx : fmaxf(mx, 0.f);
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-d);
+            l_run[qb] *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+            m_run[qb] += d;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[qb][mb][r] -= d;
+        }
+    };
+    // exp2 / pack / row sum of block qb (straight-line: shares a basic block with the other block's MFMAs)
+    auto sexp = [&](const int qb) {
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        // pin the start of the softmax arithmetic HERE (pure VALU code is otherwise free to be emitted ahead of the phase's
+        // scheduling region, where it runs before the MFMAs instead of beside them)
+        asm volatile("" : "+v"(sc[qb][0]), "+v"(sc[qb][1]));
+        float psum = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u4v w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = s2 * 8 + i * 2;
+                    const float p0 = __builtin_amdgcn_exp2f(sc[qb][mb][r]), p1 = __builtin_amdgcn_exp2f(sc[qb][mb][r + 1]);
+                    const h2 pk = {(half_t)p0, (half_t)p1};
+                    w[i] = __builtin_bit_cast(unsigned, pk);
+                    psum += p0 + p1;
+                }
+                pf[qb][mb][s2] = __builtin_bit_cast(h8, w);
+            }
+        l_run[qb] += psum;
+    };
+    // scheduling hint for one phase: 16 x { 1 LDS read, 1 MFMA, 2 exp2, 4 VALU } (the tail takes whatever is left)
+    auto hint = [&]() {
+        if constexpr (OPT & AO_SGB) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one fragment read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);     // two exp2 (transcendentals are not in the VALU class)
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // pack / row sum / accumulator init
+            }
+        }
+    };
+
+    // AO_MINI: a phase cut into four pinned quarters -- {4 MFMAs of block qm, exp2 / pack / sum of 8 scores of block qs} each,
+    // every quarter its own scheduling region (sched_barrier on both sides, the scores it exponentiates made opaque at its
+    // start so the arithmetic cannot be emitted ahead of it), with a {1 read, 1 MFMA, 2 exp2, 3 VALU} x 4 hint inside
+    auto phase_q = [&](const int qm, const int qs, const int vb, const int kb) {
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        f16v c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = -m_run[qm];
+        float psum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mb = q >> 1, s2 = q & 1;
+            // Ordering point.  MFMA and exp2 are pure operations: nothing orders them against a sched_barrier or a volatile asm
+            // unless their operands pass through it -- so the point takes (whole register tuples, in place) the scores the next
+            // two quarters exponentiate, the accumulators the previous quarter's MFMAs wrote, the row sum and the packed
+            // probabilities (the previous quarter's VALU results): that quarter is complete in program order above this line.
+            if (q == 0) asm volatile("" : "+v"(sc[qs][0]));
+            else if (q == 1) asm volatile("" : "+v"(o[qm][0]), "+v"(o[qm][1]), "+v"(psum), "+v"(pf[qs][0][0]));
+            else if (q == 2) asm volatile("" : "+v"(sc[qs][1]), "+v"(o[qm][0]), "+v"(o[qm][1]), "+v"(psum), "+v"(pf[qs][0][1]));
+            else asm volatile("" : "+v"(sc[qm][0]), "+v"(sc[qm][1]), "+v"(psum), "+v"(pf[qs][1][0]));
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = sc[qs][mb][s2 * 8 + i];
+            // ---- 4 MFMAs: quarters 0,1 = P.V (c4 = 2q, 2q+1; both d blocks), quarters 2,3 = QK^T (ks = 2(q-2), +1; both key blocks)
+            if (q < 2) {
+#pragma unroll
+                for (int c4 = 2 * q; c4 < 2 * q + 2; ++c4)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const h8 vf = *(const h8*)(smem_raw + VOFF + vb + (vA ^ (c4 << 5)) + db * 4096);
+                        o[qm][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qm][c4 >> 1][c4 & 1], o[qm][db], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int ks = 2 * (q - 2); ks < 2 * (q - 2) + 2; ++ks)
+#pragma unroll
+                    for (int mb2 = 0; mb2 < 2; ++mb2) {
+                        const h8 kf = *(const h8*)(smem_raw + kb + (kA ^ (ks << 5)) + mb2 * 4096);
+                        sc[qm][mb2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qm][ks], ks == 0 ? c0 : sc[qm][mb2], 0, 0, 0);
+                    }
+            }
+            // ---- softmax of 8 scores of the other block
+            u4v w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p0 = __builtin_amdgcn_exp2f(x[2 * i]), p1 = __builtin_amdgcn_exp2f(x[2 * i + 1]);
+                const h2 pk = {(half_t)p0, (half_t)p1};
+                w[i] = __builtin_bit_cast(unsigned, pk);
+                psum += p0 + p1;
+            }
+            pf[qs][mb][s2] = __builtin_bit_cast(h8, w);
+            if constexpr (OPT & AO_SGB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("" : "+v"(sc[qm][0]), "+v"(sc[qm][1]), "+v"(psum), "+v"(pf[qs][1][1]));
+        l_run[qs] += psum;
+    };
+
+    // prologue: scores of block A for tile 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    qk(0, 0);
+    smax(0, true);
+
+    auto step = [&](auto slot_c, const int t) {
+        constexpr int S0 = decltype(slot_c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;     // t % 3, (t+1) % 3, (t+2) % 3 = (t-1) % 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K(t+1), V(t) (issued one tile ago) have landed
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < ntiles) stage_k(t + 2, S2);
+        if (t + 1 < ntiles) stage_v(t + 1, S1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (OPT & AO_MINI) {
+            phase_q(1, 0, S2 * TILEB, S0 * TILEB);
+            smax(1, t == 0);
+            __builtin_amdgcn_sched_barrier(0);
+            phase_q(0, 1, S0 * TILEB, S1 * TILEB);
+            if (t + 1 < ntiles) smax(0, false);
+        } else {
+            // ---- phase 1 ----
+            pv(1, S2 * TILEB);                  // B, tile t-1 (all-zero P on the first tile)
+            qk(1, S0 * TILEB);                  // B, tile t
+            sexp(0);                            // A, tile t
+            hint();
+            __builtin_amdgcn_sched_barrier(0);
+            smax(1, t == 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase 2 ----
+            pv(0, S0 * TILEB);                  // A, tile t
+            qk(0, S1 * TILEB);                  // A, tile t+1 (past the last tile: stale finite data, result unused)
+            sexp(1);                            // B, tile t
+            hint();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < ntiles) smax(0, false);
+        }
+    };
+    int t = 0;
+    for (; t + 3 <= ntiles; t += 3) {
+        step(std::integral_constant<int, 0>{}, t);
+        step(std::integral_constant<int, 1>{}, t + 1);
+        step(std::integral_constant<int, 2>{}, t + 2);
+    }
+    if (t < ntiles) { step(std::integral_constant<int, 0>{}, t); ++t; }
+    if (t < ntiles) { step(std::integral_constant<int, 1>{}, t); ++t; }
+    // epilogue: P.V of block B for the last tile (runtime slot)
+    pv(1, ((ntiles - 1) % 3) * TILEB);
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + qb * 32 + lq;
+        if (q < Lq) {
+            half_t* op = (half_t*)a.O + ((size_t)b * Lq + q) * a.ldo + (size_t)h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = db * 32 + 8 * g + 4 * hi;
+                    h4 v = {(half_t)(o[qb][db][4 * g] * inv), (half_t)(o[qb][db][4 * g + 1] * inv),
+                            (half_t)(o[qb][db][4 * g + 2] * inv), (half_t)(o[qb][db][4 * g + 3] * inv)};
+                    *(h4*)(op + d0) = v;
+                }
+        }
+    }
+}
+
+template <int OPT>
+int launch_d64p(const AttnArgs& a, hipStream_t s) {
+    constexpr size_t smem = (size_t)3 * 2 * 64 * 64 * sizeof(half_t);
+    static bool attr_done[kMaxDevices] = {};
+    const int dev = cur_device();
+    if (!attr_done[dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_d64p_kernel<OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done[dev] = true;
+    }
+    const int qtiles = (a.Lq + 255) / 256, pairs = a.B * a.heads;
+    dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
+    PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
+    prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
+    prof_symbol("flash_attn_d64p_kernel<%d>", OPT);
+    LAUNCH("flash_attn", (flash_attn_d64p_kernel<OPT>), grid, dim3(256), smem, s, a);
+    return 0;
+}
+
 template <int QB, int NW, int OPT>
 int launch_d64(const AttnArgs& a, hipStream_t s) {
     constexpr size_t smem = (size_t)3 * 2 * 64 * 64 * sizeof(half_t);
@@ -311,15 +640,19 @@ int attn_variant() {
 int op_flash_attn_d64(const AttnArgs& a, hipStream_t s, int variant) {
     switch (variant) {
         case 1: return launch_d64<1, 8, 0>(a, s);
-        case 2: return launch_d64<1, 8, AO_DOT2>(a, s);
-        case 3: return launch_d64<1, 8, AO_MINI | AO_DOT2>(a, s);
-        case 4: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DOT2>(a, s);
-        case 5: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DOT2 | AO_PRIO>(a, s);
-        case 6: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DOT2 | AO_DEFER>(a, s);
-        case 7: return launch_d64<2, 4, AO_DOT2>(a, s);
-        case 8: return launch_d64<2, 4, AO_NEGM | AO_DOT2>(a, s);
-        case 9: return launch_d64<2, 4, AO_MINI | AO_NEGM | AO_DOT2>(a, s);
-        case 10: return launch_d64<2, 8, AO_MINI | AO_NEGM | AO_DOT2>(a, s);
+        case 2: return launch_d64<1, 8, AO_DEFER>(a, s);
+        case 3: return launch_d64<1, 8, AO_MINI | AO_NEGM>(a, s);
+        case 4: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DEFER>(a, s);
+        case 5: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DEFER | AO_PRIO>(a, s);
+        case 6: return launch_d64<2, 4, 0>(a, s);
+        case 7: return launch_d64<2, 4, AO_DEFER>(a, s);
+        case 8: return launch_d64p<0>(a, s);
+        case 9: return launch_d64p<AO_DEFER>(a, s);
+        case 10: return launch_d64p<AO_SGB>(a, s);
+        case 11: return launch_d64p<AO_SGB | AO_DEFER>(a, s);
+        case 12: return launch_d64p<AO_MINI>(a, s);
+        case 13: return launch_d64p<AO_MINI | AO_SGB>(a, s);
+        case 14: return launch_d64p<AO_MINI | AO_SGB | AO_DEFER>(a, s);
         default: CTRL_FAIL("flash_attn: unknown variant " + std::to_string(variant));
     }
 }

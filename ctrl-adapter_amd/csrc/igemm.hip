@@ -445,6 +445,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                             }
                         }
                     }
+                    // Fused LayerNorm (full-row tile only, BN == Nout == 512 = the adapter's token width): the finished fp32 rows
+                    // -- what the stand-alone layernorm_kernel would re-read from HBM -- stay in registers (the accumulators of a
+                    // slab are dead once it is staged, its finished pieces take their place), per-row (sum, sum of squares)
+                    // partials are reduced inside the 16 lanes that share a row (DPP, fixed order), exchanged between the
+                    // WAVES_N waves of a row through LDS, and the normalised fp16 rows are written next to the fp32 master.
+                    constexpr bool LNT = (BN == 512 && WN == 128);
+                    constexpr int LNM = LNT ? MI : 1, LNR = LNT ? RT : 1;
+                    float ln_x[LNM][LNR][8];
+                    float ln_s[LNM][LNR], ln_q[LNM][LNR];
+#pragma unroll
+                    for (int i = 0; i < LNM; ++i)
+#pragma unroll
+                        for (int j = 0; j < LNR; ++j) { ln_s[i][j] = 0.f; ln_q[i][j] = 0.f; }
+                    const bool do_ln = LNT && e.ln_out != nullptr;
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
                         const int row_w = m0 + wm * WM + mi * 16 + erow;
@@ -526,6 +540,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
                             }
+                            if constexpr (LNT) {
+                                if (do_ln) {
+                                    float sx = 0.f, sq = 0.f;
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) { sx += x[i]; sq += x[i] * x[i]; ln_x[mi][t][i] = x[i]; }
+                                    // the 16 lanes of a DPP row hold the 128 columns of one output row (r = idx / 16): xor 1, xor 2,
+                                    // half-row mirror, row mirror -- every lane ends with the wave's partial of its row
+                                    sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0xB1, 0xF, 0xF, true));
+                                    sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0xB1, 0xF, 0xF, true));
+                                    sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x4E, 0xF, 0xF, true));
+                                    sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x4E, 0xF, 0xF, true));
+                                    sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x141, 0xF, 0xF, true));
+                                    sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x141, 0xF, 0xF, true));
+                                    sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x140, 0xF, 0xF, true));
+                                    sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x140, 0xF, 0xF, true));
+                                    ln_s[mi][t] = sx; ln_q[mi][t] = sq;
+                                }
+                            }
                             if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
                                 h8 pk;
 #pragma unroll
@@ -565,6 +597,47 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                             }
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
+                    }
+                    if constexpr (LNT) {
+                        if (do_ln) {       // workgroup-uniform: every wave takes the barrier
+                            // partials [wm][wn][row of the wave tile] behind the staging areas (the ring is dead)
+                            f2* part = (f2*)(epi_smem + (size_t)NW * 16 * SLD * sizeof(float));
+                            const int lrow = lane >> 4, c8l = lane & 15;
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                                for (int t = 0; t < RT; ++t)
+                                    if (c8l == 0) part[(wm * WAVES_N + wn) * WM + mi * 16 + lrow + 4 * t] = f2{ln_s[mi][t], ln_q[mi][t]};
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            const int ocol = wcol0 + c8l * 8;
+                            const f4 g0 = *(const f4*)(e.ln_gamma + ocol), g1 = *(const f4*)(e.ln_gamma + ocol + 4);
+                            const f4 b0 = *(const f4*)(e.ln_beta + ocol), b1 = *(const f4*)(e.ln_beta + ocol + 4);
+                            const float gam[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                            const float bet[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                                for (int t = 0; t < RT; ++t) {
+                                    const int rl = mi * 16 + lrow + 4 * t;
+                                    const int row = m0 + wm * WM + rl;
+                                    float sx = 0.f, sq = 0.f;
+#pragma unroll
+                                    for (int w2 = 0; w2 < WAVES_N; ++w2) {       // fixed order over the waves of the row
+                                        const f2 pv = part[(wm * WAVES_N + w2) * WM + rl];
+                                        sx += pv[0]; sq += pv[1];
+                                    }
+                                    const float mean = sx * (1.0f / BN);
+                                    const float var = fmaxf(sq * (1.0f / BN) - mean * mean, 0.f);
+                                    const float rstd = rsqrtf(var + e.ln_eps);
+                                    if (row < e.M) {
+                                        h8 pk;
+#pragma unroll
+                                        for (int i = 0; i < 8; ++i) pk[i] = (half_t)((ln_x[mi][t][i] - mean) * rstd * gam[i] + bet[i]);
+                                        *(h8*)((half_t*)e.ln_out + (size_t)row * e.ln_ld + ocol) = pk;
+                                    }
+                                }
+                        }
                     }
                 }
             } else {
@@ -850,6 +923,19 @@ void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, 
     tileorder::tile_of(bid, ntm, ntn, tileorder::make_order(mode, group), tile_m, tile_n);
 }
 
+// can the LayerNorm of this GEMM's output rows ride on its epilogue (ctrl_igemm_desc::ln_out)?  `a` without the ln_* fields set
+// describes the producer; the full-row tile exists for Nout == 512 (the adapter's token width, INNER)
+bool igemm_ln_fusable(const IGemmArgs& a) {
+    if (a.mode != IG_ROWS || a.Nout != 512 || a.geglu || a.nseg != 1 || a.seg[0].fmt != SEG_ROW || a.splitk_ws || a.a_split) return false;
+    if (a.scale2_from) return false;
+    if (!can_swap(a)) return false;
+    if (a.ln_out) {
+        if (!a.ln_gamma || !a.ln_beta || a.ln_ld % 8 != 0) return false;
+        if ((((uintptr_t)a.ln_out | (uintptr_t)a.ln_gamma | (uintptr_t)a.ln_beta) & 15) != 0) return false;
+    }
+    return true;
+}
+
 int igemm_splitk_factor(const IGemmArgs& a) {
     if (a.geglu || a.nseg != 1 || a.seg[0].fmt != SEG_ROW || a.Nout % 64 != 0 || a.Cin % 32 != 0 || a.mode == IG_TEMPORAL) return 1;
     const int bn = (a.Nout % 320 == 0) ? 320 : 256;
@@ -887,6 +973,8 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
             return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
         }
     }
+    // fused LayerNorm of the finished rows: the full-row tile (128 x 512, 64 x 128 per wave)
+    if (a.ln_out) return launch_cfg2<128, 512, 32, 2, 4, 3, MODE, true>(a, s);
     if (const char* f = getenv("CTRL_IGEMM_FORCE")) {      // tile experiments (tools/tile_experiment.py), row outputs only
         if (can_swap(a) && MODE == IG_ROWS) {
             if (!strcmp(f, "128x256")) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
@@ -935,6 +1023,8 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(!a.out16 || (a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a)), "igemm: the fp16 mirror needs a single aligned row-major output");
     CTRL_CHECK(!a.blend_mix || (a.blend_x && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && !a.geglu && can_swap(a)),
                "igemm: the blend fold needs a single aligned row-major output and an aligned blend operand");
+    CTRL_CHECK(!a.ln_out || igemm_ln_fusable(a), "igemm: the fused LayerNorm needs a rows-mode GEMM with Nout == 512, one aligned row-major "
+                                                  "output, no GEGLU / split-K / split operand, 16-byte aligned gamma / beta / output");
     for (int i = 0; i < a.nseg; ++i) {
         CTRL_CHECK(a.seg[i].col_begin % 16 == 0, "igemm: segment boundary must be a multiple of 16");
         CTRL_CHECK(a.seg[i].out != nullptr, "igemm: null segment output");

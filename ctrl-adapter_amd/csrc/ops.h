@@ -17,6 +17,8 @@ typedef ctrl_igemm_desc IGemmArgs;
 int op_igemm(const IGemmArgs& a, hipStream_t s);
 // K-split factor op_igemm would use given scratch (1 = no split); scratch needed = factor * M * Nout * sizeof(float)
 int igemm_splitk_factor(const IGemmArgs& a);
+// true when the LayerNorm that follows this GEMM can be computed by its epilogue (ctrl_igemm_desc::ln_out)
+bool igemm_ln_fusable(const IGemmArgs& a);
 // tile walk order of the implicit GEMM (tile_order.h): "legacy" | "auto" | "m,G" | "n,G"; 0 = accepted
 int igemm_set_order(const char* spec);
 void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);

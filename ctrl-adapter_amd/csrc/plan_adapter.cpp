@@ -294,9 +294,10 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
     half_t* mid = cx.h((size_t)M * 4 * dim);
     TRY(run_linear(cx, w.ffin1, xn, dim, tv16(mid), 4 * dim, M, TV(), 0));
     TV x0 = stream_alloc(cx, (size_t)M * dim, false);
-    TRY(run_linear(cx, w.ffin2, mid, 4 * dim, x0, dim, M, X, dim));
+    // (every LayerNorm below rides on the epilogue of the GEMM that produces its input: xn is free again once ff_in.net.0 has
+    // read it, and this stream is in order)
+    TRY(run_linear(cx, w.ffin2, mid, 4 * dim, x0, dim, M, X, dim, nullptr, 0, 0, nullptr, TV(), &w.norm1, xn));
     // x = attn1(norm1(x)) + x  (sequence = frames)
-    TRY(run_layernorm(cx, w.norm1, x0, xn, M, dim));
     half_t* o = nullptr;
     if (!a.comm) {
         half_t* qkv = cx.h((size_t)M * 3 * Ci);
@@ -332,9 +333,8 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
     // (note N5), added by the out-projection's epilogue.  Rows are (b f p) and the context is the broadcast vector or
     // the first frame of the only clip: the same vector for every row.
     TV x2 = stream_alloc(cx, (size_t)M * dim, false);
-    TRY(run_linear(cx, w.attn1.out, o, Ci, x2, dim, M, x0, dim, ov, dim, M));
+    TRY(run_linear(cx, w.attn1.out, o, Ci, x2, dim, M, x0, dim, ov, dim, M, nullptr, TV(), &w.norm3, xn));
     // x = ff(norm3(x)) + x
-    TRY(run_layernorm(cx, w.norm3, x2, xn, M, dim));
     half_t* mid2 = mid;
     TRY(run_linear(cx, w.ff1, xn, dim, tv16(mid2), 4 * dim, M, TV(), 0));
     TRY(run_linear(cx, w.ff2, mid2, 4 * dim, out, dim, M, x2, dim, nullptr, 0, 0, blend_mix, blend_other));
@@ -394,11 +394,13 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             half_t* n = cx.h((size_t)M * C);
             TRY(run_groupnorm(cx, b.norm, x, n, N, Lt, 1e-6f, false));
             TV tok = stream_alloc(cx, (size_t)M * INNER, false);
-            TRY(run_linear(cx, b.proj_in, n, C, tok, INNER, M, TV(), 0));
+            // the first LayerNorm of the spatial transformer rides on proj_in's epilogue
+            half_t* tok_ln = st ? cx.h((size_t)M * INNER) : nullptr;
+            TRY(run_linear(cx, b.proj_in, n, C, tok, INNER, M, TV(), 0, nullptr, 0, 0, nullptr, TV(), st ? &Lw.stb.norm1 : nullptr, tok_ln));
             TV smix;
             if (st) {
                 TV t2 = stream_alloc(cx, (size_t)M * INNER, !tt);      // proj_out operand when no temporal block follows
-                TRY(run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e, a.e.Lk == 1 ? pre.stb_ov[i] : nullptr));
+                TRY(run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e, a.e.Lk == 1 ? pre.stb_ov[i] : nullptr, nullptr, tok_ln));
                 tok = t2; smix = t2;
             }
             if (tt) {

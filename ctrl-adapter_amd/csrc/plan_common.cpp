@@ -96,8 +96,14 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
     return 0;
 }
 
+static bool ln_fuse_enabled() {
+    static const bool on = [] { const char* e = getenv("CTRL_LN_FUSE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, long ldy, int M, const TV& res, long ldres,
-               const float* rowvec, int rowvec_ld, int rows_per_vec, const float* blend_mix, const TV& blend_other) {
+               const float* rowvec, int rowvec_ld, int rows_per_vec, const float* blend_mix, const TV& blend_other,
+               const Norm* ln, half_t* ln_out) {
     IGemmArgs g = {};
     g.A = x; g.lda = ldx; g.mode = IG_ROWS; g.Cin = l.K; g.taps = 1;
     g.W = l.w; g.M = M; g.Nout = l.N; g.Ktot = l.K;
@@ -106,7 +112,16 @@ int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, lo
     set_res(g, res, ldres);
     set_out(g, y, ldy, l.geglu ? l.N / 2 : l.N);
     set_blend(g, blend_mix, blend_other, ldy);
+    // the dry pass has no real pointers (alignment checks would misfire) and launches nothing: fusable or not, the buffers are
+    // the same
+    bool fused = false;
+    if (ln && ln_out && !cx.dry && ln_fuse_enabled() && y.dt == DT_F32 && ldy == l.N && igemm_ln_fusable(g)) {
+        g.ln_gamma = ln->g; g.ln_beta = ln->b; g.ln_out = ln_out; g.ln_ld = l.N; g.ln_eps = 1e-5f;
+        fused = igemm_ln_fusable(g);
+        if (!fused) { g.ln_gamma = g.ln_beta = nullptr; g.ln_out = nullptr; }
+    }
     RUN(cx, op_igemm(g, cx.s));
+    if (ln && ln_out && !fused) TRY(run_layernorm(cx, *ln, y, ln_out, M, l.N));
     return 0;
 }
 
@@ -156,7 +171,7 @@ static int run_attention(Ctx& cx, const half_t* Q, long ldq, const half_t* K, lo
 // `addvec` (optional): a per-image vector added to the block output by the out-projection's epilogue -- the
 // single-key cross-attention that follows the self-attention (note N5) costs no pass of its own
 static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, const TV& resid, const TV& out, int B, int L,
-                         const float* addvec = nullptr, int addvec_rows = 0) {
+                         const float* addvec = nullptr, int addvec_rows = 0, const Norm* ln_next = nullptr, half_t* ln_out = nullptr) {
     const size_t mk = cx.mark();
     const int M = B * L, Ci = w.inner;
     const int Lpad = (L + 63) / 64 * 64;
@@ -180,7 +195,7 @@ static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, con
     RUN(cx, op_igemm(gv, cx.s));
     half_t* o = cx.h((size_t)M * Ci);
     TRY(run_attention(cx, qk, 2 * Ci, qk + Ci, 2 * Ci, vt, Lpad, o, Ci, B, B, w.heads, w.D, L, L));
-    TRY(run_linear(cx, w.out, o, Ci, out, dim, M, resid, dim, addvec, dim, addvec_rows));
+    TRY(run_linear(cx, w.out, o, Ci, out, dim, M, resid, dim, addvec, dim, addvec_rows, nullptr, TV(), ln_next, ln_out));
     cx.release(mk);
     return 0;
 }
@@ -230,8 +245,10 @@ int project_text_kv(Ctx& cx, const AttnW& w, const EhsCtx& e, PreKV* out) {
     return 0;
 }
 
+// xn_pre (optional): LayerNorm(ln)(x) already computed by x's producer; ln_next / ln_out: the LayerNorm applied to `out` next
 static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, int dim, const TV& out, int B, int L,
-                          const EhsCtx& e, const PreKV* pre = nullptr) {
+                          const EhsCtx& e, const PreKV* pre = nullptr, const half_t* xn_pre = nullptr,
+                          const Norm* ln_next = nullptr, half_t* ln_out = nullptr) {
     const size_t mk = cx.mark();
     const int M = B * L, Ci = w.inner;
     if (e.Lk == 1) {
@@ -239,11 +256,16 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, 
         float* o = nullptr;
         TRY(single_key_vector(cx, w, dim, e, &o));
         RUN(cx, op_add_rowvec(x.p, x.dt, o, dim, out.p, out.dt, (size_t)M, dim, L, e.batch, cx.s));
+        if (ln_next && ln_out) TRY(run_layernorm(cx, *ln_next, out, ln_out, M, dim));
         cx.release(mk);
         return 0;
     }
-    half_t* xn = cx.h((size_t)M * dim);
-    TRY(run_layernorm(cx, ln, x, xn, M, dim));
+    const half_t* xn = xn_pre;
+    if (!xn) {
+        half_t* xb = cx.h((size_t)M * dim);
+        TRY(run_layernorm(cx, ln, x, xb, M, dim));
+        xn = xb;
+    }
     half_t* q = cx.h((size_t)M * Ci);
     TRY(run_linear(cx, w.q, xn, dim, tv16(q), Ci, M, TV(), 0));
     const int Lkpad = (e.Lk + 63) / 64 * 64;
@@ -253,15 +275,21 @@ static int run_cross_attn(Ctx& cx, const AttnW& w, const Norm& ln, const TV& x, 
     half_t* k = kv.k; half_t* vt = kv.vt;
     half_t* o = cx.h((size_t)M * Ci);
     TRY(run_attention(cx, q, Ci, k, Ci, vt, Lkpad, o, Ci, B, e.batch == 1 ? 1 : B, w.heads, w.D, L, e.Lk));
-    TRY(run_linear(cx, w.out, o, Ci, out, dim, M, x, dim));
+    TRY(run_linear(cx, w.out, o, Ci, out, dim, M, x, dim, nullptr, 0, 0, nullptr, TV(), ln_next, ln_out));
     cx.release(mk);
     return 0;
 }
 
-static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const TV& x, int dim, const TV& out, int M) {
+// xn_pre (optional): LayerNorm(ln)(x) already computed by x's producer
+static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const TV& x, int dim, const TV& out, int M,
+                  const half_t* xn_pre = nullptr) {
     const size_t mk = cx.mark();
-    half_t* xn = cx.h((size_t)M * dim);
-    TRY(run_layernorm(cx, ln, x, xn, M, dim));
+    const half_t* xn = xn_pre;
+    if (!xn) {
+        half_t* xb = cx.h((size_t)M * dim);
+        TRY(run_layernorm(cx, ln, x, xb, M, dim));
+        xn = xb;
+    }
     const int inner = ff1.N / 2;
     half_t* hmid = cx.h((size_t)M * inner);
     TRY(run_linear(cx, ff1, xn, dim, tv16(hmid), inner, M, TV(), 0));
@@ -271,25 +299,34 @@ static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const
 }
 
 int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e, const float* ov_pre,
-                 const PreKV* kv_pre) {
+                 const PreKV* kv_pre, const half_t* X_ln) {
     CTRL_CHECK(e.batch == 1 || e.batch == B, "encoder_hidden_states batch must be 1 or equal to the sample batch");
     const size_t mk = cx.mark();
     const int M = B * L, dim = w.dim;
-    half_t* xn = cx.h((size_t)M * dim);
-    TRY(run_layernorm(cx, w.norm1, X, xn, M, dim));
+    const half_t* xn = X_ln;
+    if (!xn) {
+        half_t* xb = cx.h((size_t)M * dim);
+        TRY(run_layernorm(cx, w.norm1, X, xb, M, dim));
+        xn = xb;
+    }
+    // every LayerNorm of the block is handed to the GEMM that produces its input (run_linear: fused into that epilogue for
+    // 512-wide fp32 rows, the stand-alone kernel otherwise)
+    half_t* xn2 = cx.h((size_t)M * dim);        // LayerNorm(norm2)(x1), then re-used for LayerNorm(norm3)(x2)
     TV x2 = stream_alloc(cx, (size_t)M * dim, false);
     if (e.Lk == 1) {
         // x2 = X + attn1(norm1 X) + to_out(to_v(ctx)): the query-independent cross-attention term rides on the self-
         // attention's out-projection epilogue (per-image vector; one vector for all rows when the context is broadcast)
         float* ov = const_cast<float*>(ov_pre);
         if (!ov) TRY(single_key_vector(cx, w.attn2, dim, e, &ov));
-        TRY(run_self_attn(cx, w.attn1, xn, dim, X, x2, B, L, ov, e.batch == 1 ? M : L));
+        TRY(run_self_attn(cx, w.attn1, xn, dim, X, x2, B, L, ov, e.batch == 1 ? M : L, &w.norm3, xn2));
+        TRY(run_ff(cx, w.norm3, w.ff1, w.ff2, x2, dim, out, M, xn2));
     } else {
         TV x1 = stream_alloc(cx, (size_t)M * dim, false);
-        TRY(run_self_attn(cx, w.attn1, xn, dim, X, x1, B, L));
-        TRY(run_cross_attn(cx, w.attn2, w.norm2, x1, dim, x2, B, L, e, kv_pre));
+        half_t* xn3 = cx.h((size_t)M * dim);
+        TRY(run_self_attn(cx, w.attn1, xn, dim, X, x1, B, L, nullptr, 0, &w.norm2, xn2));
+        TRY(run_cross_attn(cx, w.attn2, w.norm2, x1, dim, x2, B, L, e, kv_pre, xn2, &w.norm3, xn3));
+        TRY(run_ff(cx, w.norm3, w.ff1, w.ff2, x2, dim, out, M, xn3));
     }
-    TRY(run_ff(cx, w.norm3, w.ff1, w.ff2, x2, dim, out, M));
     cx.release(mk);
     return 0;
 }

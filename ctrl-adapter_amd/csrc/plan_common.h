@@ -432,9 +432,12 @@ struct ConvOpts {
 };
 int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int Hin, int Win, const ConvOpts& o);
 // rowvec (optional): fp32 [M / rows_per_vec][rowvec_ld] added to every row of its group by the GEMM epilogue
+// ln / ln_out (optional): the LayerNorm that the NEXT op applies to y, written as fp16 rows [M][l.N] into ln_out -- by this
+// GEMM's epilogue when it can (igemm_ln_fusable: 512-wide fp32 stream rows), by the stand-alone kernel otherwise; either
+// way the caller finds LayerNorm(y) in ln_out afterwards (CTRL_LN_FUSE=0 forces the stand-alone kernel)
 int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, long ldy, int M, const TV& res, long ldres,
                const float* rowvec = nullptr, int rowvec_ld = 0, int rows_per_vec = 0,
-               const float* blend_mix = nullptr, const TV& blend_other = TV());
+               const float* blend_mix = nullptr, const TV& blend_other = TV(), const Norm* ln = nullptr, half_t* ln_out = nullptr);
 // out = ResnetBlock2D(x, temb); temb_proj = rowvec [N][ld] (already time_emb_proj(SiLU(emb)) incl. bias).
 // x.m16 must exist when the block has a shortcut conv (it is that conv's operand).
 int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int H, int W, int up,
@@ -447,8 +450,9 @@ struct PreKV { half_t* k = nullptr; half_t* vt = nullptr; };
 int project_text_kv(Ctx& cx, const AttnW& w, const EhsCtx& e, PreKV* out);
 // X [B*L][dim] stream -> out stream (out.m16 is filled when the caller needs a GEMM-operand copy)
 // ov_pre (optional, Lk == 1 only): the single-key cross-attention vector computed ahead of time (single_key_vector)
+// X_ln (optional): LayerNorm(norm1)(X) already computed by X's producer (run_linear(..., &w.norm1, X_ln))
 int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, int L, const EhsCtx& e, const float* ov_pre = nullptr,
-                 const PreKV* kv_pre = nullptr);
+                 const PreKV* kv_pre = nullptr, const half_t* X_ln = nullptr);
 // [e.batch][dim] fp32 output of a one-key cross-attention (query independent, note N5)
 int single_key_vector(Ctx& cx, const AttnW& w, int dim, const EhsCtx& e, float** out);
 int run_layernorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int M, int dim);

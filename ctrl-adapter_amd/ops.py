@@ -57,8 +57,10 @@ def pack_vec(v, geglu=False):
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
           res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None,
-          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False, scale2=0.0, scale2_from=0):
-    """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
+          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False, scale2=0.0, scale2_from=0,
+          ln=None):
+    """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L); ln: (gamma fp32, beta fp32, out fp16 [M][ld], ld, eps) = the
+    LayerNorm of the finished rows computed by the epilogue (Nout == 512)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
     g = geom or {}
@@ -84,6 +86,8 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.scale = scale; d.geglu = int(geglu)
     d.scale2 = scale2; d.scale2_from = scale2_from
     d.a_split = int(a_split); d.out16_lo_off = out16_lo_off      # a_split: 0 | 1 (weights packed twice) | 2 (paired walk)
+    if ln is not None:
+        d.ln_gamma = ln[0].data_ptr(); d.ln_beta = ln[1].data_ptr(); d.ln_out = ln[2].data_ptr(); d.ln_ld = ln[3]; d.ln_eps = ln[4]
     d.nseg = len(segs)
     for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):
         d.seg[i].out = out.data_ptr(); d.seg[i].ld = ld; d.seg[i].col_begin = cb; d.seg[i].ncols = nc
@@ -101,7 +105,7 @@ def set_igemm_order(spec):
 def set_attn_variant(v):
     """instruction-selection variant of the head_dim-64 long-sequence attention kernel (0 = the round-2 kernel); every
     variant computes the same function (csrc/attention_d64.hip)"""
-    check(L.lib().ctrl_attn_set_variant(int(v)))
+    L.check(L.lib().ctrl_attn_set_variant(int(v)))
 
 
 def linear(x, w_packed, bias=None, res=None, geglu=False):

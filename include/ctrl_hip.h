@@ -95,6 +95,12 @@ typedef struct ctrl_igemm_desc {
     float scale2; int32_t scale2_from;   /* scale2_from > 0: output columns >= scale2_from are multiplied by scale2 instead of scale
                                             (row-major outputs): the K half of a Q|K projection leaves pre-multiplied by
                                             softmax_scale * log2(e) for ctrl_attn_desc::k_prescaled */
+    /* optional fused LayerNorm of the finished output rows (rows mode, Nout == 512, one row-major output; the LayerNorm
+     * -> Linear pairs of diffusers' BasicTransformerBlock / TemporalBasicTransformerBlock reached from
+     * model/adapter_spatial_temporal.py:108-130): besides the output itself the epilogue writes
+     * ln_out[m*ln_ld + n] = fp16((y[m][n] - mean_m) * rstd_m * ln_gamma[n] + ln_beta[n]) with the row statistics taken in
+     * fp32 from the finished values (biased variance, eps inside the square root, fixed summation order) */
+    const float* ln_gamma; const float* ln_beta; void* ln_out; int64_t ln_ld; float ln_eps; int32_t pad2_;
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);

@@ -235,7 +235,7 @@ def test_flash_attn_d64_variants(ops, gpu):
     vt = v.half().permute(0, 2, 1).contiguous()
     ks = (k * (1.4426950408889634 / math.sqrt(D))).half()
     try:
-        for variant in range(0, 11):
+        for variant in range(0, 15):
             ops.set_attn_variant(variant)
             out = ops.flash_attn(q.half().reshape(B * L, Cc).to(gpu), Cc, ks.reshape(B * L, Cc).to(gpu), Cc, vt.to(gpu), L,
                                  B, heads, D, L, L, k_prescaled=True)
@@ -454,6 +454,35 @@ def test_two_workgroup_tiles_at_large_m(ops, gpu, K, geglu, f32):
         ops.igemm(x.half().to(gpu), K, wp, M, N, K, bias=bp, res=r.to(gpu), ldres=N, segs=[(out, N, 0, N, ops.SEG_ROW, 1)], out16=mirror, ld16=N)
         report("2-WG tile f32 stream K%d master" % K, rel_inf(out, ref), 2e-5)
         report("2-WG tile f32 stream K%d mirror" % K, rel_inf(mirror, ref))
+
+
+@pytest.mark.parametrize("M,K,res", [(4096, 320, False), (1000, 320, True), (16384 + 72, 2048, True)])
+def test_linear_with_fused_layernorm(ops, gpu, M, K, res):
+    """ctrl_igemm_desc::ln_out -- the LayerNorm -> Linear pairs of diffusers' (Temporal)BasicTransformerBlock reached from
+    model/adapter_spatial_temporal.py:108-130: the GEMM that produces a 512-wide fp32 stream row also writes LayerNorm(row)
+    in fp16 (full-row 128 x 512 tile).  Master vs an fp32 matmul, normalised rows vs torch's LayerNorm of the master the
+    kernel itself wrote (same input, so only the statistics / affine arithmetic is compared), ragged M"""
+    N = 512
+    x, w, b = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=0.05), rnd(N, seed=33)
+    gamma = (1.0 + 0.1 * rnd(N, seed=34)).contiguous()
+    beta = (0.1 * rnd(N, seed=35)).contiguous()
+    r = (torch.randn(M, N, generator=torch.Generator().manual_seed(36)) * 2.0 + 0.7) if res else None     # a row mean away from 0
+    wp, bp = ops.pack_linear_w(w.to(gpu)), ops.pack_vec(b.to(gpu))
+    out = torch.empty(M, N, dtype=torch.float32, device=gpu)
+    ln = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    ops.igemm(x.half().to(gpu), K, wp, M, N, K, bias=bp, res=r.to(gpu) if res else None, ldres=N,
+              segs=[(out, N, 0, N, ops.SEG_ROW, 1)], ln=(gamma.to(gpu), beta.to(gpu), ln, N, 1e-5))
+    ref = x.half().float() @ w.half().float().t() + b + (r if res else 0.0)
+    report("fused LN: fp32 master M%d K%d" % (M, K), rel_inf(out, ref), 2e-5)
+    want = F.layer_norm(out.cpu(), (N,), gamma, beta, 1e-5)
+    report("fused LN: normalised rows M%d K%d" % (M, K), rel_inf(ln, want), 6e-4)
+    # and the same rows through the stand-alone kernel (what the plan falls back to for other widths)
+    alone = ops.layernorm(out, gamma.to(gpu), beta.to(gpu))
+    assert (ln.float() - alone.float()).abs().max().item() <= 2e-3 * want.abs().max().item()
+    with pytest.raises((ValueError, RuntimeError)):      # only the 512-wide full-row tile exists
+        ops.igemm(x.half().to(gpu), K, ops.pack_linear_w(rnd(640, K, seed=1).to(gpu)), M, 640, K,
+                  segs=[(torch.empty(M, 640, dtype=torch.float32, device=gpu), 640, 0, 640, ops.SEG_ROW, 1)],
+                  ln=(gamma.to(gpu), beta.to(gpu), ln, N, 1e-5))
 
 
 def test_tile_walk_orders_are_bit_identical(ops, gpu):

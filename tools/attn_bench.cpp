@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
     if (argc > 2) {
         for (char* tok = strtok(argv[2], ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
     } else {
-        for (int v = 0; v <= 10; ++v) variants.push_back(v);
+        for (int v = 0; v <= 14; ++v) variants.push_back(v);
     }
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -138,7 +138,7 @@ int main(int argc, char** argv) {
                 const int samples[][3] = {{0, 0, 0}, {0, 0, 1}, {B - 1, sh.heads - 1, L - 1}, {B / 2, sh.heads / 2, L / 2 + 37}, {1, 1, 255}, {2, 0, 256}, {3, 2, 8191}};
                 std::vector<double> sc(L);
                 for (auto& sm : samples) {
-                    const int b = sm[0], h = sm[1], q = sm[2];
+                    const int b = sm[0], h = sm[1], q = sm[2] % L;
                     double mx = -1e300;
                     for (int k = 0; k < L; ++k) {
                         double s = 0;
