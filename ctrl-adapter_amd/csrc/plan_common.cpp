@@ -97,7 +97,7 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
 }
 
 static bool ln_fuse_enabled() {
-    static const bool on = [] { const char* e = getenv("CTRL_LN_FUSE"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = getenv("CTRL_LN_FUSE"); return e && e[0] == '1'; }();
     return on;
 }
 

@@ -35,14 +35,17 @@ def symbol_of(name):
         tf = lambda v: "true" if v == "1" else "false"
         # (the 9th argument -- persistent-workgroup form -- exists from round 2's last build on; older traces lack it)
         return "igemm_kernel<%s, %s, %s, %s, %s, %s, %s, %s%s>" % (g[:7] + (tf(g[7]), ", " + tf(g[8]) if g[8] is not None else ""))
-    m = re.search(r"flash_attn_d64_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)
+    m = re.search(r"flash_attn_d64_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
-        return "flash_attn_d64_kernel<%s, %s, %s>" % m.groups()
+        return "flash_attn_d64_kernel<%s, %s, %s, %s>" % m.groups()
+    m = re.search(r"flash_attn_d64p_kernelILi(\d+)E", name)
+    if m:
+        return "flash_attn_d64p_kernel<%s>" % m.groups()
     m = re.search(r"flash_attn_kernelILi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
     if m:
         tf = lambda v: "true" if v == "1" else "false"
         return "flash_attn_kernel<%s, %s, %s, %s>" % (m.group(1), m.group(2), tf(m.group(3)), tf(m.group(4)))
-    m = re.search(r"((?:igemm|flash_attn|flash_attn_d64)_kernel<[^>]*>)", name)
+    m = re.search(r"((?:igemm|flash_attn|flash_attn_d64|flash_attn_d64p)_kernel<[^>]*>)", name)
     if m:
         return re.sub(r",\s*", ", ", m.group(1))
     m = re.search(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+_kernel)", name) or re.search(r"([a-z0-9_]+_kernel)", name)
