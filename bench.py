@@ -140,6 +140,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-kernel-out", default=os.path.join(ROOT, "bench_per_kernel.json"),
                     help="where rank 0 writes the per-kernel / per-class tables (they are too long for the headline line)")
+    ap.add_argument("--clip-split", action="store_true",
+                    help="video workloads: ONE clip for the whole job, its 16 frames sharded over the --gpus ranks (frame-mixing "
+                         "ops exchange over RCCL: all_to_all around the temporal transformers, Conv3d halo, GroupNorm "
+                         "all-reduce; SURVEY.md 8e row 2); strong scaling, eager launches (the exchanges are host callbacks)")
     ap.add_argument("--fused", action="store_true",
                     help="time the fused controlled_step(controlnet, adapter, ...) instead of the pipelines' two calls "
                          "controlnet(...) ; adapter(...) (same arithmetic, bit-identical results)")
@@ -168,7 +172,21 @@ def main():
     n = args.batch if not w["video"] else 32          # video: one CFG pair of a 16-frame clip per GPU
     nf = 1 if not w["video"] else 16
     P, cns, ad, router = build_models(dev, w)
-    x = make_inputs(dev, w, n, seed=1234 + rank)       # every rank owns different images / clips (no collective)
+    comm = None
+    if args.clip_split:
+        if not w["video"] or w["n_cn"] != 1 or nf % world:
+            raise SystemExit("--clip-split: a single-ControlNet video workload whose 16 frames divide by --gpus")
+        from ctrl_adapter_amd.clip_parallel import TorchDistTransport, shard_frames
+        if world == 1 and not torch.distributed.is_initialized():      # a one-rank group still runs every exchange through RCCL
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+            torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port_, rank=0, world_size=1)
+        comm = TorchDistTransport()
+        x = make_inputs(dev, w, n, seed=1234)          # the SAME clip on every rank ...
+        x = {k: (shard_frames(v, nf, rank, world) if v.shape[0] == n else v) for k, v in x.items()}      # ... its frames sharded
+        n, nf = n // world, nf // world
+        args.no_graph = True
+    else:
+        x = make_inputs(dev, w, n, seed=1234 + rank)   # every rank owns different images / clips (no collective)
     t = torch.tensor([499.0], device=dev)
     masks = [1] * w["n_cn"]
 
@@ -186,6 +204,8 @@ def main():
     def step_separate():
         s = P.pool_latents(x["latents"], (64, 64))
         down, mid = controlnets(s)
+        if comm is not None:
+            return (down, mid), ad(down, mid_block_res_sample=mid, num_frames=nf, timestep=t, encoder_hidden_states=x["ehs_a"], clip_comm=comm)
         return (down, mid), ad(down, mid_block_res_sample=mid, num_frames=nf, timestep=t, encoder_hidden_states=x["ehs_a"])
 
     def step_fused():
@@ -224,11 +244,13 @@ def main():
     elapsed = dp.timed_region(run, args.steps, device=dev)        # barrier + sync on both sides, MAX over ranks
     ms_per_step = elapsed / args.steps * 1e3
     value = dp.aggregate_throughput(1, args.steps, elapsed, world)   # whole-job denoise-steps/s (each rank: its own batch / clip)
+    if comm is not None:
+        value = args.steps / elapsed                                 # ONE clip for the whole job: strong scaling
 
     # ---- the same step through the fused entry point (ControlNet on its own stream, adapter blocks start when their input
     #      exists): same arithmetic, bit-identical results; reported beside the headline, never as `value` ----
     fused = None
-    if w["n_cn"] == 1 and not args.fused and not args.no_graph:
+    if w["n_cn"] == 1 and not args.fused and not args.no_graph and comm is None:
         try:
             for _ in range(2):
                 step_fused()
@@ -291,7 +313,7 @@ def main():
     # ---- cpu_baseline leg: the fp32 oracle on the host cores, ONE pass over the whole step of this workload (rank 0, N=1
     #      only) on the very inputs the HIP step was timed on; its outputs are the parity check of the benched configuration ----
     cpu, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and comm is None:
         import cases  # noqa: F401
         from oracle.init import seeded_init
         from oracle.controlnet import ControlNetOracle
@@ -341,7 +363,7 @@ def main():
                   "what": "HIP step (these plans, these %d distinct inputs) vs fp32 oracle -> oracle chain" % n}
 
     if rank == 0:
-        flops_step = step_flops(w, n)
+        flops_step = step_flops(w, n)       # this rank's share (clip split: N / world frames)
         if kernels or per_kernel:
             try:
                 with open(args.per_kernel_out, "w") as fh:
@@ -352,12 +374,16 @@ def main():
         top = [{"kernel": r["kernel"][:96], "ms_per_step": r["ms_per_step"], "frac": r["frac"]} for r in per_kernel[1:4]]
         line = {
             "metric": w["metric"], "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong" if comm is not None else "weak",
             "vs_baseline": None,
             "dtype": "f16",    # MFMA operands fp16; fp32 accumulate / statistics / softmax / residual streams
             "data": "synthetic latents, prompts, condition images; seeded random weights",
             "config": {"workload": args.workload + ": " + ((w["what"] % (n, n)) if "%d" in w["what"] else w["what"])[:150],
-                       "baseline_config": w["config"], "batch_per_gpu": n, "parallelism": "dp%d, no collective" % world,
+                       "baseline_config": w["config"], "batch_per_gpu": n,
+                       "parallelism": ("one clip, frames sharded over %d ranks: all_to_all / halo / all-reduce over RCCL, %.0f MB sent "
+                                       "per rank and step" % (world, comm.bytes_sent / max(1, args.steps + args.warmup + 2 + 3) / 1e6))
+                       if comm is not None else "dp%d, no collective" % world,
                        "launch": mode, "call_form": "controlnet(...) ; adapter(...)" if not args.fused else "controlled_step(...)"},
             "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
             "mfma_frac_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),

@@ -73,12 +73,13 @@ class AdapterConfig(C.Structure):
 CB_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
 CB_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
 CB_HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
+CB_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
 
 
 class ClipComm(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
                 ("all_gather", CB_GATHER), ("all_reduce_sum_f32", CB_REDUCE), ("halo_exchange", CB_HALO),
-                ("user", C.c_void_p), ("ws_needed", C.c_int64)]
+                ("user", C.c_void_p), ("ws_needed", C.c_int64), ("all_to_all", CB_A2A)]
 
 
 # every symbol include/ctrl_hip.h declares (tests check the library exports all of them)

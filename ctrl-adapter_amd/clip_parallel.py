@@ -2,7 +2,8 @@
 
 Every rank holds F / world consecutive frames of every clip and runs the whole hot path on them; only the three frame-mixing
 ops of the adapter exchange data (include/ctrl_hip.h, ctrl_clip_comm):
-    temporal attention   all-gather of the K|V rows over the frame axis     (model/adapter_spatial_temporal.py:280)
+    temporal transformer all-to-all: frame shards <-> pixel shards around    (model/adapter_spatial_temporal.py:280)
+                         the block (or, without it, an all-gather of the K|V rows over the frame axis)
     Conv3d (3,1,1)       +-1-frame halo with the neighbour ranks            (TemporalResnetBlock, :226)
     temporal GroupNorm   all-reduce of the 2 x 32 x clips partial sums      (TemporalResnetBlock, :226)
 The native side calls back into a *transport* with byte offsets into an exchange workspace the transport owns:
@@ -47,7 +48,9 @@ class ClipTransport:
         self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
         self.ws = None
         self.error = None
-        self._cb = (L.CB_GATHER(self._c_gather), L.CB_REDUCE(self._c_reduce), L.CB_HALO(self._c_halo))
+        self._cb = (L.CB_GATHER(self._c_gather), L.CB_REDUCE(self._c_reduce), L.CB_HALO(self._c_halo), L.CB_A2A(self._c_a2a))
+        self.use_all_to_all = True       # False: the K|V all-gather form of the temporal attention (ctrl_clip_comm::all_to_all = NULL)
+        self.bytes_sent = 0              # payload this rank handed to the transport (diagnostics / bench)
         self.ensure(1 << 20)
 
     def ensure(self, nbytes):
@@ -62,27 +65,43 @@ class ClipTransport:
         s = L.ClipComm()
         s.rank, s.world = self.rank, self.world
         s.ws, s.ws_bytes = self.ws.data_ptr(), self.ws.numel()
-        s.all_gather, s.all_reduce_sum_f32, s.halo_exchange = self._cb
+        s.all_gather, s.all_reduce_sum_f32, s.halo_exchange = self._cb[:3]
+        s.all_to_all = self._cb[3] if self.use_all_to_all else L.CB_A2A()
         s.user, s.ws_needed = None, 0
         return s
 
     # ---- C callbacks: never let an exception cross the C frame ----
-    def _guard(self, fn, *a):
+    def _guard(self, stream, fn, *a):
+        """runs one exchange with `stream` (the hipStream_t the forward enqueues on) as torch's current stream, so that the
+        collective is ordered exactly where the native side placed it even when the caller's torch stream is another one"""
         try:
-            fn(*a)
+            ctx = None
+            if self.ws.is_cuda and stream and int(stream) != torch.cuda.current_stream(self.device).cuda_stream:
+                ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=self.device))
+            if ctx is None:
+                fn(*a)
+            else:
+                with ctx:
+                    fn(*a)
             return 0
         except BaseException as e:      # noqa: BLE001 - reported to the caller of the forward
             self.error = e
             return 1
 
     def _c_gather(self, user, send_off, recv_off, nbytes, stream):
-        return self._guard(self.all_gather, send_off, recv_off, nbytes)
+        self.bytes_sent += nbytes
+        return self._guard(stream, self.all_gather, send_off, recv_off, nbytes)
 
     def _c_reduce(self, user, off, count, stream):
-        return self._guard(self.all_reduce_sum_f32, off, count)
+        return self._guard(stream, self.all_reduce_sum_f32, off, count)
 
     def _c_halo(self, user, sp, sn, rp, rn, nbytes, stream):
-        return self._guard(self.halo_exchange, sp, sn, rp, rn, nbytes)
+        self.bytes_sent += nbytes * ((self.rank > 0) + (self.rank < self.world - 1))
+        return self._guard(stream, self.halo_exchange, sp, sn, rp, rn, nbytes)
+
+    def _c_a2a(self, user, send_off, recv_off, nbytes, stream):
+        self.bytes_sent += nbytes * (self.world - 1)
+        return self._guard(stream, self.all_to_all, send_off, recv_off, nbytes)
 
 
 class TorchDistTransport(ClipTransport):
@@ -109,6 +128,21 @@ class TorchDistTransport(ClipTransport):
 
     def all_reduce_sum_f32(self, off, count):
         self.dist.all_reduce(self.view(off, 4 * count, torch.float32), op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_to_all(self, send_off, recv_off, nbytes):
+        send = self.view(send_off, nbytes * self.world)
+        recv = self.view(recv_off, nbytes * self.world)
+        try:
+            self.dist.all_to_all_single(recv, send, group=self.group)      # RCCL: every peer pair over its own xGMI link
+        except (RuntimeError, NotImplementedError):        # backends without it (gloo on some builds): pairwise exchange
+            d, ops = self.dist, []
+            recv[self.rank * nbytes:(self.rank + 1) * nbytes].copy_(send[self.rank * nbytes:(self.rank + 1) * nbytes])
+            for r in range(self.world):
+                if r != self.rank:
+                    ops += [d.P2POp(d.isend, send[r * nbytes:(r + 1) * nbytes], self._peer(r), self.group),
+                            d.P2POp(d.irecv, recv[r * nbytes:(r + 1) * nbytes], self._peer(r), self.group)]
+            for req in d.batch_isend_irecv(ops):
+                req.wait()
 
     def halo_exchange(self, sp, sn, rp, rn, nbytes):
         d, ops = self.dist, []
@@ -165,6 +199,12 @@ class LoopbackTransport(ClipTransport):
             self._tmp = sum(parts[1:], parts[0])
         self._rendezvous(copy)
         self.view(off, 4 * count, torch.float32).copy_(self._tmp)      # after the second barrier: every rank has read the inputs
+
+    def all_to_all(self, send_off, recv_off, nbytes):
+        def copy():
+            for r, p in enumerate(self.lw.peers):
+                self.view(recv_off + r * nbytes, nbytes).copy_(p.view(send_off + self.rank * nbytes, nbytes))
+        self._rendezvous(copy)
 
     def halo_exchange(self, sp, sn, rp, rn, nbytes):
         def copy():

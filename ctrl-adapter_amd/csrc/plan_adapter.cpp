@@ -342,6 +342,60 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
     return 0;
 }
 
+// The temporal transformer of a frame-sharded clip, all-to-all form: everything inside the block is per
+// pixel, so the ranks swap their frame shards [(b f_local) L][512] for pixel shards [(b F) L/G][512] (one all_to_all of the
+// fp32 token stream), run the UNSHARDED block on their pixels -- all frames present, no exchange inside -- and swap the
+// fp16 result back.  A rank sends and receives (G-1)/G x (4 + 2) x 512 B per token instead of RECEIVING G x 2C x 2 B per
+// token in the K|V all_gather form (C = 320 .. 1280): 4x .. 27x fewer bytes at G = 8.  The AlphaBlender of the block's
+// output with the spatial branch (:282) is applied after the way back (op_blend).
+bool clip_a2a_enabled() {
+    static const bool on = [] { const char* e = getenv("CTRL_CLIP_A2A"); return !(e && e[0] == '0'); }();
+    return on;
+}
+int run_temporal_tb_pixel_sharded(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, const AFwd& a, int L,
+                                  const float* blend_mix, const TV& blend_other, const float* ov) {
+    const size_t mk = cx.mark();
+    const int G = a.comm->world, B = a.B, Fl = a.F, Fg = a.Fg, Lp = L / G, dim = w.dim;
+    const size_t esz = X.dt == DT_F32 ? 4 : 2;
+    const size_t row_in = (size_t)Lp * dim * esz, row_out = (size_t)Lp * dim * sizeof(half_t);
+    const size_t blk_in = al256((size_t)B * Fl * row_in), blk_out = al256((size_t)B * Fl * row_out);
+    ws_need(a, 2 * (size_t)G * blk_in);
+    char* ws = cx.dry ? nullptr : (char*)a.comm->ws;
+    const int Mp = B * Fg * Lp;                       // rows of the pixel shard: all frames of every clip, L/G pixels
+    void* xp = cx.alloc((size_t)Mp * dim * esz);
+    half_t* yp = cx.h((size_t)Mp * dim);
+    half_t* y = blend_mix ? cx.h((size_t)B * Fl * L * dim) : out.m16;
+    CTRL_CHECK(cx.dry || y != nullptr, "clip-sharded temporal transformer: the output needs an fp16 tensor");
+    if (!cx.dry) {
+        // frame shard -> G pixel-shard blocks: block r = pixels [r*Lp, (r+1)*Lp) of every local (clip, frame) row
+        for (int r = 0; r < G; ++r)
+            HIP_TRY(hipMemcpy2DAsync(ws + (size_t)r * blk_in, row_in, (const char*)X.p + (size_t)r * row_in, (size_t)L * dim * esz,
+                                     row_in, (size_t)B * Fl, hipMemcpyDeviceToDevice, cx.s));
+        COMM_TRY(a.comm->all_to_all(a.comm->user, 0, (int64_t)((size_t)G * blk_in), (int64_t)blk_in, cx.s));
+        // block r of the receive area = rank r's frames [r*Fl, (r+1)*Fl) of my pixels: -> [(b F) Lp][dim]
+        for (int r = 0; r < G; ++r)
+            HIP_TRY(hipMemcpy2DAsync((char*)xp + (size_t)r * Fl * row_in, (size_t)Fg * row_in, ws + (size_t)(G + r) * blk_in,
+                                     (size_t)Fl * row_in, (size_t)Fl * row_in, (size_t)B, hipMemcpyDeviceToDevice, cx.s));
+    }
+    AFwd a2 = a;
+    a2.comm = nullptr; a2.F = Fg; a2.N = B * Fg;
+    TV Xp; Xp.p = xp; Xp.dt = X.dt; Xp.m16 = X.dt == DT_F16 ? (half_t*)xp : nullptr;
+    TRY(run_temporal_tb(cx, w, Xp, tv16(yp), a2, Lp, nullptr, TV(), ov));
+    if (!cx.dry) {
+        for (int r = 0; r < G; ++r)       // block r = frames [r*Fl, (r+1)*Fl) of my pixel shard, for rank r
+            HIP_TRY(hipMemcpy2DAsync(ws + (size_t)r * blk_out, (size_t)Fl * row_out, (const char*)yp + (size_t)r * Fl * row_out,
+                                     (size_t)Fg * row_out, (size_t)Fl * row_out, (size_t)B, hipMemcpyDeviceToDevice, cx.s));
+        COMM_TRY(a.comm->all_to_all(a.comm->user, 0, (int64_t)((size_t)G * blk_out), (int64_t)blk_out, cx.s));
+        for (int r = 0; r < G; ++r)       // block r of the receive area = rank r's pixels of my frames
+            HIP_TRY(hipMemcpy2DAsync((char*)y + (size_t)r * row_out, (size_t)L * dim * sizeof(half_t), ws + (size_t)(G + r) * blk_out,
+                                     row_out, row_out, (size_t)B * Fl, hipMemcpyDeviceToDevice, cx.s));
+    }
+    if (blend_mix)      // AlphaBlender: a * spatial + (1 - a) * temporal
+        RUN(cx, op_blend(blend_other.p, blend_other.dt, y, DT_F16, blend_mix, out.p, out.dt, (size_t)B * Fl * L * dim, cx.s));
+    cx.release(mk);
+    return 0;
+}
+
 // one AdapterSpatioTemporal block: in NCHW [N][C][h][w] (in_dt) -> out NCHW [N][C][h*up][w*up] (out_dt)
 int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, const AFwd& a, const BlockPre& pre,
               const void* in, void* out, int h, int w) {
@@ -406,15 +460,19 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             if (tt) {
                 TV t3 = stream_alloc(cx, (size_t)M * INNER, false);
                 RUN(cx, op_add_rowvec(tok.p, tok.dt, femb, INNER, t3.p, t3.dt, (size_t)M, INNER, Lt, a.F, cx.s));
+                // frame-sharded clip: pixel shards around the temporal block when the transport can and the pixels divide
+                const bool a2a = a.comm && a.comm->all_to_all && clip_a2a_enabled() && (Lt % a.comm->world == 0);
                 if (st) {
                     // AlphaBlender (:282) folded into the temporal block's last GEMM; the blended tokens are consumed
                     // only as proj_out's operand: fp16
                     TV t5 = tv16(cx.h((size_t)M * INNER));
-                    TRY(run_temporal_tb(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix, pre.ttb_ov[i]));
+                    if (a2a) TRY(run_temporal_tb_pixel_sharded(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix, pre.ttb_ov[i]));
+                    else TRY(run_temporal_tb(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix, pre.ttb_ov[i]));
                     tok = t5;
                 } else {
                     TV t4 = stream_alloc(cx, (size_t)M * INNER, true);
-                    TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV(), pre.ttb_ov[i]));
+                    if (a2a) TRY(run_temporal_tb_pixel_sharded(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV(), pre.ttb_ov[i]));
+                    else TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV(), pre.ttb_ov[i]));
                     tok = t4;
                 }
             }

@@ -288,7 +288,9 @@ int ctrl_adapter_text_cache(ctrl_adapter* h, int mode);
  * owns frames [r*Fl, (r+1)*Fl) of each clip), num_frames = Fl.  All ops of the adapter are per frame except three, and
  * each of those does exactly one exchange through the caller-supplied transport (stream-ordered on `stream`; byte
  * offsets into the exchange workspace `ws`, which the caller registered with its transport):
- *   temporal attention  (model/adapter_spatial_temporal.py:280)  all_gather of the K|V rows over the frame axis
+ *   temporal transformer (model/adapter_spatial_temporal.py:280) all_to_all: frame shards <-> pixel shards around the block
+ *                       (everything inside it is per pixel), or -- when the transport has no all_to_all or the
+ *                       pixels do not divide by the ranks -- all_gather of the K|V rows over the frame axis
  *   Conv3d (3,1,1)      (TemporalResnetBlock, :226)              halo_exchange of the first / last local frame
  *   temporal GroupNorm  (TemporalResnetBlock, :226)              all_reduce_sum_f32 of the (clip, group) sums
  * The transports used are torch.distributed over RCCL (ctrl-adapter_amd/clip_parallel.py); any transport with these
@@ -307,6 +309,11 @@ typedef struct ctrl_clip_comm {
                          int64_t bytes, void* stream);
     void* user;
     int64_t ws_needed;
+    /* optional (NULL: the K|V all_gather form is used): recv[r*bytes .. (r+1)*bytes) = rank r's send[me*bytes .. (me+1)*bytes),
+       i.e. block r of my send area goes to rank r.  Swaps frame shards for pixel shards around the temporal transformer:
+       2 + 1 KB per token and direction instead of the 2*C*2 B x world a rank RECEIVES per token in the all_gather form
+        */
+    int (*all_to_all)(void* user, int64_t send_off, int64_t recv_off, int64_t bytes_per_rank, void* stream);
 } ctrl_clip_comm;
 int ctrl_adapter_forward_clip_sharded(ctrl_adapter* h,
                                       const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,

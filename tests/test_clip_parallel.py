@@ -48,6 +48,15 @@ WORKER = textwrap.dedent("""
     else:
         assert t.view(2 * blk, blk).eq(200).all()           # rank 0's last frame
         assert t.view(3 * blk, blk).eq(7).all()
+    # all-to-all (frame shards <-> pixel shards): block r of my send area -> rank r; block r of my recv area <- rank r
+    t.view(0, 2 * blk).copy_(torch.cat([torch.full((blk,), 30 + 10 * rank + r, dtype=torch.uint8) for r in range(2)]))
+    assert cs.all_to_all(None, 0, 4 * blk, blk, None) == 0
+    got = t.view(4 * blk, 2 * blk)
+    assert got[:blk].eq(30 + rank).all() and got[blk:].eq(40 + rank).all()
+    t.use_all_to_all = False
+    assert not t.c_struct().all_to_all                        # NULL pointer: the native side falls back to the K|V all-gather
+    t.use_all_to_all = True
+    assert t.bytes_sent > 0
     # a failing exchange is reported, never swallowed
     assert cs.all_gather(None, 0, 0, 1 << 40, None) == 1 and t.error is not None
     x = torch.arange(2 * 4 * 3).reshape(8, 3)                # 2 clips x 4 frames
@@ -92,9 +101,14 @@ def test_loopback_transport_and_frame_sharding():
         s = t.view(0, 4 * 8, torch.float32).clone()
         t.view(1024, 8).fill_(50 + r); t.view(1032, 8).fill_(60 + r); t.view(1040, 16).fill_(0)
         t.halo_exchange(1024, 1032, 1040, 1048, 8)
-        return g, s, t.view(1040, 16).clone()
+        h = t.view(1040, 16).clone()
+        for k in range(W):
+            t.view(2048 + 8 * k, 8).fill_(10 * r + k)           # block k of my send area goes to rank k
+        t.all_to_all(2048, 4096, 8)
+        return g, s, h, t.view(4096, 8 * W).clone()
     res = run_virtual_ranks(W, body)
-    for r, (g, s, h) in enumerate(res):
+    for r, (g, s, h, a2a) in enumerate(res):
+        assert all(a2a[8 * k:8 * (k + 1)].eq(10 * k + r).all() for k in range(W))
         assert all(g[16 * k:16 * (k + 1)].eq(k + 1).all() for k in range(W))
         assert s.eq(0.0 + 1 + 2 + 3).all()
         assert h[:8].eq(60 + r - 1 if r > 0 else 0).all() and h[8:].eq(50 + r + 1 if r < W - 1 else 0).all()

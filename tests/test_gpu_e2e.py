@@ -429,13 +429,14 @@ def test_video_chain_at_benched_shapes_vs_oracle(P, gpu):
     assert max(e_cn) <= TOL and max(e_chain) <= TOL_CHAIN
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_clip_sharded_adapter_equals_unsharded(P, gpu, world):
+@pytest.mark.parametrize("world,a2a", [(2, True), (4, True), (2, False), (4, False)])
+def test_clip_sharded_adapter_equals_unsharded(P, gpu, world, a2a):
     """SURVEY.md 8e row 2 / BASELINE config 4 with fewer clips than GPUs: ONE clip's frames sharded over `world` ranks.
     Virtual ranks = threads of this process on one GPU (each with its own plan, stream and exchange workspace; the
     transport is clip_parallel.LoopbackTransport -- the RCCL transport runs the same native code with the same
     callbacks).  Every rank runs ctrl_adapter_forward_clip_sharded on its F / world frames of both clips; gathered, the
-    results must reproduce the unsharded forward.  The frame-mixing kernels are bit-exact given exact exchanges
+    results must reproduce the unsharded forward.  a2a: the temporal transformer swaps frame shards for pixel shards
+    (all_to_all, the default) instead of all-gathering K|V.  The frame-mixing kernels are bit-exact given exact exchanges
     (tests/test_gpu_ops.py::test_frame_sharded_temporal_ops_are_bit_exact); what differs end to end is fp32 summation order
     -- the clip-wide GroupNorm sums (per-rank partials, then ranks) and the GEMM tile / split-K configuration the smaller
     per-rank M selects (slots whose configuration does not change come out bit-identical) -- which moves isolated fp16
@@ -457,6 +458,8 @@ def test_clip_sharded_adapter_equals_unsharded(P, gpu, world):
     lw = LoopbackWorld(world, gpu)
     plans = [ad] + [seeded_init(P.ControlNetAdapter(**cfg), seed=33).to(gpu) for _ in range(world - 1)]
     comms = [lw.transport(r) for r in range(world)]
+    for c in comms:
+        c.use_all_to_all = a2a
 
     def rank_body(r):
         ins = [shard_frames(d.half().to(gpu), F_, r, world) for d in downs]
@@ -467,12 +470,14 @@ def test_clip_sharded_adapter_equals_unsharded(P, gpu, world):
     got = [unshard_frames([res[r][0][i] for r in range(world)], F_) for i in range(12)]
     got_mid = unshard_frames([res[r][1] for r in range(world)], F_)
     errs = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ref) + [ref_mid])]
-    print("PARITY clip-sharded (%d ranks x %d frames) vs unsharded rel_inf: %s" % (world, F_ // world, " ".join("%.1e" % e for e in errs)))
+    form = "all-to-all" if a2a else "K|V all-gather"
+    print("PARITY clip-sharded (%d ranks x %d frames, %s, %.1f MB sent per rank) vs unsharded rel_inf: %s" %
+          (world, F_ // world, form, comms[0].bytes_sent / 1e6, " ".join("%.1e" % e for e in errs)))
     assert max(errs) <= 5e-4
     oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=33)
     ro, rom = oa(downs, mid_block_res_sample=mid, num_frames=F_, timestep=t, encoder_hidden_states=e_img)
     eo = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ro) + [rom])]
-    print("PARITY clip-sharded (%d ranks) vs oracle rel_inf: %s" % (world, " ".join("%.2e" % e for e in eo)))
+    print("PARITY clip-sharded (%d ranks, %s) vs oracle rel_inf: %s" % (world, form, " ".join("%.2e" % e for e in eo)))
     assert max(eo) <= TOL_ADAPTER
 
 
@@ -723,3 +728,48 @@ def test_checkpoint_to_forward_on_gpu(P, gpu, tmp_path, ckpt_dtype):
         e32 = [rel_inf(a, b) for a, b in zip(list(d32) + [m32] + list(o32[:9]), list(rd) + [rm] + list(ro[:9]))]
         print("PARITY checkpoint(bfloat16) -> forward, fp32 boundary tensors: max %.2e" % max(e32))
         assert max(e32) <= 1e-3
+
+
+def test_clip_sharded_adapter_over_rccl_world1(P, gpu):
+    """The production transport of the clip split, clip_parallel.TorchDistTransport over torch.distributed backend "nccl"
+    (= RCCL), executed for real: a one-rank process group on this GPU (the test box has one; with two visible GPUs
+    tests/test_dist.py-style workers would add nothing the 2-rank gloo + virtual-rank tests do not cover).  Every exchange of
+    the sharded forward -- all_to_all around the temporal transformers, the Conv3d halo (no neighbours), the GroupNorm
+    all_reduce -- goes through RCCL on the forward's stream; the result must reproduce the unsharded forward."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from ctrl_adapter_amd.clip_parallel import TorchDistTransport
+    torch.set_grad_enabled(False)
+    F_, clips = 4, 2
+    N = F_ * clips
+    cfg = dict(cases.ADAPTER_VIDEO, num_frames=F_)
+    downs, mid = cases.pyramid_inputs(N=N, h0=8, seed=1400, with_mid=True)
+    e_img = seeded_tensor((1, 1, 1024), 1401)
+    t = torch.full((N,), 961.0)
+    ad = seeded_init(P.ControlNetAdapter(**cfg), seed=33).to(gpu)
+    kw = dict(encoder_hidden_states=e_img.half().to(gpu), out_dtype=torch.float32)
+    ins = [d.half().to(gpu) for d in downs]
+    ref, ref_mid = ad(ins, mid_block_res_sample=mid.half().to(gpu), num_frames=F_, timestep=t.to(gpu), **kw)
+    own = not dist.is_initialized()
+    if own:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        for a2a in (True, False):
+            comm = TorchDistTransport()
+            assert (comm.rank, comm.world) == (0, 1) and comm.ws.is_cuda
+            comm.use_all_to_all = a2a
+            side = torch.cuda.Stream()          # not torch's current stream when the callbacks fire: the transport must follow it
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                got, got_mid = ad(ins, mid_block_res_sample=mid.half().to(gpu), num_frames=F_, timestep=t.to(gpu), clip_comm=comm, **kw)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            errs = [rel_inf(a, b) for a, b in zip(list(got) + [got_mid], list(ref) + [ref_mid])]
+            print("PARITY clip-sharded over RCCL (world 1, %s) vs unsharded rel_inf max %.1e" % ("all-to-all" if a2a else "all-gather", max(errs)))
+            assert max(errs) <= 5e-4 and comm.bytes_sent >= 0
+    finally:
+        if own:
+            dist.destroy_process_group()
