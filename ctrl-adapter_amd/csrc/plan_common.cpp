@@ -78,7 +78,7 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
     const int k = c.taps == 9 ? 3 : 1, pad = c.taps == 9 ? 1 : 0;
     const int Hout = (Hin * o.up + 2 * pad - k) / o.stride + 1, Wout = (Win * o.up + 2 * pad - k) / o.stride + 1;
     IGemmArgs g = {};
-    g.A = x; g.lda = c.Cin; g.mode = IG_CONV2D; g.Cin = c.Cin; g.taps = c.taps;
+    g.A = x; g.lda = o.lda ? o.lda : c.Cin; g.mode = IG_CONV2D; g.Cin = c.Cin; g.taps = c.taps;
     g.Hin = Hin; g.Win = Win; g.Hout = Hout; g.Wout = Wout; g.stride = o.stride; g.up = o.up;
     g.W = c.w; g.M = N * Hout * Wout; g.Nout = c.Cout; g.Ktot = c.taps * c.Cin;
     g.bias = c.b; g.rowvec = o.rowvec; g.rowvec_ld = o.rowvec_ld; g.rows_per_img = Hout * Wout;
@@ -140,9 +140,10 @@ int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int
     TV sc = x;
     if (w.has_shortcut) {
         CTRL_CHECK(cx.dry || x.m16 != nullptr, "resnet: the shortcut conv needs an fp16 copy of its input");
-        CTRL_CHECK((x.lo_off > 0) == w.shortcut.dup, "resnet: split-operand shortcut conv and its input mirror disagree");
+        CTRL_CHECK(x.lo_off > 0 || !w.shortcut.dup, "resnet: a split-operand shortcut conv needs a split [hi | lo] input mirror");
         TV s2 = stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
         ConvOpts os; os.up = up;
+        if (x.lo_off > 0 && !w.shortcut.dup) os.lda = 2 * w.Cin;      // plain conv on a split mirror: the hi half of every row
         TRY(run_conv(cx, w.shortcut, x.m16, s2, N, H, W, os));
         sc = s2;
     }

@@ -426,6 +426,7 @@ int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int 
 // 3x3 / 1x1 conv through the implicit GEMM, NHWC fp16 operand -> NHWC stream tensor
 struct ConvOpts {
     int stride = 1, up = 1;
+    long lda = 0;              // row stride of the operand (0 = the conv's Cin); 2*C: a plain conv reading the hi half of split rows
     const float* rowvec = nullptr; int rowvec_ld = 0;
     TV res;
     int act = 0;

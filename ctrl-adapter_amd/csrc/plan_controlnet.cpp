@@ -48,6 +48,16 @@ bool cn_split_enabled() {
     const char* e = getenv("CTRL_CN_SPLIT");
     return !(e && e[0] == '0') && stream_f32_enabled();
 }
+// How deep the split goes (CTRL_CN_SPLIT_LEVELS, default 2): down blocks 0 .. levels-1 take split operands (mid block =
+// level 4); the 13 zero-convs always do.  Round 3, tools/experiments/fp16_error_budget.py with the rounding points of this
+// selection: exact operands in blocks 0-1 + every zero-conv keep the ControlNet outputs at 6.9e-4 / the chain at 7.5e-4
+// (all convolutions exact: 5.7e-4 / 7.7e-4; none: 1.12e-3 / 1.06e-3) -- the 16x16 / 8x8 levels are where a split conv
+// costs most (small M, split-K, 0.07-0.19 of the MFMA peak) and adds least.
+int cn_split_levels() {
+    const char* e = getenv("CTRL_CN_SPLIT_LEVELS");
+    const int v = e ? atoi(e) : 2;
+    return v < 0 ? 0 : (v > 5 ? 5 : v);
+}
 // CTRL_CN_SPLIT=dup: the first form of the split (weights packed twice, [hi | lo] walked as one long K) for A/B runs
 bool cn_split_paired() {
     const char* e = getenv("CTRL_CN_SPLIT");
@@ -113,8 +123,9 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
 
     std::vector<std::string> temb_names;
     std::vector<int> temb_ns;
-    auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r) -> int {
-        TRY(build_resnet(ps, pre, Cin, Cout, false, r, dup));
+    const int levels = cn_split_levels();
+    auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r, bool dup_r) -> int {
+        TRY(build_resnet(ps, pre, Cin, Cout, false, r, dup_r));
         r->temb_off = w->temb_total;
         w->temb_total += Cout;
         temb_names.push_back(pre + ".time_emb_proj");
@@ -132,18 +143,20 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
         d.resnets.resize(c.layers_per_block);
         if (d.has_attn) { d.tnorm.resize(c.layers_per_block); d.proj_in.resize(c.layers_per_block);
                           d.proj_out.resize(c.layers_per_block); d.tb.resize(c.layers_per_block); }
+        const bool dup_i = dup && i < levels;
         for (int j = 0; j < c.layers_per_block; ++j) {
-            TRY(add_resnet(pre + ".resnets." + std::to_string(j), j == 0 ? d.Cin : d.Cout, d.Cout, &d.resnets[j]));
+            TRY(add_resnet(pre + ".resnets." + std::to_string(j), j == 0 ? d.Cin : d.Cout, d.Cout, &d.resnets[j], dup_i));
             if (d.has_attn)
                 TRY(build_transformer2d(ps, pre + ".attentions." + std::to_string(j), d.Cout, c.num_attention_heads,
-                                        c.cross_attention_dim, &d.tnorm[j], &d.proj_in[j], &d.proj_out[j], &d.tb[j], dup));
+                                        c.cross_attention_dim, &d.tnorm[j], &d.proj_in[j], &d.proj_out[j], &d.tb[j], dup_i));
         }
-        if (d.has_down) TRY(ps.conv(pre + ".downsamplers.0.conv", d.Cout, d.Cout, 3, false, &d.down, dup));
+        if (d.has_down) TRY(ps.conv(pre + ".downsamplers.0.conv", d.Cout, d.Cout, 3, false, &d.down, dup_i));
     }
-    TRY(add_resnet("mid_block.resnets.0", out_c, out_c, &w->mid_r0));
+    const bool dup_mid = dup && levels > 4;
+    TRY(add_resnet("mid_block.resnets.0", out_c, out_c, &w->mid_r0, dup_mid));
     TRY(build_transformer2d(ps, "mid_block.attentions.0", out_c, c.num_attention_heads, c.cross_attention_dim,
-                            &w->mid_tnorm, &w->mid_pin, &w->mid_pout, &w->mid_tb, dup));
-    TRY(add_resnet("mid_block.resnets.1", out_c, out_c, &w->mid_r1));
+                            &w->mid_tnorm, &w->mid_pin, &w->mid_pout, &w->mid_tb, dup_mid));
+    TRY(add_resnet("mid_block.resnets.1", out_c, out_c, &w->mid_r1, dup_mid));
     TRY(ps.linear_cat(temb_names, temb_ns, temb_dim, true, &w->temb_cat));
 
     // zero convs: slot channels follow the residual list (controlnet/controlnet.py:360-408)
@@ -230,7 +243,8 @@ int run_transformer2d(Ctx& cx, const Norm& tn, const ConvW& pin, const ConvW& po
     TV t0 = stream_alloc(cx, (size_t)M * C, false);
     ConvOpts o;
     TRY(run_conv(cx, pin, n, t0, N, H, W, o));
-    TV t1 = stream_alloc_rc(cx, (size_t)M, C, true);    // its fp16 mirror is proj_out's operand
+    // its fp16 mirror is proj_out's operand: [hi | lo] rows only when that conv takes split operands
+    TV t1 = pout.dup ? stream_alloc_rc(cx, (size_t)M, C, true) : stream_alloc(cx, (size_t)M * C, true);
     TRY(run_basic_tb(cx, tb, t0, t1, N, H * W, e, nullptr, kv));
     ConvOpts oo; oo.res = x;
     TRY(run_conv(cx, pout, t1.m16, out, N, H, W, oo));
@@ -378,6 +392,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
             const int ho = (h - 1) / 2 + 1, wo = (wd - 1) / 2 + 1;
             TV y = stream_alloc_rc(cx, (size_t)N * ho * wo, d.Cout, true);
             ConvOpts o; o.stride = 2;
+            if (cur.lo_off > 0 && !d.down.dup) o.lda = 2 * d.Cout;      // plain conv on a split mirror: the hi half of every row
             TRY(run_conv(cx, d.down, cur.m16, y, N, h, wd, o));
             cur = y; h = ho; wd = wo;
             TRY(emit(cur, h, wd));

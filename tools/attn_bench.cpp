@@ -6,7 +6,8 @@
 //
 //   build:  hipcc -O2 -std=c++17 -Iinclude tools/attn_bench.cpp -o tools/bin/attn_bench -Lctrl-adapter_amd -lctrlhip \
 //                 -Wl,-rpath,'$ORIGIN/../../ctrl-adapter_amd'
-//   run:    tools/bin/attn_bench [out.txt [v1,v2,...]]          (on the GPU box, from the repo root)
+//   run:    tools/bin/attn_bench [out.txt [v1,v2,... [nshapes]]]   (on the GPU box, from the repo root; nshapes = 1: only the
+//           L = 16384 shape, e.g. under rocprofv3 --pmc -- tools/attn_pmc.sh)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -92,7 +93,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const Shape shapes[] = {{8, 5, 16384}, {8, 10, 4096}, {8, 5, 4096}};
+    const Shape all_shapes[] = {{8, 5, 16384}, {8, 10, 4096}, {8, 5, 4096}};
+    const int nshapes = argc > 3 ? std::max(1, std::min(3, atoi(argv[3]))) : 3;
+    const std::vector<Shape> shapes(all_shapes, all_shapes + nshapes);
     const float kscale = 1.4426950408889634f / 8.0f;     // softmax_scale * log2(e) for head_dim 64, folded into K
     for (const Shape& sh : shapes) {
         const int C = sh.heads * 64, L = sh.L, B = sh.B;
