@@ -44,7 +44,10 @@ template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (NW
 // (A persistent-workgroup form -- one workgroup per CU walking its tiles with one LDS ring running across them -- was built
 // in round 2 and measured again at the start of round 3 after the epilogue fetch hoisting: 0.72-1.03x the one-tile form on
 // every shape of the path, profiles/r03_gemm_persistent_form.txt.  It is gone from the product.)
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
+// GN: the epilogue also writes the per-slab column sums of the finished output (ctrl_igemm_desc::gn_part).  A template
+// argument, not a run-time branch: the extra live state costs the 128-register two-workgroup tiles a few epilogue spills,
+// which the plain instantiations (everything that does not feed a GroupNorm) must not pay.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP, bool GN = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk, int order) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
@@ -445,20 +448,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                             }
                         }
                     }
-                    // Fused LayerNorm (full-row tile only, BN == Nout == 512 = the adapter's token width): the finished fp32 rows
-                    // -- what the stand-alone layernorm_kernel would re-read from HBM -- stay in registers (the accumulators of a
-                    // slab are dead once it is staged, its finished pieces take their place), per-row (sum, sum of squares)
-                    // partials are reduced inside the 16 lanes that share a row (DPP, fixed order), exchanged between the
-                    // WAVES_N waves of a row through LDS, and the normalised fp16 rows are written next to the fp32 master.
-                    constexpr bool LNT = (BN == 512 && WN == 128);
-                    constexpr int LNM = LNT ? MI : 1, LNR = LNT ? RT : 1;
-                    float ln_x[LNM][LNR][8];
-                    float ln_s[LNM][LNR], ln_q[LNM][LNR];
-#pragma unroll
-                    for (int i = 0; i < LNM; ++i)
-#pragma unroll
-                        for (int j = 0; j < LNR; ++j) { ln_s[i][j] = 0.f; ln_q[i][j] = 0.f; }
-                    const bool do_ln = LNT && e.ln_out != nullptr;
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
                         const int row_w = m0 + wm * WM + mi * 16 + erow;
@@ -492,7 +481,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                             const int r = idx / OWC, c8 = idx - r * OWC;
                             const int row = m0 + wm * WM + mi * 16 + r;
                             const int ocol = wcol0 + c8 * 8;
-                            if (row >= e.M || ocol >= nout_eff) continue;
+                            if (row >= e.M || ocol >= nout_eff) {
+                                if constexpr (GN) {       // rows / columns past the problem contribute zeros to the column sums
+                                    *(f4*)(stg + r * SLD + c8 * 8) = f4{0.f, 0.f, 0.f, 0.f};
+                                    *(f4*)(stg + r * SLD + c8 * 8 + 4) = f4{0.f, 0.f, 0.f, 0.f};
+                                }
+                                continue;
+                            }
                             const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
                             float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                             if (Rptr) {
@@ -540,23 +535,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
                             }
-                            if constexpr (LNT) {
-                                if (do_ln) {
-                                    float sx = 0.f, sq = 0.f;
-#pragma unroll
-                                    for (int i = 0; i < 8; ++i) { sx += x[i]; sq += x[i] * x[i]; ln_x[mi][t][i] = x[i]; }
-                                    // the 16 lanes of a DPP row hold the 128 columns of one output row (r = idx / 16): xor 1, xor 2,
-                                    // half-row mirror, row mirror -- every lane ends with the wave's partial of its row
-                                    sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0xB1, 0xF, 0xF, true));
-                                    sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0xB1, 0xF, 0xF, true));
-                                    sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x4E, 0xF, 0xF, true));
-                                    sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x4E, 0xF, 0xF, true));
-                                    sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x141, 0xF, 0xF, true));
-                                    sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x141, 0xF, 0xF, true));
-                                    sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x140, 0xF, 0xF, true));
-                                    sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x140, 0xF, 0xF, true));
-                                    ln_s[mi][t] = sx; ln_q[mi][t] = sq;
-                                }
+                            if constexpr (GN) {     // GroupNorm statistics of the output: the FINISHED values go back into the slab
+                                *(f4*)(stg + r * SLD + c8 * 8) = f4{x[0], x[1], x[2], x[3]};
+                                *(f4*)(stg + r * SLD + c8 * 8 + 4) = f4{x[4], x[5], x[6], x[7]};
                             }
                             if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
                                 h8 pk;
@@ -596,48 +577,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                                 *(us8*)((u16*)sg_out + o) = pk;
                             }
                         }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
-                    }
-                    if constexpr (LNT) {
-                        if (do_ln) {       // workgroup-uniform: every wave takes the barrier
-                            // partials [wm][wn][row of the wave tile] behind the staging areas (the ring is dead)
-                            f2* part = (f2*)(epi_smem + (size_t)NW * 16 * SLD * sizeof(float));
-                            const int lrow = lane >> 4, c8l = lane & 15;
-#pragma unroll
-                            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                                for (int t = 0; t < RT; ++t)
-                                    if (c8l == 0) part[(wm * WAVES_N + wn) * WM + mi * 16 + lrow + 4 * t] = f2{ln_s[mi][t], ln_q[mi][t]};
+                        if constexpr (GN) {
+                            // per-column (sum, sum of squares) of this 16-row slab, straight from LDS (a lane owns a column: 16
+                            // conflict-free reads), written as one partial row: gn_part[slab][column][2].  The consumer adds the
+                            // slabs of an image and the channels of a group in a fixed order (gn_finalize_kernel) -- the
+                            // statistics pass over the whole map (gn_stats_kernel) is gone
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_s_barrier();
-                            const int ocol = wcol0 + c8l * 8;
-                            const f4 g0 = *(const f4*)(e.ln_gamma + ocol), g1 = *(const f4*)(e.ln_gamma + ocol + 4);
-                            const f4 b0 = *(const f4*)(e.ln_beta + ocol), b1 = *(const f4*)(e.ln_beta + ocol + 4);
-                            const float gam[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                            const float bet[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                            const int slab_row0 = m0 + wm * WM + mi * 16;
+                            if (slab_row0 < e.M) {
 #pragma unroll
-                            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                                for (int t = 0; t < RT; ++t) {
-                                    const int rl = mi * 16 + lrow + 4 * t;
-                                    const int row = m0 + wm * WM + rl;
-                                    float sx = 0.f, sq = 0.f;
-#pragma unroll
-                                    for (int w2 = 0; w2 < WAVES_N; ++w2) {       // fixed order over the waves of the row
-                                        const f2 pv = part[(wm * WAVES_N + w2) * WM + rl];
-                                        sx += pv[0]; sq += pv[1];
-                                    }
-                                    const float mean = sx * (1.0f / BN);
-                                    const float var = fmaxf(sq * (1.0f / BN) - mean * mean, 0.f);
-                                    const float rstd = rsqrtf(var + e.ln_eps);
-                                    if (row < e.M) {
-                                        h8 pk;
-#pragma unroll
-                                        for (int i = 0; i < 8; ++i) pk[i] = (half_t)((ln_x[mi][t][i] - mean) * rstd * gam[i] + bet[i]);
-                                        *(h8*)((half_t*)e.ln_out + (size_t)row * e.ln_ld + ocol) = pk;
+                                for (int cp = 0; cp < (WN + 63) / 64; ++cp) {
+                                    const int cc = lane + 64 * cp;
+                                    if (cc < OW && wcol0 + cc < nout_eff) {
+                                        float sx = 0.f, sq = 0.f;
+#pragma unroll 4
+                                        for (int rr = 0; rr < 16; ++rr) { const float v = stg[rr * SLD + cc]; sx += v; sq += v * v; }
+                                        *(f2*)(e.gn_part + ((size_t)(slab_row0 >> 4) * nout_eff + wcol0 + cc) * 2) = f2{sx, sq};
                                     }
                                 }
+                            }
                         }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
                     }
                 }
             } else {
@@ -836,8 +796,8 @@ int plan_order(const IGemmArgs& a, int BM, int BN, int ntm, int ntn) {
     return G < ntn ? tileorder::make_order(tileorder::ORDER_XCD_M, G) : 0;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
-int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP, bool GN>
+int launch_cfg3(const IGemmArgs& a, hipStream_t s, int splitk) {
     constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
     constexpr int BNP = (BN + PASSROWS - 1) / PASSROWS * PASSROWS;
     constexpr size_t ring = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
@@ -847,7 +807,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     static bool attr_done[kMaxDevices] = {};       // function attributes are per device
     const int dev = cur_device();
     if (!attr_done[dev]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>,
+        HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP, GN>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done[dev] = true;
     }
@@ -860,7 +820,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
-    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
+    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false", GN ? "true" : "false"); };
     if (splitk > 1) {
         // partial sums go to fp32 slabs [splitk][M][Nout]; every epilogue term is applied once, by the finish kernel
         IGemmArgs p = a;
@@ -870,7 +830,7 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
         prof_detail("M%d N%d K%d taps%d%s splitk%d", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
         sym();
-        LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn * splitk),
+        LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP, GN>), dim3(ntm * ntn * splitk),
                dim3(WAVES_M * WAVES_N * 64), smem, s, p, ntm, ntn, zeros, splitk, order);
         const size_t total = (size_t)a.M * (a.Nout / 8);
         size_t blocks = (total + 255) / 256;
@@ -881,9 +841,17 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         return 0;
     }
     sym();
-    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
+    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP, GN>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
            a, ntm, ntn, zeros, 1, order);
     return 0;
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
+int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
+    if constexpr (SWAP) {
+        if (a.gn_part && splitk <= 1) return launch_cfg3<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, true, true>(a, s, splitk);
+    }
+    return launch_cfg3<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP, false>(a, s, splitk);
 }
 
 // Aligned row-major outputs and single aligned transposed (NCHW / V^T) outputs use the swapped-operand kernel (LDS-staged
@@ -923,17 +891,10 @@ void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, 
     tileorder::tile_of(bid, ntm, ntn, tileorder::make_order(mode, group), tile_m, tile_n);
 }
 
-// can the LayerNorm of this GEMM's output rows ride on its epilogue (ctrl_igemm_desc::ln_out)?  `a` without the ln_* fields set
-// describes the producer; the full-row tile exists for Nout == 512 (the adapter's token width, INNER)
-bool igemm_ln_fusable(const IGemmArgs& a) {
-    if (a.mode != IG_ROWS || a.Nout != 512 || a.geglu || a.nseg != 1 || a.seg[0].fmt != SEG_ROW || a.splitk_ws || a.a_split) return false;
-    if (a.scale2_from) return false;
-    if (!can_swap(a)) return false;
-    if (a.ln_out) {
-        if (!a.ln_gamma || !a.ln_beta || a.ln_ld % 8 != 0) return false;
-        if ((((uintptr_t)a.ln_out | (uintptr_t)a.ln_gamma | (uintptr_t)a.ln_beta) & 15) != 0) return false;
-    }
-    return true;
+// can the per-slab column sums of this GEMM's output (ctrl_igemm_desc::gn_part) be produced by its epilogue?  Needs the
+// row-layout vector epilogue and no split-K (`splitk` = what the caller will run with)
+bool igemm_gn_fusable(const IGemmArgs& a, int splitk) {
+    return splitk <= 1 && !a.geglu && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a);
 }
 
 int igemm_splitk_factor(const IGemmArgs& a) {
@@ -973,8 +934,6 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
             return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
         }
     }
-    // fused LayerNorm of the finished rows: the full-row tile (128 x 512, 64 x 128 per wave)
-    if (a.ln_out) return launch_cfg2<128, 512, 32, 2, 4, 3, MODE, true>(a, s);
     if (const char* f = getenv("CTRL_IGEMM_FORCE")) {      // tile experiments (tools/tile_experiment.py), row outputs only
         if (can_swap(a) && MODE == IG_ROWS) {
             if (!strcmp(f, "128x256")) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
@@ -1023,8 +982,8 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(!a.out16 || (a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a)), "igemm: the fp16 mirror needs a single aligned row-major output");
     CTRL_CHECK(!a.blend_mix || (a.blend_x && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && !a.geglu && can_swap(a)),
                "igemm: the blend fold needs a single aligned row-major output and an aligned blend operand");
-    CTRL_CHECK(!a.ln_out || igemm_ln_fusable(a), "igemm: the fused LayerNorm needs a rows-mode GEMM with Nout == 512, one aligned row-major "
-                                                  "output, no GEGLU / split-K / split operand, 16-byte aligned gamma / beta / output");
+    CTRL_CHECK(!a.gn_part || (igemm_gn_fusable(a, (a.splitk_ws && can_swap(a)) ? igemm_splitk_factor(a) : 1) && (((uintptr_t)a.gn_part & 7) == 0)),
+               "igemm: the fused GroupNorm partial sums need one aligned row-major output, no GEGLU, no split-K");
     for (int i = 0; i < a.nseg; ++i) {
         CTRL_CHECK(a.seg[i].col_begin % 16 == 0, "igemm: segment boundary must be a multiple of 16");
         CTRL_CHECK(a.seg[i].out != nullptr, "igemm: null segment output");

@@ -185,15 +185,79 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// Stand-alone producer of the per-slab column sums (same layout as the GEMM epilogue's gn_part): one workgroup per 16-row slab
+// group, a thread owns 8 channels of one row, partial rows go through LDS and are added in row order.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partials_kernel(const T* __restrict__ x, float* __restrict__ part, long M, int C) {
+    extern __shared__ float sh[];            // [16][2*C]
+    const int lpr = C >> 3;                  // lanes per row
+    const int rpi = 256 / lpr;               // rows per iteration (>= 1: C <= 2048)
+    const long slab = blockIdx.x;
+    const int tid = threadIdx.x, tr = tid / lpr, tc = tid - tr * lpr;
+    for (int r0 = 0; r0 < 16; r0 += rpi) {
+        const int r = r0 + tr;
+        if (tr < rpi && r < 16) {
+            const long row = slab * 16 + r;
+            float v[8];
+            if (row < M) load8<T>(x + (size_t)row * C + tc * 8, v);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            float* dst = sh + (size_t)r * 2 * C + tc * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dst[j] = v[j]; dst[C + j] = v[j] * v[j]; }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float sx = 0.f, sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sx += sh[(size_t)r * 2 * C + c]; sq += sh[(size_t)r * 2 * C + C + c]; }
+        *(f2*)(part + ((size_t)slab * C + c) * 2) = f2{sx, sq};
+    }
+}
+
+// partial rows -> stats[img][G][2]: one workgroup per (image, group); thread t adds the entries t, t + 256, ... of the
+// group's (slab, channel) grid, then a fixed LDS tree -- the order never depends on timing
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                          int slabs_per_img, int C, int G) {
+    __shared__ float red[2][256];
+    const int img = blockIdx.x / G, g = blockIdx.x - img * G;
+    const int cg = C / G, tid = threadIdx.x;
+    const long n = (long)slabs_per_img * cg;
+    const float* base = part + ((size_t)img * slabs_per_img * C + (size_t)g * cg) * 2;
+    float sx = 0.f, sq = 0.f;
+    for (long e = tid; e < n; e += 256) {
+        const long sl = e / cg;
+        const int c = (int)(e - sl * cg);
+        const f2 v = *(const f2*)(base + ((size_t)sl * C + c) * 2);
+        sx += v[0]; sq += v[1];
+    }
+    red[0][tid] = sx; red[1][tid] = sq;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { stats[((size_t)img * G + g) * 2] = red[0][0]; stats[((size_t)img * G + g) * 2 + 1] = red[1][0]; }
+}
+
 // one wavefront per row; C <= 64*8*NCH
+// addv (optional): a per-image fp32 vector added to the row BEFORE the norm, addv[((row / rows_per_img) % vmod) * ldv + c] (the
+// frame-index embedding in front of the temporal transformer, model/adapter_spatial_temporal.py:279); the sum is also
+// written out (xsum, in x's dtype) because it is the block's residual stream -- one pass instead of add_rowvec + layernorm
 template <int NCH, typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        half_t* __restrict__ y, long ldy, int M, int C, float eps) {
+                                                        half_t* __restrict__ y, long ldy, int M, int C, float eps,
+                                                        const float* __restrict__ addv, long ldv, int rows_per_img, int vmod,
+                                                        T* __restrict__ xsum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
     const T* xp = x + (size_t)row * ldx;
+    const float* av = addv ? addv + (size_t)((row / rows_per_img) % vmod) * ldv : nullptr;
     float v[NCH][8];
     float s = 0.f;
 #pragma unroll
@@ -201,6 +265,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
         const int c0 = (lane + i * 64) * 8;
         if (c0 < C) {
             load8<T>(xp + c0, v[i]);
+            if (av) {
+                const f4 a0 = *(const f4*)(av + c0), a1 = *(const f4*)(av + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[i][j] += a0[j]; v[i][4 + j] += a1[j]; }
+                T* sp = xsum + (size_t)row * ldx + c0;
+                if constexpr (sizeof(T) == 4) {
+                    *(f4*)sp = f4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                    *(f4*)(sp + 4) = f4{v[i][4], v[i][5], v[i][6], v[i][7]};
+                } else {
+                    h8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { o[j] = (half_t)v[i][j]; v[i][j] = (float)o[j]; }     // the norm sees what is stored
+                    *(h8*)sp = o;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[i][j];
         } else {
@@ -269,6 +348,27 @@ int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per
     return 0;
 }
 
+size_t op_gn_part_floats(long M, int C) { return (size_t)((M + 15) / 16) * C * 2; }
+
+int op_gn_partials(const void* x, int x_dtype, float* part, long M, int C, hipStream_t s) {
+    CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_partials: input must be fp16 or fp32");
+    CTRL_CHECK(C % 8 == 0 && C / 8 <= 256 && M > 0, "gn_partials: C must be a multiple of 8, <= 2048");
+    const long slabs = (M + 15) / 16;
+    PROF_WORK(0, (x_dtype == DT_F32 ? 4.0 : 2.0) * M * C);
+    const size_t lds = (size_t)16 * 2 * C * sizeof(float);
+    if (x_dtype == DT_F32) LAUNCH("gn_stats", gn_partials_kernel<float>, dim3((unsigned)slabs), dim3(256), lds, s, (const float*)x, part, M, C);
+    else LAUNCH("gn_stats", gn_partials_kernel<half_t>, dim3((unsigned)slabs), dim3(256), lds, s, (const half_t*)x, part, M, C);
+    return 0;
+}
+
+int op_gn_finalize(const float* part, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
+    CTRL_CHECK(rows_per_img % 16 == 0 && rows_per_img > 0, "gn_finalize: rows per image must be a multiple of 16 (a slab never spans two images)");
+    CTRL_CHECK(C % G == 0 && G >= 1 && imgs >= 1, "gn_finalize: C must be a multiple of G");
+    PROF_WORK(0, 8.0 * imgs * (rows_per_img / 16) * C);
+    LAUNCH("gn_finalize", gn_finalize_kernel, dim3((unsigned)(imgs * G)), dim3(256), 0, s, part, stats, rows_per_img / 16, C, G);
+    return 0;
+}
+
 int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
                 int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s, long ldy, int lo_off,
                 long stat_rows, long y_img_rows, long y_row0) {
@@ -295,17 +395,28 @@ int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gam
 
 int op_layernorm(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, half_t* y, long ldy,
                  int M, int C, float eps, hipStream_t s) {
+    return op_layernorm_add(x, x_dtype, ldx, nullptr, 0, 1, 1, nullptr, gamma, beta, y, ldy, M, C, eps, s);
+}
+
+int op_layernorm_add(const void* x, int x_dtype, long ldx, const float* addv, long ldv, int rows_per_img, int vmod, void* xsum,
+                     const float* gamma, const float* beta, half_t* y, long ldy, int M, int C, float eps, hipStream_t s) {
+    CTRL_CHECK(!addv || (xsum && rows_per_img > 0 && vmod > 0 && ldv % 4 == 0 && (((uintptr_t)addv | (uintptr_t)xsum) & 15) == 0),
+               "layernorm: the added vector needs an output for the sum, 16-byte aligned");
     CTRL_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C must be a multiple of 8 and <= 2048");
     CTRL_CHECK(ldx % 8 == 0 && ldy % 8 == 0, "layernorm: leading dims must be multiples of 8");
     CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "layernorm: input must be fp16 or fp32");
     const dim3 grid((M + 3) / 4), block(256);
-    PROF_WORK(0, (x_dtype == DT_F32 ? 6.0 : 4.0) * M * C);
+    PROF_WORK(0, ((x_dtype == DT_F32 ? 6.0 : 4.0) + (addv ? (x_dtype == DT_F32 ? 4.0 : 2.0) : 0.0)) * M * C);
+    if (!rows_per_img) rows_per_img = 1;
+    if (!vmod) vmod = 1;
 #define LN_LAUNCH(NCH)                                                                                              \
     do {                                                                                                            \
         if (x_dtype == DT_F32)                                                                                      \
-            LAUNCH("layernorm", (layernorm_kernel<NCH, float>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, y, ldy, M, C, eps); \
+            LAUNCH("layernorm", (layernorm_kernel<NCH, float>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, y, ldy, M, C, eps, \
+                   addv, ldv, rows_per_img, vmod, (float*)xsum);                                                    \
         else                                                                                                        \
-            LAUNCH("layernorm", (layernorm_kernel<NCH, half_t>), grid, block, 0, s, (const half_t*)x, ldx, gamma, beta, y, ldy, M, C, eps); \
+            LAUNCH("layernorm", (layernorm_kernel<NCH, half_t>), grid, block, 0, s, (const half_t*)x, ldx, gamma, beta, y, ldy, M, C, eps, \
+                   addv, ldv, rows_per_img, vmod, (half_t*)xsum);                                                   \
     } while (0)
     if (C <= 512) LN_LAUNCH(1);
     else if (C <= 1024) LN_LAUNCH(2);

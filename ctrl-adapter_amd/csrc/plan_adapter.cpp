@@ -259,12 +259,17 @@ int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, 
         TRY(run_groupnorm(cx, w.norm1, x, n1, a.B, a.F * HW, 1e-6f, true));     // statistics span the clip's frames
     }
     TV h1 = stream_alloc(cx, (size_t)M * C, false);
+    if (!a.comm) want_gn(cx, h1, (size_t)M, C, HW);      // norm2's clip-wide statistics from conv1's epilogue
     IGemmArgs g = {};
     g.A = n1; g.lda = C; g.mode = IG_TEMPORAL; g.Cin = C; g.taps = 3; g.F = a.F; g.HW = HW; g.t_pad = a.comm ? 1 : 0;
     g.W = w.conv1.w; g.M = M; g.Nout = C; g.Ktot = 3 * C; g.bias = w.conv1.b;
     g.rowvec = tp; g.rowvec_ld = C; g.rows_per_img = HW; g.scale = 1.f;
     set_out(g, h1, C, C);
-    RUN(cx, op_igemm(g, cx.s));
+    {
+        const bool gn_after = !cx.dry && set_gn(g, h1, 1);
+        RUN(cx, op_igemm(g, cx.s));
+        if (gn_after) TRY(gn_partials_after(cx, h1, M, C));
+    }
     half_t* n2 = n1;
     if (a.comm) {
         TRY(gn_clip_sharded(cx, w.norm2, h1, n2, a, HW, 1e-6f));
@@ -277,20 +282,30 @@ int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, 
     set_res(g2, x, C);
     set_out(g2, out, C, C);
     set_blend(g2, blend_mix, x, C);
-    RUN(cx, op_igemm(g2, cx.s));
+    {
+        const bool gn_after = !cx.dry && set_gn(g2, out, 1);
+        RUN(cx, op_igemm(g2, cx.s));
+        if (gn_after) TRY(gn_partials_after(cx, out, M, C));
+    }
     cx.release(mk);
     return 0;
 }
 
 // TemporalBasicTransformerBlock on frame-major tokens X [(b f) L][512]; every op but the attention is per token
 // blend_mix / blend_other (optional): out = a*blend_other + (1-a)*block(X), folded into the last GEMM's epilogue
+// X_ln (optional): norm_in(X) already computed by X's producer (the fused frame-embedding add + LayerNorm pass); the buffer is
+// then re-used for the block's other LayerNorm outputs
 int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, const AFwd& a, int L,
-                    const float* blend_mix, const TV& blend_other, const float* ov /*one-key cross-attention vector*/) {
+                    const float* blend_mix, const TV& blend_other, const float* ov /*one-key cross-attention vector*/,
+                    half_t* X_ln = nullptr) {
     const size_t mk = cx.mark();
     const int M = a.N * L, dim = w.dim, Ci = w.attn1.inner;
     // x = ff_in(norm_in(x)) + x
-    half_t* xn = cx.h((size_t)M * dim);
-    TRY(run_layernorm(cx, w.norm_in, X, xn, M, dim));
+    half_t* xn = X_ln;
+    if (!xn) {
+        xn = cx.h((size_t)M * dim);
+        TRY(run_layernorm(cx, w.norm_in, X, xn, M, dim));
+    }
     half_t* mid = cx.h((size_t)M * 4 * dim);
     TRY(run_linear(cx, w.ffin1, xn, dim, tv16(mid), 4 * dim, M, TV(), 0));
     TV x0 = stream_alloc(cx, (size_t)M * dim, false);
@@ -422,6 +437,8 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
         if (sr) {
             const float* tp = pre.sres_tp[i];
             TV y = stream_alloc(cx, (size_t)N * H * up * W * up * C, need16 && !tr);
+            // a GroupNorm reads it next (the temporal ResNet's clip-wide norm1, or the block's `norm`): statistics from conv2
+            if ((tr || has_tf) && !a.comm) want_gn(cx, y, (size_t)N * H * up * W * up, C, H * up * W * up);
             TRY(run_resnet(cx, Lw.sres, x, y, N, H, W, up, tp, C, 1e-6f));
             x = y; H *= up; W *= up;
         } else if (up > 1 && !tr) {
@@ -440,6 +457,7 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             // with a spatial ResNet in front the AlphaBlender (:229) is folded into the temporal block's last conv
             TV yt = stream_alloc(cx, (size_t)N * H * W * C, false);
             if (need16) yt = tv16(cx.h((size_t)N * H * W * C));       // only a layout change follows: fp16 is enough
+            if (has_tf) want_gn(cx, yt, (size_t)N * H * W, C, H * W);
             TRY(run_temporal_resnet(cx, Lw.tres, x, yt, a, H * W, C, pre.tres_tp[i], sr ? Lw.res_mix : nullptr));
             x = yt;
         }
@@ -459,20 +477,29 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             }
             if (tt) {
                 TV t3 = stream_alloc(cx, (size_t)M * INNER, false);
-                RUN(cx, op_add_rowvec(tok.p, tok.dt, femb, INNER, t3.p, t3.dt, (size_t)M, INNER, Lt, a.F, cx.s));
                 // frame-sharded clip: pixel shards around the temporal block when the transport can and the pixels divide
                 const bool a2a = a.comm && a.comm->all_to_all && clip_a2a_enabled() && (Lt % a.comm->world == 0);
+                // frame-index embedding add (:279) and the temporal block's first LayerNorm in one pass over the tokens (the
+                // pixel-sharded form normalises after its exchange instead)
+                half_t* t3_ln = a2a ? nullptr : cx.h((size_t)M * INNER);
+                if (t3_ln && tok.dt == t3.dt)
+                    RUN(cx, op_layernorm_add(tok.p, tok.dt, INNER, femb, INNER, Lt, a.F, t3.p, Lw.ttb.norm_in.g, Lw.ttb.norm_in.b,
+                                             t3_ln, INNER, M, INNER, 1e-5f, cx.s));
+                else {
+                    RUN(cx, op_add_rowvec(tok.p, tok.dt, femb, INNER, t3.p, t3.dt, (size_t)M, INNER, Lt, a.F, cx.s));
+                    t3_ln = nullptr;
+                }
                 if (st) {
                     // AlphaBlender (:282) folded into the temporal block's last GEMM; the blended tokens are consumed
                     // only as proj_out's operand: fp16
                     TV t5 = tv16(cx.h((size_t)M * INNER));
                     if (a2a) TRY(run_temporal_tb_pixel_sharded(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix, pre.ttb_ov[i]));
-                    else TRY(run_temporal_tb(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix, pre.ttb_ov[i]));
+                    else TRY(run_temporal_tb(cx, Lw.ttb, t3, t5, a, Lt, Lw.tr_mix, smix, pre.ttb_ov[i], t3_ln));
                     tok = t5;
                 } else {
                     TV t4 = stream_alloc(cx, (size_t)M * INNER, true);
                     if (a2a) TRY(run_temporal_tb_pixel_sharded(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV(), pre.ttb_ov[i]));
-                    else TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV(), pre.ttb_ov[i]));
+                    else TRY(run_temporal_tb(cx, Lw.ttb, t3, t4, a, Lt, nullptr, TV(), pre.ttb_ov[i], t3_ln));
                     tok = t4;
                 }
             }
@@ -488,8 +515,11 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
                 RUN(cx, op_igemm(g, cx.s));
             } else {
                 TV y = stream_alloc(cx, (size_t)M * C, true);      // next layer's shortcut conv reads the fp16 copy
+                if (!a.comm) want_gn(cx, y, (size_t)M, C, Lt);     // ... and its norm1 the statistics
                 set_out(g, y, C, C);
+                const bool gn_after = !cx.dry && set_gn(g, y, 1);
                 RUN(cx, op_igemm(g, cx.s));
+                if (gn_after) TRY(gn_partials_after(cx, y, M, C));
                 x = y;
             }
         } else if (last) {

@@ -48,14 +48,15 @@ bool cn_split_enabled() {
     const char* e = getenv("CTRL_CN_SPLIT");
     return !(e && e[0] == '0') && stream_f32_enabled();
 }
-// How deep the split goes (CTRL_CN_SPLIT_LEVELS, default 2): down blocks 0 .. levels-1 take split operands (mid block =
-// level 4); the 13 zero-convs always do.  Round 3, tools/experiments/fp16_error_budget.py with the rounding points of this
-// selection: exact operands in blocks 0-1 + every zero-conv keep the ControlNet outputs at 6.9e-4 / the chain at 7.5e-4
-// (all convolutions exact: 5.7e-4 / 7.7e-4; none: 1.12e-3 / 1.06e-3) -- the 16x16 / 8x8 levels are where a split conv
-// costs most (small M, split-K, 0.07-0.19 of the MFMA peak) and adds least.
+// How deep the split goes (CTRL_CN_SPLIT_LEVELS, default 3): down blocks 0 .. levels-1 take split operands (mid block =
+// level 4); the 13 zero-convs always do.  Round 3: the 8x8 level (down block 3 + mid block) is where a split conv costs
+// most -- M = 64 rows per image, split-K 16, 0.07-0.19 of the MFMA peak -- and, by tools/experiments/fp16_error_budget.py
+// with the rounding points of each selection, adds least: plain operands there leave the ControlNet outputs / the chain at
+// the all-exact level (+0..5e-5), while also un-splitting the 16x16 level costs ~1e-4 -- measured on the GPU at the SVD-16
+// shapes: chain mid output 1.01e-3 with levels = 2 (profiles/r03_split_levels.md), over the bound.
 int cn_split_levels() {
     const char* e = getenv("CTRL_CN_SPLIT_LEVELS");
-    const int v = e ? atoi(e) : 2;
+    const int v = e ? atoi(e) : 3;
     return v < 0 ? 0 : (v > 5 ? 5 : v);
 }
 // CTRL_CN_SPLIT=dup: the first form of the split (weights packed twice, [hi | lo] walked as one long K) for A/B runs
@@ -306,6 +307,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     // ---- 2. stem: conv_in(sample) (:802-807) ----
     const int H = a.Hs, W = a.Ws;
     TV x = stream_alloc_rc(cx, (size_t)N * H * W, c0, true);   // block input (also residual slot 0)
+    want_gn(cx, x, (size_t)N * H * W, c0, H * W);              // (every tensor below that a GroupNorm reads next: statistics from its producer)
     half_t* stem = nullptr;
     if (!(a.flags & CTRL_SKIP_CONV_IN)) {
         stem = cx.h((size_t)N * H * W * c0);
@@ -379,10 +381,12 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         const DownBlockW& d = w.down[i];
         for (size_t j = 0; j < d.resnets.size(); ++j) {
             TV r = stream_alloc_rc(cx, (size_t)N * h * wd, d.Cout, true);
+            want_gn(cx, r, (size_t)N * h * wd, d.Cout, h * wd);
             TRY(run_resnet(cx, d.resnets[j], cur, r, N, h, wd, 1, tproj + d.resnets[j].temb_off, w.temb_total, c.norm_eps));
             cur = r;
             if (d.has_attn) {
                 TV t = stream_alloc_rc(cx, (size_t)N * h * wd, d.Cout, true);
+                if (j + 1 < d.resnets.size()) want_gn(cx, t, (size_t)N * h * wd, d.Cout, h * wd);     // (the last one feeds the down-sampler)
                 TRY(run_transformer2d(cx, d.tnorm[j], d.proj_in[j], d.proj_out[j], d.tb[j], cur, t, N, h, wd, e, next_kv()));
                 cur = t;
             }
@@ -391,6 +395,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         if (d.has_down) {
             const int ho = (h - 1) / 2 + 1, wo = (wd - 1) / 2 + 1;
             TV y = stream_alloc_rc(cx, (size_t)N * ho * wo, d.Cout, true);
+            want_gn(cx, y, (size_t)N * ho * wo, d.Cout, ho * wo);
             ConvOpts o; o.stride = 2;
             if (cur.lo_off > 0 && !d.down.dup) o.lda = 2 * d.Cout;      // plain conv on a split mirror: the hi half of every row
             TRY(run_conv(cx, d.down, cur.m16, y, N, h, wd, o));
@@ -402,8 +407,10 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     {
         const int C = c.block_out_channels[3];
         TV m0 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
+        want_gn(cx, m0, (size_t)N * h * wd, C, h * wd);
         TRY(run_resnet(cx, w.mid_r0, cur, m0, N, h, wd, 1, tproj + w.mid_r0.temb_off, w.temb_total, c.norm_eps));
         TV m1 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
+        want_gn(cx, m1, (size_t)N * h * wd, C, h * wd);
         TRY(run_transformer2d(cx, w.mid_tnorm, w.mid_pin, w.mid_pout, w.mid_tb, m0, m1, N, h, wd, e, next_kv()));
         TV m2 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
         TRY(run_resnet(cx, w.mid_r1, m1, m2, N, h, wd, 1, tproj + w.mid_r1.temb_off, w.temb_total, c.norm_eps));

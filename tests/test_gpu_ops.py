@@ -456,33 +456,33 @@ def test_two_workgroup_tiles_at_large_m(ops, gpu, K, geglu, f32):
         report("2-WG tile f32 stream K%d mirror" % K, rel_inf(mirror, ref))
 
 
-@pytest.mark.parametrize("M,K,res", [(4096, 320, False), (1000, 320, True), (16384 + 72, 2048, True)])
-def test_linear_with_fused_layernorm(ops, gpu, M, K, res):
-    """ctrl_igemm_desc::ln_out -- the LayerNorm -> Linear pairs of diffusers' (Temporal)BasicTransformerBlock reached from
-    model/adapter_spatial_temporal.py:108-130: the GEMM that produces a 512-wide fp32 stream row also writes LayerNorm(row)
-    in fp16 (full-row 128 x 512 tile).  Master vs an fp32 matmul, normalised rows vs torch's LayerNorm of the master the
-    kernel itself wrote (same input, so only the statistics / affine arithmetic is compared), ragged M"""
-    N = 512
-    x, w, b = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=0.05), rnd(N, seed=33)
-    gamma = (1.0 + 0.1 * rnd(N, seed=34)).contiguous()
-    beta = (0.1 * rnd(N, seed=35)).contiguous()
-    r = (torch.randn(M, N, generator=torch.Generator().manual_seed(36)) * 2.0 + 0.7) if res else None     # a row mean away from 0
+@pytest.mark.parametrize("M,N,K,hw,res", [(8192, 320, 320, 1024, True), (8 * 256 + 48, 640, 2880 // 9, 16, False), (131072 // 4, 320, 512, 4096, True)])
+def test_gemm_epilogue_writes_groupnorm_partials(ops, gpu, M, N, K, hw, res):
+    """ctrl_igemm_desc::gn_part -- every conv / GEMM whose output feeds a GroupNorm (model/resnet_block_2d.py:164-221, diffusers
+    ResnetBlock2D / Transformer2DModel) writes the per-16-row-slab column sums of its FINISHED fp32 values; gn_finalize turns
+    them into the (image, group) statistics gn_stats_kernel used to take from a pass over the whole map.  Against fp64 sums
+    of the kernel's own output, against the stand-alone partial pass, ragged M (rows past M count as zero)"""
+    x, w, b = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.05), rnd(N, seed=43)
+    r = (torch.randn(M, N, generator=torch.Generator().manual_seed(44)) + 0.3) if res else None
     wp, bp = ops.pack_linear_w(w.to(gpu)), ops.pack_vec(b.to(gpu))
     out = torch.empty(M, N, dtype=torch.float32, device=gpu)
-    ln = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    nslab = (M + 15) // 16
+    part = torch.full((nslab, N, 2), float("nan"), dtype=torch.float32, device=gpu)
     ops.igemm(x.half().to(gpu), K, wp, M, N, K, bias=bp, res=r.to(gpu) if res else None, ldres=N,
-              segs=[(out, N, 0, N, ops.SEG_ROW, 1)], ln=(gamma.to(gpu), beta.to(gpu), ln, N, 1e-5))
-    ref = x.half().float() @ w.half().float().t() + b + (r if res else 0.0)
-    report("fused LN: fp32 master M%d K%d" % (M, K), rel_inf(out, ref), 2e-5)
-    want = F.layer_norm(out.cpu(), (N,), gamma, beta, 1e-5)
-    report("fused LN: normalised rows M%d K%d" % (M, K), rel_inf(ln, want), 6e-4)
-    # and the same rows through the stand-alone kernel (what the plan falls back to for other widths)
-    alone = ops.layernorm(out, gamma.to(gpu), beta.to(gpu))
-    assert (ln.float() - alone.float()).abs().max().item() <= 2e-3 * want.abs().max().item()
-    with pytest.raises((ValueError, RuntimeError)):      # only the 512-wide full-row tile exists
-        ops.igemm(x.half().to(gpu), K, ops.pack_linear_w(rnd(640, K, seed=1).to(gpu)), M, 640, K,
-                  segs=[(torch.empty(M, 640, dtype=torch.float32, device=gpu), 640, 0, 640, ops.SEG_ROW, 1)],
-                  ln=(gamma.to(gpu), beta.to(gpu), ln, N, 1e-5))
+              segs=[(out, N, 0, N, ops.SEG_ROW, 1)], gn_part=part)
+    o64 = out.double().cpu()
+    pad = torch.zeros(nslab * 16 - M, N, dtype=torch.float64)
+    slabs = torch.cat([o64, pad]).reshape(nslab, 16, N)
+    want = torch.stack([slabs.sum(1), (slabs * slabs).sum(1)], dim=-1)
+    report("gn partials from the GEMM epilogue M%d N%d" % (M, N), rel_inf(part, want), 2e-6)
+    alone = ops.gn_partials(out)
+    report("gn partials, stand-alone pass M%d N%d" % (M, N), rel_inf(alone, want), 2e-6)
+    if M % hw == 0 and hw % 16 == 0:
+        imgs = M // hw
+        st = ops.gn_finalize(part, imgs, hw)
+        g = o64.reshape(imgs, hw, 32, N // 32)
+        ref = torch.stack([g.sum((1, 3)), (g * g).sum((1, 3))], dim=-1)
+        report("gn finalize M%d N%d" % (M, N), rel_inf(st, ref), 2e-6)
 
 
 def test_tile_walk_orders_are_bit_identical(ops, gpu):

@@ -33,7 +33,7 @@ def symbol_of(name):
     if m:
         g = m.groups()
         tf = lambda v: "true" if v == "1" else "false"
-        # (the 9th argument -- persistent-workgroup form -- exists from round 2's last build on; older traces lack it)
+        # (9th argument: round 2's last build = persistent-workgroup form, round 3 = fused GroupNorm partial sums; older traces lack it)
         return "igemm_kernel<%s, %s, %s, %s, %s, %s, %s, %s%s>" % (g[:7] + (tf(g[7]), ", " + tf(g[8]) if g[8] is not None else ""))
     m = re.search(r"flash_attn_d64_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
