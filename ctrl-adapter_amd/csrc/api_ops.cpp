@@ -32,13 +32,6 @@ size_t ctrl_op_gn_stats_floats(int imgs, int rows_per_img, int C, int G) { retur
 int ctrl_op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, void* stream) {
     return op_gn_stats(x, x_dtype, stats, imgs, rows_per_img, C, G, S(stream));
 }
-size_t ctrl_op_gn_part_floats(int64_t M, int C) { return op_gn_part_floats((long)M, C); }
-int ctrl_op_gn_partials(const void* x, int x_dtype, float* part, int64_t M, int C, void* stream) {
-    return op_gn_partials(x, x_dtype, part, (long)M, C, S(stream));
-}
-int ctrl_op_gn_finalize(const float* part, float* stats, int imgs, int rows_per_img, int C, int G, void* stream) {
-    return op_gn_finalize(part, stats, imgs, rows_per_img, C, G, S(stream));
-}
 int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream) {
     return op_gn_apply(x, x_dtype, stats, gamma, beta, H(y), imgs, rows_per_img, C, G, eps, silu, S(stream));

@@ -44,10 +44,7 @@ template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (NW
 // (A persistent-workgroup form -- one workgroup per CU walking its tiles with one LDS ring running across them -- was built
 // in round 2 and measured again at the start of round 3 after the epilogue fetch hoisting: 0.72-1.03x the one-tile form on
 // every shape of the path, profiles/r03_gemm_persistent_form.txt.  It is gone from the product.)
-// GN: the epilogue also writes the per-slab column sums of the finished output (ctrl_igemm_desc::gn_part).  A template
-// argument, not a run-time branch: the extra live state costs the 128-register two-workgroup tiles a few epilogue spills,
-// which the plain instantiations (everything that does not feed a GroupNorm) must not pay.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP, bool GN = false>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk, int order) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
@@ -481,13 +478,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                             const int r = idx / OWC, c8 = idx - r * OWC;
                             const int row = m0 + wm * WM + mi * 16 + r;
                             const int ocol = wcol0 + c8 * 8;
-                            if (row >= e.M || ocol >= nout_eff) {
-                                if constexpr (GN) {       // rows / columns past the problem contribute zeros to the column sums
-                                    *(f4*)(stg + r * SLD + c8 * 8) = f4{0.f, 0.f, 0.f, 0.f};
-                                    *(f4*)(stg + r * SLD + c8 * 8 + 4) = f4{0.f, 0.f, 0.f, 0.f};
-                                }
-                                continue;
-                            }
+                            if (row >= e.M || ocol >= nout_eff) continue;
                             const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
                             float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                             if (Rptr) {
@@ -535,10 +526,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
                             }
-                            if constexpr (GN) {     // GroupNorm statistics of the output: the FINISHED values go back into the slab
-                                *(f4*)(stg + r * SLD + c8 * 8) = f4{x[0], x[1], x[2], x[3]};
-                                *(f4*)(stg + r * SLD + c8 * 8 + 4) = f4{x[4], x[5], x[6], x[7]};
-                            }
                             if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
                                 h8 pk;
 #pragma unroll
@@ -575,26 +562,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
                                 *(us8*)((u16*)sg_out + o) = pk;
-                            }
-                        }
-                        if constexpr (GN) {
-                            // per-column (sum, sum of squares) of this 16-row slab, straight from LDS (a lane owns a column: 16
-                            // conflict-free reads), written as one partial row: gn_part[slab][column][2].  The consumer adds the
-                            // slabs of an image and the channels of a group in a fixed order (gn_finalize_kernel) -- the
-                            // statistics pass over the whole map (gn_stats_kernel) is gone
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            const int slab_row0 = m0 + wm * WM + mi * 16;
-                            if (slab_row0 < e.M) {
-#pragma unroll
-                                for (int cp = 0; cp < (WN + 63) / 64; ++cp) {
-                                    const int cc = lane + 64 * cp;
-                                    if (cc < OW && wcol0 + cc < nout_eff) {
-                                        float sx = 0.f, sq = 0.f;
-#pragma unroll 4
-                                        for (int rr = 0; rr < 16; ++rr) { const float v = stg[rr * SLD + cc]; sx += v; sq += v * v; }
-                                        *(f2*)(e.gn_part + ((size_t)(slab_row0 >> 4) * nout_eff + wcol0 + cc) * 2) = f2{sx, sq};
-                                    }
-                                }
                             }
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
@@ -796,8 +763,8 @@ int plan_order(const IGemmArgs& a, int BM, int BN, int ntm, int ntn) {
     return G < ntn ? tileorder::make_order(tileorder::ORDER_XCD_M, G) : 0;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP, bool GN>
-int launch_cfg3(const IGemmArgs& a, hipStream_t s, int splitk) {
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
+int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
     constexpr int BNP = (BN + PASSROWS - 1) / PASSROWS * PASSROWS;
     constexpr size_t ring = (size_t)NSTAGE * (BM + BNP) * BK * sizeof(half_t);
@@ -807,7 +774,7 @@ int launch_cfg3(const IGemmArgs& a, hipStream_t s, int splitk) {
     static bool attr_done[kMaxDevices] = {};       // function attributes are per device
     const int dev = cur_device();
     if (!attr_done[dev]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP, GN>,
+        HIP_TRY(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done[dev] = true;
     }
@@ -820,7 +787,7 @@ int launch_cfg3(const IGemmArgs& a, hipStream_t s, int splitk) {
     PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
-    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false", GN ? "true" : "false"); };
+    const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
     if (splitk > 1) {
         // partial sums go to fp32 slabs [splitk][M][Nout]; every epilogue term is applied once, by the finish kernel
         IGemmArgs p = a;
@@ -830,7 +797,7 @@ int launch_cfg3(const IGemmArgs& a, hipStream_t s, int splitk) {
         p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
         prof_detail("M%d N%d K%d taps%d%s splitk%d", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
         sym();
-        LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP, GN>), dim3(ntm * ntn * splitk),
+        LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn * splitk),
                dim3(WAVES_M * WAVES_N * 64), smem, s, p, ntm, ntn, zeros, splitk, order);
         const size_t total = (size_t)a.M * (a.Nout / 8);
         size_t blocks = (total + 255) / 256;
@@ -841,17 +808,9 @@ int launch_cfg3(const IGemmArgs& a, hipStream_t s, int splitk) {
         return 0;
     }
     sym();
-    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP, GN>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
+    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
            a, ntm, ntn, zeros, 1, order);
     return 0;
-}
-
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
-int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
-    if constexpr (SWAP) {
-        if (a.gn_part && splitk <= 1) return launch_cfg3<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, true, true>(a, s, splitk);
-    }
-    return launch_cfg3<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP, false>(a, s, splitk);
 }
 
 // Aligned row-major outputs and single aligned transposed (NCHW / V^T) outputs use the swapped-operand kernel (LDS-staged
@@ -889,12 +848,6 @@ int igemm_set_order(const char* spec) {
 
 void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n) {
     tileorder::tile_of(bid, ntm, ntn, tileorder::make_order(mode, group), tile_m, tile_n);
-}
-
-// can the per-slab column sums of this GEMM's output (ctrl_igemm_desc::gn_part) be produced by its epilogue?  Needs the
-// row-layout vector epilogue and no split-K (`splitk` = what the caller will run with)
-bool igemm_gn_fusable(const IGemmArgs& a, int splitk) {
-    return splitk <= 1 && !a.geglu && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a);
 }
 
 int igemm_splitk_factor(const IGemmArgs& a) {
@@ -982,8 +935,6 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(!a.out16 || (a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a)), "igemm: the fp16 mirror needs a single aligned row-major output");
     CTRL_CHECK(!a.blend_mix || (a.blend_x && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && !a.geglu && can_swap(a)),
                "igemm: the blend fold needs a single aligned row-major output and an aligned blend operand");
-    CTRL_CHECK(!a.gn_part || (igemm_gn_fusable(a, (a.splitk_ws && can_swap(a)) ? igemm_splitk_factor(a) : 1) && (((uintptr_t)a.gn_part & 7) == 0)),
-               "igemm: the fused GroupNorm partial sums need one aligned row-major output, no GEGLU, no split-K");
     for (int i = 0; i < a.nseg; ++i) {
         CTRL_CHECK(a.seg[i].col_begin % 16 == 0, "igemm: segment boundary must be a multiple of 16");
         CTRL_CHECK(a.seg[i].out != nullptr, "igemm: null segment output");

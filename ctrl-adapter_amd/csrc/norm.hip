@@ -185,64 +185,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-// Stand-alone producer of the per-slab column sums (same layout as the GEMM epilogue's gn_part): one workgroup per 16-row slab
-// group, a thread owns 8 channels of one row, partial rows go through LDS and are added in row order.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_partials_kernel(const T* __restrict__ x, float* __restrict__ part, long M, int C) {
-    extern __shared__ float sh[];            // [16][2*C]
-    const int lpr = C >> 3;                  // lanes per row
-    const int rpi = 256 / lpr;               // rows per iteration (>= 1: C <= 2048)
-    const long slab = blockIdx.x;
-    const int tid = threadIdx.x, tr = tid / lpr, tc = tid - tr * lpr;
-    for (int r0 = 0; r0 < 16; r0 += rpi) {
-        const int r = r0 + tr;
-        if (tr < rpi && r < 16) {
-            const long row = slab * 16 + r;
-            float v[8];
-            if (row < M) load8<T>(x + (size_t)row * C + tc * 8, v);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            }
-            float* dst = sh + (size_t)r * 2 * C + tc * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { dst[j] = v[j]; dst[C + j] = v[j] * v[j]; }
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float sx = 0.f, sq = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sx += sh[(size_t)r * 2 * C + c]; sq += sh[(size_t)r * 2 * C + C + c]; }
-        *(f2*)(part + ((size_t)slab * C + c) * 2) = f2{sx, sq};
-    }
-}
-
-// partial rows -> stats[img][G][2]: one workgroup per (image, group); thread t adds the entries t, t + 256, ... of the
-// group's (slab, channel) grid, then a fixed LDS tree -- the order never depends on timing
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                          int slabs_per_img, int C, int G) {
-    __shared__ float red[2][256];
-    const int img = blockIdx.x / G, g = blockIdx.x - img * G;
-    const int cg = C / G, tid = threadIdx.x;
-    const long n = (long)slabs_per_img * cg;
-    const float* base = part + ((size_t)img * slabs_per_img * C + (size_t)g * cg) * 2;
-    float sx = 0.f, sq = 0.f;
-    for (long e = tid; e < n; e += 256) {
-        const long sl = e / cg;
-        const int c = (int)(e - sl * cg);
-        const f2 v = *(const f2*)(base + ((size_t)sl * C + c) * 2);
-        sx += v[0]; sq += v[1];
-    }
-    red[0][tid] = sx; red[1][tid] = sq;
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
-        __syncthreads();
-    }
-    if (tid == 0) { stats[((size_t)img * G + g) * 2] = red[0][0]; stats[((size_t)img * G + g) * 2 + 1] = red[1][0]; }
-}
-
 // one wavefront per row; C <= 64*8*NCH
 // addv (optional): a per-image fp32 vector added to the row BEFORE the norm, addv[((row / rows_per_img) % vmod) * ldv + c] (the
 // frame-index embedding in front of the temporal transformer, model/adapter_spatial_temporal.py:279); the sum is also
@@ -345,27 +287,6 @@ int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per
     else
         LAUNCH("gn_stats", gn_stats_kernel<half_t>, dim3(chunks, imgs), dim3(256), lds, s,
                (const half_t*)x, stats, rows_per_img, C, G, rows_per_block);
-    return 0;
-}
-
-size_t op_gn_part_floats(long M, int C) { return (size_t)((M + 15) / 16) * C * 2; }
-
-int op_gn_partials(const void* x, int x_dtype, float* part, long M, int C, hipStream_t s) {
-    CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_partials: input must be fp16 or fp32");
-    CTRL_CHECK(C % 8 == 0 && C / 8 <= 256 && M > 0, "gn_partials: C must be a multiple of 8, <= 2048");
-    const long slabs = (M + 15) / 16;
-    PROF_WORK(0, (x_dtype == DT_F32 ? 4.0 : 2.0) * M * C);
-    const size_t lds = (size_t)16 * 2 * C * sizeof(float);
-    if (x_dtype == DT_F32) LAUNCH("gn_stats", gn_partials_kernel<float>, dim3((unsigned)slabs), dim3(256), lds, s, (const float*)x, part, M, C);
-    else LAUNCH("gn_stats", gn_partials_kernel<half_t>, dim3((unsigned)slabs), dim3(256), lds, s, (const half_t*)x, part, M, C);
-    return 0;
-}
-
-int op_gn_finalize(const float* part, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
-    CTRL_CHECK(rows_per_img % 16 == 0 && rows_per_img > 0, "gn_finalize: rows per image must be a multiple of 16 (a slab never spans two images)");
-    CTRL_CHECK(C % G == 0 && G >= 1 && imgs >= 1, "gn_finalize: C must be a multiple of G");
-    PROF_WORK(0, 8.0 * imgs * (rows_per_img / 16) * C);
-    LAUNCH("gn_finalize", gn_finalize_kernel, dim3((unsigned)(imgs * G)), dim3(256), 0, s, part, stats, rows_per_img / 16, C, G);
     return 0;
 }
 

@@ -17,8 +17,6 @@ typedef ctrl_igemm_desc IGemmArgs;
 int op_igemm(const IGemmArgs& a, hipStream_t s);
 // K-split factor op_igemm would use given scratch (1 = no split); scratch needed = factor * M * Nout * sizeof(float)
 int igemm_splitk_factor(const IGemmArgs& a);
-// true when this GEMM's epilogue can write the per-slab column sums of its output (ctrl_igemm_desc::gn_part)
-bool igemm_gn_fusable(const IGemmArgs& a, int splitk);
 // tile walk order of the implicit GEMM (tile_order.h): "legacy" | "auto" | "m,G" | "n,G"; 0 = accepted
 int igemm_set_order(const char* spec);
 void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
@@ -48,14 +46,6 @@ int op_temporal_attn(const TAttnArgs& a, hipStream_t s);
 // been zeroed once (the kernel leaves its tickets zero again).
 size_t op_gn_stats_floats(int imgs, int rows_per_img, int C, int G);
 int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s);
-// GroupNorm statistics in two stages without a pass over the map by a statistics kernel: the GEMM that PRODUCES x writes, for
-// every 16-row slab, the per-column (sum, sum of squares) of its finished values (ctrl_igemm_desc::gn_part,
-// [ceil(M/16)][C][2] fp32); op_gn_finalize adds the slabs of an image and the channels of a group in a fixed order into
-// stats[img][G][2] (what op_gn_stats produces).  rows_per_img % 16 == 0.  op_gn_partials: the same partial rows from a
-// stand-alone pass, for producers whose epilogue cannot write them (split-K, transposed outputs).
-size_t op_gn_part_floats(long M, int C);
-int op_gn_partials(const void* x, int x_dtype, float* part, long M, int C, hipStream_t s);
-int op_gn_finalize(const float* part, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s);
 // y = (x-mean)*rstd*gamma+beta (optionally SiLU); x,y [imgs*rows][C]
 // ldy / lo_off: row stride of y (0 = C) and, when > 0, the column offset of the LOW half of a split operand
 // (y[r][c] = hi = fp16(v), y[r][lo_off + c] = fp16(v - hi)): consumed by a convolution packed with dup weights

@@ -259,17 +259,12 @@ int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, 
         TRY(run_groupnorm(cx, w.norm1, x, n1, a.B, a.F * HW, 1e-6f, true));     // statistics span the clip's frames
     }
     TV h1 = stream_alloc(cx, (size_t)M * C, false);
-    if (!a.comm) want_gn(cx, h1, (size_t)M, C, HW);      // norm2's clip-wide statistics from conv1's epilogue
     IGemmArgs g = {};
     g.A = n1; g.lda = C; g.mode = IG_TEMPORAL; g.Cin = C; g.taps = 3; g.F = a.F; g.HW = HW; g.t_pad = a.comm ? 1 : 0;
     g.W = w.conv1.w; g.M = M; g.Nout = C; g.Ktot = 3 * C; g.bias = w.conv1.b;
     g.rowvec = tp; g.rowvec_ld = C; g.rows_per_img = HW; g.scale = 1.f;
     set_out(g, h1, C, C);
-    {
-        const bool gn_after = !cx.dry && set_gn(g, h1, 1);
-        RUN(cx, op_igemm(g, cx.s));
-        if (gn_after) TRY(gn_partials_after(cx, h1, M, C));
-    }
+    RUN(cx, op_igemm(g, cx.s));
     half_t* n2 = n1;
     if (a.comm) {
         TRY(gn_clip_sharded(cx, w.norm2, h1, n2, a, HW, 1e-6f));
@@ -282,11 +277,7 @@ int run_temporal_resnet(Ctx& cx, const TResnetW& w, const TV& x, const TV& out, 
     set_res(g2, x, C);
     set_out(g2, out, C, C);
     set_blend(g2, blend_mix, x, C);
-    {
-        const bool gn_after = !cx.dry && set_gn(g2, out, 1);
-        RUN(cx, op_igemm(g2, cx.s));
-        if (gn_after) TRY(gn_partials_after(cx, out, M, C));
-    }
+    RUN(cx, op_igemm(g2, cx.s));
     cx.release(mk);
     return 0;
 }
@@ -437,8 +428,6 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
         if (sr) {
             const float* tp = pre.sres_tp[i];
             TV y = stream_alloc(cx, (size_t)N * H * up * W * up * C, need16 && !tr);
-            // a GroupNorm reads it next (the temporal ResNet's clip-wide norm1, or the block's `norm`): statistics from conv2
-            if ((tr || has_tf) && !a.comm) want_gn(cx, y, (size_t)N * H * up * W * up, C, H * up * W * up);
             TRY(run_resnet(cx, Lw.sres, x, y, N, H, W, up, tp, C, 1e-6f));
             x = y; H *= up; W *= up;
         } else if (up > 1 && !tr) {
@@ -457,7 +446,6 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             // with a spatial ResNet in front the AlphaBlender (:229) is folded into the temporal block's last conv
             TV yt = stream_alloc(cx, (size_t)N * H * W * C, false);
             if (need16) yt = tv16(cx.h((size_t)N * H * W * C));       // only a layout change follows: fp16 is enough
-            if (has_tf) want_gn(cx, yt, (size_t)N * H * W, C, H * W);
             TRY(run_temporal_resnet(cx, Lw.tres, x, yt, a, H * W, C, pre.tres_tp[i], sr ? Lw.res_mix : nullptr));
             x = yt;
         }
@@ -515,11 +503,8 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
                 RUN(cx, op_igemm(g, cx.s));
             } else {
                 TV y = stream_alloc(cx, (size_t)M * C, true);      // next layer's shortcut conv reads the fp16 copy
-                if (!a.comm) want_gn(cx, y, (size_t)M, C, Lt);     // ... and its norm1 the statistics
                 set_out(g, y, C, C);
-                const bool gn_after = !cx.dry && set_gn(g, y, 1);
                 RUN(cx, op_igemm(g, cx.s));
-                if (gn_after) TRY(gn_partials_after(cx, y, M, C));
                 x = y;
             }
         } else if (last) {

@@ -64,9 +64,7 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
 // ------------------------------------------------------------------------------------------ runners
 int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu, bool split) {
     float* st = cx.stats(op_gn_stats_floats(imgs, rows, n.C, 32));
-    // the producer already left per-slab column sums (TV::gn_part): add them up instead of reading the map again
-    if (x.gn_part && rows % 16 == 0) RUN(cx, op_gn_finalize(x.gn_part, st, imgs, rows, n.C, 32, cx.s));
-    else RUN(cx, op_gn_stats(x.p, x.dt, st, imgs, rows, n.C, 32, cx.s));
+    RUN(cx, op_gn_stats(x.p, x.dt, st, imgs, rows, n.C, 32, cx.s));
     RUN(cx, op_gn_apply(x.p, x.dt, st, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s, split ? 2 * n.C : n.C, split ? n.C : 0));
     return 0;
 }
@@ -93,9 +91,7 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
         g.splitk_ws_bytes = (int64_t)sk * g.M * g.Nout * (int64_t)sizeof(float);
         g.splitk_ws = cx.alloc((size_t)g.splitk_ws_bytes);
     }
-    const bool gn_after = !cx.dry && set_gn(g, y, sk);
     RUN(cx, op_igemm(g, cx.s));
-    if (gn_after) TRY(gn_partials_after(cx, y, g.M, c.Cout));
     cx.release(mk);
     return 0;
 }
@@ -111,9 +107,7 @@ int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, lo
     set_res(g, res, ldres);
     set_out(g, y, ldy, l.geglu ? l.N / 2 : l.N);
     set_blend(g, blend_mix, blend_other, ldy);
-    const bool gn_after = !cx.dry && set_gn(g, y, 1);
     RUN(cx, op_igemm(g, cx.s));
-    if (gn_after) TRY(gn_partials_after(cx, y, M, l.N));
     if (ln && ln_out) TRY(run_layernorm(cx, *ln, y, ln_out, M, l.N));
     return 0;
 }
@@ -126,7 +120,6 @@ int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int
     TRY(run_groupnorm(cx, w.norm1, x, a, N, H * W, eps, true, w.conv1.dup));
     // conv1 output feeds only GroupNorm: keep it in the stream dtype (its statistics are taken from this copy)
     TV h1 = stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
-    want_gn(cx, h1, (size_t)N * Ho * Wo, w.Cout, Ho * Wo);       // norm2 reads it: statistics from conv1's epilogue
     ConvOpts o1; o1.up = up; o1.rowvec = temb_proj; o1.rowvec_ld = temb_ld;
     TRY(run_conv(cx, w.conv1, a, h1, N, H, W, o1));
     half_t* b = cx.h((size_t)N * Ho * Wo * w.conv2.Cin);

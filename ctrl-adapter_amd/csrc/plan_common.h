@@ -383,20 +383,8 @@ struct TV {
     int dt = DT_F16;
     half_t* m16 = nullptr;
     int lo_off = 0;      // > 0: m16 rows are [hi | lo] (2 x the width), lo at this column offset (split operand)
-    // When a GroupNorm will read this tensor: per-16-row-slab column sums [ceil(rows/16)][C][2] that the PRODUCER fills (its GEMM
-    // epilogue, or op_gn_partials when that GEMM cannot); run_groupnorm then needs no statistics pass over the map
-    float* gn_part = nullptr;
     bool ok() const { return p != nullptr; }
 };
-// CTRL_GN_FUSE=0: every GroupNorm takes its statistics with gn_stats_kernel (round-2 behaviour)
-inline bool gn_fuse_enabled() {
-    static const bool on = [] { const char* e = getenv("CTRL_GN_FUSE"); return !(e && e[0] == '0'); }();
-    return on;
-}
-// mark a stream tensor [rows][C] whose next reader is a GroupNorm over images of rows_per_img rows
-inline void want_gn(Ctx& cx, TV& t, size_t rows, int C, int rows_per_img) {
-    if (gn_fuse_enabled() && rows_per_img % 16 == 0) t.gn_part = cx.f(op_gn_part_floats((long)rows, C));
-}
 inline TV tv16(const half_t* x) { TV t; t.p = (void*)x; t.dt = DT_F16; t.m16 = (half_t*)x; return t; }
 inline TV stream_alloc(Ctx& cx, size_t n, bool need16) {
     TV t;
@@ -421,19 +409,6 @@ inline void set_out(IGemmArgs& g, const TV& out, long ld, int ncols) {
     g.seg[0] = IGemmSeg{out.p, ld, 0, ncols, SEG_ROW, out.dt, 1, 0};
     g.out16 = nullptr; g.ld16 = 0; g.out16_lo_off = 0;
     if (out.dt == DT_F32 && out.m16) { g.out16 = out.m16; g.ld16 = out.lo_off ? 2 * ld : ld; g.out16_lo_off = out.lo_off; }
-}
-// after set_out: hand the tensor's partial-sum buffer to the GEMM when its epilogue can fill it; returns true when the caller
-// must run op_gn_partials on the finished output instead
-inline bool set_gn(IGemmArgs& g, const TV& out, int splitk) {
-    g.gn_part = nullptr;
-    if (!out.gn_part) return false;
-    if (igemm_gn_fusable(g, splitk)) { g.gn_part = out.gn_part; return false; }
-    return true;
-}
-// the stand-alone partial pass for producers that cannot fuse it
-inline int gn_partials_after(Ctx& cx, const TV& out, long M, int C) {
-    if (!cx.dry) TRY(op_gn_partials(out.p, out.dt, out.gn_part, M, C, cx.s));
-    return 0;
 }
 inline void set_res(IGemmArgs& g, const TV& res, long ld) {
     g.res = res.p; g.ldres = ld; g.res_f32 = (res.ok() && res.dt == DT_F32) ? 1 : 0;

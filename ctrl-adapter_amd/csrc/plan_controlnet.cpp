@@ -307,7 +307,6 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     // ---- 2. stem: conv_in(sample) (:802-807) ----
     const int H = a.Hs, W = a.Ws;
     TV x = stream_alloc_rc(cx, (size_t)N * H * W, c0, true);   // block input (also residual slot 0)
-    want_gn(cx, x, (size_t)N * H * W, c0, H * W);              // (every tensor below that a GroupNorm reads next: statistics from its producer)
     half_t* stem = nullptr;
     if (!(a.flags & CTRL_SKIP_CONV_IN)) {
         stem = cx.h((size_t)N * H * W * c0);
@@ -381,12 +380,10 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         const DownBlockW& d = w.down[i];
         for (size_t j = 0; j < d.resnets.size(); ++j) {
             TV r = stream_alloc_rc(cx, (size_t)N * h * wd, d.Cout, true);
-            want_gn(cx, r, (size_t)N * h * wd, d.Cout, h * wd);
             TRY(run_resnet(cx, d.resnets[j], cur, r, N, h, wd, 1, tproj + d.resnets[j].temb_off, w.temb_total, c.norm_eps));
             cur = r;
             if (d.has_attn) {
                 TV t = stream_alloc_rc(cx, (size_t)N * h * wd, d.Cout, true);
-                if (j + 1 < d.resnets.size()) want_gn(cx, t, (size_t)N * h * wd, d.Cout, h * wd);     // (the last one feeds the down-sampler)
                 TRY(run_transformer2d(cx, d.tnorm[j], d.proj_in[j], d.proj_out[j], d.tb[j], cur, t, N, h, wd, e, next_kv()));
                 cur = t;
             }
@@ -395,7 +392,6 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         if (d.has_down) {
             const int ho = (h - 1) / 2 + 1, wo = (wd - 1) / 2 + 1;
             TV y = stream_alloc_rc(cx, (size_t)N * ho * wo, d.Cout, true);
-            want_gn(cx, y, (size_t)N * ho * wo, d.Cout, ho * wo);
             ConvOpts o; o.stride = 2;
             if (cur.lo_off > 0 && !d.down.dup) o.lda = 2 * d.Cout;      // plain conv on a split mirror: the hi half of every row
             TRY(run_conv(cx, d.down, cur.m16, y, N, h, wd, o));
@@ -407,10 +403,8 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     {
         const int C = c.block_out_channels[3];
         TV m0 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
-        want_gn(cx, m0, (size_t)N * h * wd, C, h * wd);
         TRY(run_resnet(cx, w.mid_r0, cur, m0, N, h, wd, 1, tproj + w.mid_r0.temb_off, w.temb_total, c.norm_eps));
         TV m1 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
-        want_gn(cx, m1, (size_t)N * h * wd, C, h * wd);
         TRY(run_transformer2d(cx, w.mid_tnorm, w.mid_pin, w.mid_pout, w.mid_tb, m0, m1, N, h, wd, e, next_kv()));
         TV m2 = stream_alloc_rc(cx, (size_t)N * h * wd, C, true);
         TRY(run_resnet(cx, w.mid_r1, m1, m2, N, h, wd, 1, tproj + w.mid_r1.temb_off, w.temb_total, c.norm_eps));

@@ -57,10 +57,8 @@ def pack_vec(v, geglu=False):
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
           res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None,
-          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False, scale2=0.0, scale2_from=0,
-          gn_part=None):
-    """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L); gn_part: fp32 [ceil(M/16)][Nout][2] buffer the epilogue fills
-    with the per-slab column sums of the output (GroupNorm statistics, see gn_finalize)"""
+          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False, scale2=0.0, scale2_from=0):
+    """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
     g = geom or {}
@@ -86,7 +84,6 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.scale = scale; d.geglu = int(geglu)
     d.scale2 = scale2; d.scale2_from = scale2_from
     d.a_split = int(a_split); d.out16_lo_off = out16_lo_off      # a_split: 0 | 1 (weights packed twice) | 2 (paired walk)
-    d.gn_part = gn_part.data_ptr() if gn_part is not None else None
     d.nseg = len(segs)
     for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):
         d.seg[i].out = out.data_ptr(); d.seg[i].ld = ld; d.seg[i].col_begin = cb; d.seg[i].ncols = nc
@@ -186,23 +183,6 @@ def groupnorm_split(x, gamma, beta, imgs, rows_per_img, G=32, eps=1e-5, silu=Fal
     L.check(lib.ctrl_op_gn_apply_split(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(y),
                                        C.c_int64(2 * Cc), Cc, imgs, rows_per_img, Cc, G, C.c_float(eps), int(silu), L.cur_stream()))
     return y
-
-
-def gn_partials(x):
-    """[M][C] fp16 / fp32 -> per-16-row-slab column (sum, sum of squares) [ceil(M/16)][C][2] fp32 (stand-alone pass)"""
-    M, Cc = x.shape
-    part = torch.empty((M + 15) // 16, Cc, 2, dtype=torch.float32, device=x.device)
-    assert L.lib().ctrl_op_gn_part_floats(C.c_int64(M), Cc) == part.numel()
-    L.check(L.lib().ctrl_op_gn_partials(L.ptr(x), L.dtype_code(x.dtype), L.ptr(part), C.c_int64(M), Cc, L.cur_stream()))
-    return part
-
-
-def gn_finalize(part, imgs, rows_per_img, G=32):
-    """per-slab column sums -> GroupNorm statistics [imgs][G][2] (sum, sum of squares)"""
-    Cc = part.shape[1]
-    stats = torch.empty(imgs, G, 2, dtype=torch.float32, device=part.device)
-    L.check(L.lib().ctrl_op_gn_finalize(L.ptr(part), L.ptr(stats), imgs, rows_per_img, Cc, G, L.cur_stream()))
-    return stats
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

@@ -95,11 +95,6 @@ typedef struct ctrl_igemm_desc {
     float scale2; int32_t scale2_from;   /* scale2_from > 0: output columns >= scale2_from are multiplied by scale2 instead of scale
                                             (row-major outputs): the K half of a Q|K projection leaves pre-multiplied by
                                             softmax_scale * log2(e) for ctrl_attn_desc::k_prescaled */
-    /* optional GroupNorm partial sums of the output (one row-major output, no GEGLU, no split-K; every conv / GEMM whose
-     * result feeds a GroupNorm -- model/resnet_block_2d.py:164-221, diffusers ResnetBlock2D / Transformer2DModel /
-     * TemporalResnetBlock): gn_part[(m/16)*N + n][2] = (sum, sum of squares) over the 16 rows of slab m/16 of the FINISHED
-     * values y[m][n] (rows >= M count as 0), fp32; ctrl_op_gn_finalize turns them into the [img][group][2] statistics */
-    float* gn_part;
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
@@ -152,11 +147,6 @@ size_t ctrl_op_gn_stats_floats(int imgs, int rows_per_img, int C, int G);
 int ctrl_op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, void* stream);
 int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
-/* two-stage statistics (ctrl_igemm_desc::gn_part): `part` = [ceil(M/16)][C][2] per-slab column sums, written by the
- * producing GEMM's epilogue or by ctrl_op_gn_partials; finalize -> stats[imgs][G][2] (rows_per_img % 16 == 0) */
-size_t ctrl_op_gn_part_floats(int64_t M, int C);
-int ctrl_op_gn_partials(const void* x, int x_dtype, float* part, int64_t M, int C, void* stream);
-int ctrl_op_gn_finalize(const float* part, float* stats, int imgs, int rows_per_img, int C, int G, void* stream);
 /* split-operand variant: y rows are [hi | lo] (row stride ldy, lo at column offset lo_off), hi + lo = the fp32 result to ~2^-22 */
 int ctrl_op_gn_apply_split(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                            int64_t ldy, int lo_off, int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);

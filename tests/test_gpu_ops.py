@@ -456,35 +456,6 @@ def test_two_workgroup_tiles_at_large_m(ops, gpu, K, geglu, f32):
         report("2-WG tile f32 stream K%d mirror" % K, rel_inf(mirror, ref))
 
 
-@pytest.mark.parametrize("M,N,K,hw,res", [(8192, 320, 320, 1024, True), (8 * 256 + 48, 640, 2880 // 9, 16, False), (131072 // 4, 320, 512, 4096, True)])
-def test_gemm_epilogue_writes_groupnorm_partials(ops, gpu, M, N, K, hw, res):
-    """ctrl_igemm_desc::gn_part -- every conv / GEMM whose output feeds a GroupNorm (model/resnet_block_2d.py:164-221, diffusers
-    ResnetBlock2D / Transformer2DModel) writes the per-16-row-slab column sums of its FINISHED fp32 values; gn_finalize turns
-    them into the (image, group) statistics gn_stats_kernel used to take from a pass over the whole map.  Against fp64 sums
-    of the kernel's own output, against the stand-alone partial pass, ragged M (rows past M count as zero)"""
-    x, w, b = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.05), rnd(N, seed=43)
-    r = (torch.randn(M, N, generator=torch.Generator().manual_seed(44)) + 0.3) if res else None
-    wp, bp = ops.pack_linear_w(w.to(gpu)), ops.pack_vec(b.to(gpu))
-    out = torch.empty(M, N, dtype=torch.float32, device=gpu)
-    nslab = (M + 15) // 16
-    part = torch.full((nslab, N, 2), float("nan"), dtype=torch.float32, device=gpu)
-    ops.igemm(x.half().to(gpu), K, wp, M, N, K, bias=bp, res=r.to(gpu) if res else None, ldres=N,
-              segs=[(out, N, 0, N, ops.SEG_ROW, 1)], gn_part=part)
-    o64 = out.double().cpu()
-    pad = torch.zeros(nslab * 16 - M, N, dtype=torch.float64)
-    slabs = torch.cat([o64, pad]).reshape(nslab, 16, N)
-    want = torch.stack([slabs.sum(1), (slabs * slabs).sum(1)], dim=-1)
-    report("gn partials from the GEMM epilogue M%d N%d" % (M, N), rel_inf(part, want), 2e-6)
-    alone = ops.gn_partials(out)
-    report("gn partials, stand-alone pass M%d N%d" % (M, N), rel_inf(alone, want), 2e-6)
-    if M % hw == 0 and hw % 16 == 0:
-        imgs = M // hw
-        st = ops.gn_finalize(part, imgs, hw)
-        g = o64.reshape(imgs, hw, 32, N // 32)
-        ref = torch.stack([g.sum((1, 3)), (g * g).sum((1, 3))], dim=-1)
-        report("gn finalize M%d N%d" % (M, N), rel_inf(st, ref), 2e-6)
-
-
 def test_tile_walk_orders_are_bit_identical(ops, gpu):
     """csrc/tile_order.h only decides WHICH workgroup computes a tile: every order must give the same bits (GEGLU with bias;
     fp32 stream update with fp32 residual + fp16 mirror; a ragged M), and the fp32 result matches the fp32 reference"""

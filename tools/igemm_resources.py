@@ -77,7 +77,7 @@ def main():
     res, loops = resource_remarks(src), mfma_loops(src)
     print("# igemm.hip: hipcc -Rpass-analysis=kernel-resource-usage per instantiation, and the number of spill instructions")
     print("# (v_readlane / v_writelane / scratch_*) inside the tightest loop that contains the MFMAs (device ISA).  tools/igemm_resources.py")
-    print("# The last template argument is the persistent-workgroup form (opt-in); 128x320 is an experiment-only tile (CTRL_IGEMM_FORCE).")
+    print("# (scratch > 0 only in the BK = 64 256x128 tile of channel counts that are multiples of 64 but not 128: epilogue spills, outside the MFMA loop)")
     print("%-62s %5s %5s %4s %8s %11s %11s  %s" % ("kernel", "VGPR", "SGPR", "occ", "scratch", "SGPR spill", "VGPR spill", "tightest MFMA loop: instr / MFMAs / spill ops"))
     for n, v in sorted(res.items(), key=lambda kv: pretty(kv[0])):
         lp = loops.get(n)
