@@ -898,7 +898,7 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     // fp16 mirror write of a stream update -- run under the other's k-loop.  GEGLU 512->4096 at M = 131072: 562 -> 677
     // TFLOP/s (256x128); stream updates K = 320: 182 -> 217 (128x256), K = 2048: 551 -> 603 (256x128).
     if (MODE == IG_ROWS && a.M >= 65536 && can_swap(a) && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && a.Nout % 128 == 0) {
-        const bool f32_stream = a.seg[0].dtype == DT_F32;
+        const bool f32_stream = a.seg[0].dtype == DT_F32 || (a.res && a.res_f32);      // fp32 rows written and / or read per element
         if (a.geglu && a.Nout % 256 == 0) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
         if (f32_stream && a.Nout % 256 == 0) {
             if (a.Ktot > 1024) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);

@@ -459,7 +459,10 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             TRY(run_linear(cx, b.proj_in, n, C, tok, INNER, M, TV(), 0, nullptr, 0, 0, nullptr, TV(), st ? &Lw.stb.norm1 : nullptr, tok_ln));
             TV smix;
             if (st) {
-                TV t2 = stream_alloc(cx, (size_t)M * INNER, !tt);      // proj_out operand when no temporal block follows
+                // no temporal block: the spatial transformer's result is read once more, as proj_out's fp16 operand -- the last
+                // GEMM writes just that (the same rounding of the same fp32 value the mirror of an fp32 master would hold: bit-
+                // identical results, one 4-byte-per-element store less); with a temporal block it stays an fp32 stream
+                TV t2 = tt ? stream_alloc(cx, (size_t)M * INNER, false) : tv16(cx.h((size_t)M * INNER));
                 TRY(run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e, a.e.Lk == 1 ? pre.stb_ov[i] : nullptr, nullptr, tok_ln));
                 tok = t2; smix = t2;
             }
