@@ -29,6 +29,7 @@ class IGemmDesc(C.Structure):
                 ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
                 ("out16", C.c_void_p), ("ld16", C.c_int64),
                 ("blend_mix", C.c_void_p), ("blend_x", C.c_void_p), ("ld_blend", C.c_int64), ("blend_f32", C.c_int32), ("out16_lo_off", C.c_int32), ("scale2", C.c_float), ("scale2_from", C.c_int32),
+                ("res_up", C.c_int32), ("pad2_", C.c_int32),
                 ("seg", IGemmSeg * 3)]
 
 

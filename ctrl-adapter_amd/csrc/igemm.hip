@@ -28,6 +28,19 @@
 
 namespace {
 
+// Residual row of output row `row`.  res_up == 2: the residual is held at HALF the output resolution and read through a
+// nearest x2 up-sampling -- the 1x1 shortcut convolution of the adapter's ResnetBlock2D commutes with the nearest up-sampling
+// in front of it (model/resnet_block_2d.py:174-184 up-samples input_tensor, :216 applies conv_shortcut: every output pixel of
+// the conv is the conv of ONE input pixel), so the shortcut runs on the quarter-size map and this epilogue fetches
+// res[n][oy/2][ox/2]: the same values bit for bit, a quarter of the shortcut's FLOPs and of its fp32 round trip.
+__device__ __forceinline__ size_t res_row_of(const IGemmArgs& e, int row) {
+    if (e.res_up != 2) return (size_t)row;
+    const int hw = e.Hout * e.Wout;
+    const int n = row / hw, rem = row - n * hw;
+    const int oy = rem / e.Wout, ox = rem - oy * e.Wout;
+    return ((size_t)n * (e.Hout >> 1) + (oy >> 1)) * (size_t)(e.Wout >> 1) + (ox >> 1);
+}
+
 // LDS tiles are linear [rows][BK] (global_load_lds writes wave-uniform base + lane*16), so bank conflicts of the
 // ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte chunk index that is applied to the
 // per-lane SOURCE address when staging and to the read address when fetching fragments (same involution).
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                             const int r = idx / OWC, c8 = idx - r * OWC;
                             const int row = m0 + wm * WM + r, ocol = wcol0 + c8 * 8;
                             if (row < e.M && ocol < nout_eff) {
-                                const float* rp = (const float*)e.res + (size_t)row * e.ldres + ocol;
+                                const float* rp = (const float*)e.res + res_row_of(e, row) * e.ldres + ocol;
                                 rf0[t] = *(const f4*)rp;
                                 rf1[t] = *(const f4*)(rp + 4);
                             }
@@ -488,18 +501,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
 #pragma unroll
                                         for (int i = 0; i < 4; ++i) { x[i] += rf0[tp][i]; x[4 + i] += rf1[tp][i]; }
                                         if (mi + 1 < MI && row + 16 < e.M) {       // refill for the same piece of the next slab
-                                            const float* rp = (const float*)e.res + (size_t)(row + 16) * e.ldres + ocol;
+                                            const float* rp = (const float*)e.res + res_row_of(e, row + 16) * e.ldres + ocol;
                                             rf0[tp] = *(const f4*)rp;
                                             rf1[tp] = *(const f4*)(rp + 4);
                                         }
                                     } else {
-                                        const float* rp = (const float*)e.res + (size_t)row * e.ldres + ocol;
+                                        const float* rp = (const float*)e.res + res_row_of(e, row) * e.ldres + ocol;
                                         const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
 #pragma unroll
                                         for (int i = 0; i < 4; ++i) { x[i] += r0[i]; x[4 + i] += r1[i]; }
                                     }
                                 } else {
-                                    const h8 rr = *(const h8*)(Rptr + (size_t)row * e.ldres + ocol);
+                                    const h8 rr = *(const h8*)(Rptr + res_row_of(e, row) * e.ldres + ocol);
 #pragma unroll
                                     for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
                                 }
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
                             }
                             if (e.act == 1) x = silu_f(x);
                             if (Rptr && row < e.M)
-                                x += e.res_f32 ? ((const float*)e.res)[(size_t)row * e.ldres + ocol] : (float)Rptr[(size_t)row * e.ldres + ocol];
+                                x += e.res_f32 ? ((const float*)e.res)[res_row_of(e, row) * e.ldres + ocol] : (float)Rptr[res_row_of(e, row) * e.ldres + ocol];
                             v[i] = x * ((e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale);
                         }
                         if (sg.fmt == SEG_ROW) {
@@ -669,11 +682,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmArgs a, const f
         }
         if (a.res) {
             if (a.res_f32) {
-                const float* rp = (const float*)a.res + row * a.ldres + col;
+                const float* rp = (const float*)a.res + res_row_of(a, (int)row) * a.ldres + col;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] += rp[j];
             } else {
-                const h8 rr = *(const h8*)((const half_t*)a.res + row * a.ldres + col);
+                const h8 rr = *(const h8*)((const half_t*)a.res + res_row_of(a, (int)row) * a.ldres + col);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] += (float)rr[j];
             }
@@ -935,6 +948,9 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(!a.out16 || (a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a)), "igemm: the fp16 mirror needs a single aligned row-major output");
     CTRL_CHECK(!a.blend_mix || (a.blend_x && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && !a.geglu && can_swap(a)),
                "igemm: the blend fold needs a single aligned row-major output and an aligned blend operand");
+    CTRL_CHECK(a.res_up == 0 || a.res_up == 1 || (a.res_up == 2 && a.res && a.mode == IG_CONV2D && a.Hout % 2 == 0 && a.Wout % 2 == 0 &&
+                                                   a.nseg == 1 && a.seg[0].fmt == SEG_ROW),
+               "igemm: an up-sampled residual (res_up = 2) needs a conv2d problem with even output size and one row-major output");
     for (int i = 0; i < a.nseg; ++i) {
         CTRL_CHECK(a.seg[i].col_begin % 16 == 0, "igemm: segment boundary must be a multiple of 16");
         CTRL_CHECK(a.seg[i].out != nullptr, "igemm: null segment output");

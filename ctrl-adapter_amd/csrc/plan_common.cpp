@@ -84,6 +84,7 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
     g.bias = c.b; g.rowvec = o.rowvec; g.rowvec_ld = o.rowvec_ld; g.rows_per_img = Hout * Wout;
     g.scale = 1.f; g.act = o.act; g.a_split = c.paired ? 2 : (c.dup ? 1 : 0);
     set_res(g, o.res, c.Cout);
+    g.res_up = o.res_up;
     set_out(g, y, c.Cout, c.Cout);
     const size_t mk = cx.mark();
     const int sk = igemm_splitk_factor(g);
@@ -125,16 +126,21 @@ int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int
     half_t* b = cx.h((size_t)N * Ho * Wo * w.conv2.Cin);
     TRY(run_groupnorm(cx, w.norm2, h1, b, N, Ho * Wo, eps, true, w.conv2.dup));
     TV sc = x;
+    int sc_up = 0;
     if (w.has_shortcut) {
         CTRL_CHECK(cx.dry || x.m16 != nullptr, "resnet: the shortcut conv needs an fp16 copy of its input");
         CTRL_CHECK(x.lo_off > 0 || !w.shortcut.dup, "resnet: a split-operand shortcut conv needs a split [hi | lo] input mirror");
-        TV s2 = stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
-        ConvOpts os; os.up = up;
+        // a 1x1 conv commutes with the nearest up-sampling in front of it: with up = 2 the shortcut runs on the INPUT grid (a
+        // quarter of the rows) and conv2's epilogue reads it through the up-sampling (ctrl_igemm_desc::res_up) -- bit-identical
+        const bool low = (up == 2) && (Ho % 2 == 0) && (Wo % 2 == 0);
+        TV s2 = stream_alloc(cx, (size_t)N * (low ? H * W : Ho * Wo) * w.Cout, false);
+        ConvOpts os; os.up = low ? 1 : up;
         if (x.lo_off > 0 && !w.shortcut.dup) os.lda = 2 * w.Cin;      // plain conv on a split mirror: the hi half of every row
         TRY(run_conv(cx, w.shortcut, x.m16, s2, N, H, W, os));
         sc = s2;
+        sc_up = low ? 2 : 0;
     }
-    ConvOpts o2; o2.res = sc;
+    ConvOpts o2; o2.res = sc; o2.res_up = sc_up;
     TRY(run_conv(cx, w.conv2, b, out, N, Ho, Wo, o2));
     cx.release(m);
     return 0;

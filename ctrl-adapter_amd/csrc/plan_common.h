@@ -429,6 +429,7 @@ struct ConvOpts {
     long lda = 0;              // row stride of the operand (0 = the conv's Cin); 2*C: a plain conv reading the hi half of split rows
     const float* rowvec = nullptr; int rowvec_ld = 0;
     TV res;
+    int res_up = 0;            // 2: res is the half-resolution map, read through a nearest x2 up-sampling (ctrl_igemm_desc::res_up)
     int act = 0;
 };
 int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int Hin, int Win, const ConvOpts& o);

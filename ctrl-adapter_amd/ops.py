@@ -57,8 +57,10 @@ def pack_vec(v, geglu=False):
 
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
           res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None,
-          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False, scale2=0.0, scale2_from=0):
-    """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L)"""
+          blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False, scale2=0.0, scale2_from=0,
+          res_up=0):
+    """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L); res_up=2: `res` is [N][Hout/2][Wout/2][ldres], read through a
+    nearest x2 up-sampling (conv2d)"""
     d = L.IGemmDesc()
     d.A = A.data_ptr(); d.lda = lda; d.mode = mode; d.Cin = Cin; d.taps = taps
     g = geom or {}
@@ -73,6 +75,7 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.res = res.data_ptr() if res is not None else None
     d.ldres = ldres
     d.res_f32 = int(res is not None and res.dtype == torch.float32)
+    d.res_up = res_up
     d.out16 = out16.data_ptr() if out16 is not None else None
     d.splitk_ws = splitk_ws.data_ptr() if splitk_ws is not None else None
     d.splitk_ws_bytes = splitk_ws.numel() * splitk_ws.element_size() if splitk_ws is not None else 0
@@ -116,7 +119,7 @@ def linear(x, w_packed, bias=None, res=None, geglu=False):
 
 
 def conv2d(x_nhwc, w_packed, Cout, taps=9, stride=1, up=1, bias=None, rowvec=None, res=None, scale=1.0,
-           out_nchw_dtype=None, splitk_ws=None):
+           out_nchw_dtype=None, splitk_ws=None, res_up=0):
     """x [N][H][W][Cin] fp16 -> [N][Ho][Wo][Cout] fp16 (or NCHW in out_nchw_dtype)"""
     N, H, W, Cin = x_nhwc.shape
     pad = 1 if taps == 9 else 0
@@ -131,7 +134,7 @@ def conv2d(x_nhwc, w_packed, Cout, taps=9, stride=1, up=1, bias=None, rowvec=Non
         out = torch.empty(N, Cout, Ho, Wo, dtype=out_nchw_dtype, device=x_nhwc.device)
         segs = [(out, Ho * Wo, 0, Cout, SEG_TRANSPOSED, Ho * Wo)]
     igemm(x_nhwc, Cin, w_packed, M, Cout, Cin, taps=taps, mode=IG_CONV2D, geom=geom, bias=bias, rowvec=rowvec,
-          rows_per_img=Ho * Wo, res=res, ldres=Cout, scale=scale, segs=segs, splitk_ws=splitk_ws)
+          rows_per_img=Ho * Wo, res=res, ldres=Cout, scale=scale, segs=segs, splitk_ws=splitk_ws, res_up=res_up)
     return out
 
 

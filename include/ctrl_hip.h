@@ -95,6 +95,9 @@ typedef struct ctrl_igemm_desc {
     float scale2; int32_t scale2_from;   /* scale2_from > 0: output columns >= scale2_from are multiplied by scale2 instead of scale
                                             (row-major outputs): the K half of a Q|K projection leaves pre-multiplied by
                                             softmax_scale * log2(e) for ctrl_attn_desc::k_prescaled */
+    int32_t res_up;     /* 2: conv2d only -- `res` holds [img][Hout/2][Wout/2][ldres] and is read through a nearest x2 up-sampling
+                           (res[img][oy/2][ox/2]); 0 | 1: res[m*ldres + n] */
+    int32_t pad2_;
     ctrl_igemm_seg seg[3];
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);

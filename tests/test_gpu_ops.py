@@ -121,6 +121,26 @@ def test_conv1x1_upsampled_shortcut(ops, gpu):
     report("conv1x1 up2", rel_inf(out.permute(0, 3, 1, 2), ref))
 
 
+@pytest.mark.parametrize("c,h,n,splitk", [(320, 16, 2, False), (320, 32, 8, True), (640, 8, 3, False)])
+def test_conv3x3_with_half_resolution_residual(ops, gpu, c, h, n, splitk):
+    """ctrl_igemm_desc::res_up = 2 -- the adapter's ResnetBlock2D with up-sampling (model/resnet_block_2d.py:174-184,216): the 1x1
+    shortcut conv commutes with the nearest x2 up-sampling in front of it, so it runs on the input grid and conv2's epilogue
+    (and the split-K finish kernel) reads it as res[n][oy/2][ox/2].  Bit-identical to the full-resolution residual."""
+    x = rnd(n, c, 2 * h, 2 * h, seed=1)                 # conv2's operand (already at the up-sampled resolution)
+    w = rnd(c, c, 3, 3, seed=2, scale=0.02)
+    b = rnd(c, seed=3)
+    r_low = torch.randn(n, h, h, c, generator=torch.Generator().manual_seed(4))      # the shortcut's fp32 output, input grid
+    wp = ops.pack_conv_w(w.to(gpu))
+    xh = x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    r_full = r_low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+    ws = torch.empty(16 * n * 4 * h * h * c, dtype=torch.float32, device=gpu) if splitk else None
+    got = ops.conv2d(xh, wp, c, taps=9, bias=b.to(gpu), res=r_low.to(gpu), res_up=2, splitk_ws=ws)
+    want = ops.conv2d(xh, wp, c, taps=9, bias=b.to(gpu), res=r_full.to(gpu), splitk_ws=ws)
+    assert torch.equal(got, want)
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=1) + r_full.permute(0, 3, 1, 2)
+    report("conv3x3 + up-sampled residual c%d h%d" % (c, 2 * h), rel_inf(got.permute(0, 3, 1, 2), ref))
+
+
 def test_qkv_segments(ops, gpu):
     B, Ltok, K, Cc = 2, 192, 512, 320
     x = rnd(B * Ltok, K, seed=1)
