@@ -80,6 +80,12 @@ class ControlNetModel(ParamTreeModule):
     def _destroy(self, plan):
         L.lib().ctrl_controlnet_destroy(plan)
 
+    def trim(self):
+        """frees the workspace / cache blocks the plan outgrew (they are kept alive for queued launches and captured graphs);
+        synchronises the device -- call between requests, when no graph captured before the last growth will be replayed"""
+        if getattr(self, "_plan", None) is not None:
+            L.check(L.lib().ctrl_controlnet_trim(self._plan))
+
     def _ensure_plan(self):
         if self._plan is None:
             refs, n, keep = self._tensor_refs()

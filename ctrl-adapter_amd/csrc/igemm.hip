@@ -873,6 +873,11 @@ int igemm_splitk_factor(const IGemmArgs& a) {
     int sk = (int)((256 + tiles - 1) / tiles);
     if (sk > 16) sk = 16;
     while (sk > 1 && nk / sk < 16) --sk;
+    // paired split-operand walk: a split covers an EVEN number of k-tiles (a (hi, lo) pair is never cut), so the per-split
+    // count is rounded up to even -- pick sk such that the last split still has work (with nk = 360, sk = 16 the
+    // rounded count 24 left split 15 empty: idle workgroups writing an all-zero slab the finish kernel still read)
+    if (a.a_split == 2)
+        while (sk > 1 && (long)(sk - 1) * ((((nk + sk - 1) / sk) + 1) & ~1) >= nk) --sk;
     return sk;
 }
 namespace {

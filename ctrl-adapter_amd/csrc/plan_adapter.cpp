@@ -742,6 +742,15 @@ int ctrl_adapter_create(const ctrl_adapter_config* cfg, const ctrl_tensor_ref* t
 
 void ctrl_adapter_destroy(ctrl_adapter* h) { delete h; }
 
+int ctrl_adapter_trim(ctrl_adapter* h) {
+    CTRL_CHECK(h, "adapter_trim: null plan");
+    DeviceGuard dg(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    h->arena.trim();
+    h->kvc.trim();
+    return 0;
+}
+
 int ctrl_adapter_text_cache(ctrl_adapter* h, int mode) {
     CTRL_CHECK(h && mode >= 0 && mode <= 2, "adapter_text_cache: mode must be 0 (off), 1 (keep) or 2 (reuse)");
     h->kvc.mode = mode;
@@ -823,6 +832,7 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     cx.f32stream = dry.f32stream;
     cx.stats_total = dry.stats_total;
     cx.kvc = &h->kvc; h->kvc.next = 0;
+    cx.capturing = capturing;
     TRY(adapter_run(cx, h->w, k));
     if (h->kvc.mode == KvCache::KEEP) { h->kvc.key_batch = ehs_batch; h->kvc.key_Lk = Lk; }
     return h->leave(s, capturing);

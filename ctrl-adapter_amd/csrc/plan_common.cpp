@@ -215,7 +215,7 @@ int project_text_kv(Ctx& cx, const AttnW& w, const EhsCtx& e, PreKV* out) {
     half_t* k = nullptr; half_t* vt = nullptr;
     if (cached) {
         KvCache::Slot* sl = nullptr;
-        TRY(cx.kvc->get((size_t)Mk * Ci, (size_t)e.batch * Ci * Lkpad, cx.dry, &sl));
+        TRY(cx.kvc->get((size_t)Mk * Ci, (size_t)e.batch * Ci * Lkpad, cx.dry, &sl, cx.capturing));
         k = sl->k; vt = sl->vt;
     } else {
         k = cx.h((size_t)Mk * Ci);

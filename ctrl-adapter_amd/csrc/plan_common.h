@@ -223,6 +223,13 @@ struct Arena {
         base = nb; cap = need;
         return 0;
     }
+    // frees the retired blocks (ctrl_*_trim): the caller guarantees that no captured graph still addresses them
+    size_t trim() {
+        size_t n = retired.size();
+        for (void* p : retired) (void)hipFree(p);
+        retired.clear();
+        return n;
+    }
 };
 
 // State every plan carries besides its weights: the device it lives on and the stream that used its workspace last.
@@ -281,10 +288,19 @@ struct KvCache {
         for (auto& s : slots) { if (s.k) hipFree(s.k); if (s.vt) hipFree(s.vt); }
         for (void* p : retired) hipFree(p);
     }
-    int get(size_t k_elems, size_t vt_elems, bool dry, Slot** out) {
+    size_t trim() {
+        size_t n = retired.size();
+        for (void* p : retired) (void)hipFree(p);
+        retired.clear();
+        return n;
+    }
+    // `capturing`: the forward is being recorded into a hipGraph -- a KEEP forward that has to allocate cannot be captured
+    int get(size_t k_elems, size_t vt_elems, bool dry, Slot** out, bool capturing = false) {
         if (next >= slots.size()) slots.resize(next + 1);
         Slot& s = slots[next++];
         if (!dry && mode == KEEP && (s.k_elems < k_elems || s.vt_elems < vt_elems)) {
+            CTRL_CHECK(!capturing, "text K/V cache: the first KEEP forward of a shape allocates its buffers and cannot run under "
+                                   "stream capture -- run it eagerly once, then capture (mode REUSE or KEEP with the buffers in place)");
             if (s.k) retired.push_back(s.k);
             if (s.vt) retired.push_back(s.vt);
             s.k = s.vt = nullptr;
@@ -306,6 +322,7 @@ struct Ctx {
     bool f32stream = true;     // residual streams kept in fp32 (set from CTRL_STREAM_F32, default on)
     bool split = false;        // GEMM-operand mirrors of the streams are split [hi | lo] rows (ControlNet, CTRL_CN_SPLIT)
     KvCache* kvc = nullptr;    // text K/V cache of the plan (mode OFF: not used)
+    bool capturing = false;    // the forward is being recorded into a hipGraph (no allocation may happen)
     // pooled GroupNorm statistics (zeroed once per forward with a single memset)
     float* stats_base = nullptr;
     size_t stats_off = 0, stats_total = 0;

@@ -459,6 +459,17 @@ int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_
 
 void ctrl_controlnet_destroy(ctrl_controlnet* h) { delete h; }
 
+int ctrl_controlnet_trim(ctrl_controlnet* h) {
+    CTRL_CHECK(h, "controlnet_trim: null plan");
+    DeviceGuard dg(h->device);
+    HIP_TRY(hipDeviceSynchronize());             // nothing queued still touches a retired block
+    h->arena.trim();
+    h->kvc.trim();
+    for (void* p : h->cond_retired) (void)hipFree(p);
+    h->cond_retired.clear();
+    return 0;
+}
+
 int ctrl_controlnet_text_cache(ctrl_controlnet* h, int mode) {
     CTRL_CHECK(h && mode >= 0 && mode <= 2, "controlnet_text_cache: mode must be 0 (off), 1 (keep) or 2 (reuse)");
     h->kvc.mode = mode;
@@ -518,6 +529,7 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     cx.f32stream = dry.f32stream;
     cx.split = dry.split;
     cx.kvc = &h->kvc; h->kvc.next = 0;
+    cx.capturing = capturing;
     cx.stats_total = dry.stats_total;
     TRY(controlnet_run(cx, h->w, a));
     if (h->kvc.mode == KvCache::KEEP) { h->kvc.key_batch = N; h->kvc.key_Lk = Lk; }

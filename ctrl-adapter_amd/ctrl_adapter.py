@@ -57,6 +57,11 @@ class ControlNetAdapter(ParamTreeModule):
     def _destroy(self, plan):
         L.lib().ctrl_adapter_destroy(plan)
 
+    def trim(self):
+        """frees the workspace / cache blocks the plan outgrew (see ControlNetModel.trim)"""
+        if getattr(self, "_plan", None) is not None:
+            L.check(L.lib().ctrl_adapter_trim(self._plan))
+
     def _ensure_plan(self):
         if self._plan is None:
             refs, n, keep = self._tensor_refs()

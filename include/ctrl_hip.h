@@ -280,6 +280,13 @@ int ctrl_adapter_forward_scatter(ctrl_adapter* h,
 int ctrl_controlnet_text_cache(ctrl_controlnet* h, int mode);
 int ctrl_adapter_text_cache(ctrl_adapter* h, int mode);
 
+/* ---- Workspace hygiene.  A plan's workspace, text K/V buffers and conditioning cache grow by RETIRING the outgrown block
+ * (never freeing it inside a forward: queued launches and captured hipGraphs keep valid addresses), so a server that sees
+ * ever larger shapes keeps the sum of the earlier sizes.  ctrl_*_trim synchronises the device and frees the retired blocks;
+ * call it when no captured graph that was recorded before the last growth will be replayed again. */
+int ctrl_controlnet_trim(ctrl_controlnet* h);
+int ctrl_adapter_trim(ctrl_adapter* h);
+
 /* ---- One clip split across GPUs by frames (BASELINE.json config 4 with clips < GPUs).
  * Every rank holds Fl = F / world consecutive frames of every clip: `N` = clips * Fl LOCAL frames (frame-major, rank r
  * owns frames [r*Fl, (r+1)*Fl) of each clip), num_frames = Fl.  All ops of the adapter are per frame except three, and

@@ -429,7 +429,7 @@ def test_video_chain_at_benched_shapes_vs_oracle(P, gpu):
     assert max(e_cn) <= TOL and max(e_chain) <= TOL_CHAIN
 
 
-@pytest.mark.parametrize("world,a2a", [(2, True), (4, True), (2, False), (4, False)])
+@pytest.mark.parametrize("world,a2a", [(2, True), (4, True), (4, False)])
 def test_clip_sharded_adapter_equals_unsharded(P, gpu, world, a2a):
     """SURVEY.md 8e row 2 / BASELINE config 4 with fewer clips than GPUs: ONE clip's frames sharded over `world` ranks.
     Virtual ranks = threads of this process on one GPU (each with its own plan, stream and exchange workspace; the
@@ -474,11 +474,12 @@ def test_clip_sharded_adapter_equals_unsharded(P, gpu, world, a2a):
     print("PARITY clip-sharded (%d ranks x %d frames, %s, %.1f MB sent per rank) vs unsharded rel_inf: %s" %
           (world, F_ // world, form, comms[0].bytes_sent / 1e6, " ".join("%.1e" % e for e in errs)))
     assert max(errs) <= 5e-4
-    oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=33)
-    ro, rom = oa(downs, mid_block_res_sample=mid, num_frames=F_, timestep=t, encoder_hidden_states=e_img)
-    eo = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ro) + [rom])]
-    print("PARITY clip-sharded (%d ranks, %s) vs oracle rel_inf: %s" % (world, form, " ".join("%.2e" % e for e in eo)))
-    assert max(eo) <= TOL_ADAPTER
+    if world == 4:       # (one oracle pass per form is enough: the 2-rank case is held to the unsharded forward above)
+        oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=33)
+        ro, rom = oa(downs, mid_block_res_sample=mid, num_frames=F_, timestep=t, encoder_hidden_states=e_img)
+        eo = [rel_inf(a, b) for a, b in zip(got + [got_mid], list(ro) + [rom])]
+        print("PARITY clip-sharded (%d ranks, %s) vs oracle rel_inf: %s" % (world, form, " ".join("%.2e" % e for e in eo)))
+        assert max(eo) <= TOL_ADAPTER
 
 
 def test_text_kv_cache_and_discard_when_off(P, controlnet, gpu):
@@ -519,6 +520,26 @@ def test_text_kv_cache_and_discard_when_off(P, controlnet, gpu):
     finally:
         controlnet.cache_text = ad.cache_text = False
     assert all(torch.equal(a, b) for a, b in zip(run(ts[1])[:13], ref[1][:13]))      # cache off again: same results
+    # a KEEP forward that must allocate cannot be recorded into a hipGraph -- refused with a message, not a crash
+    ad2 = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+    d0, _ = controlnet(sample, ts[0], ehs, cond, return_dict=False)
+    ad2(d0, num_frames=1, timestep=ts[0], encoder_hidden_states=ehs_a)                # plan + workspace exist, cache buffers do not
+    ad2.cache_text = True
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="stream capture"):
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                ad2(d0, num_frames=1, timestep=ts[0], encoder_hidden_states=ehs_a)
+    torch.cuda.synchronize()
+    ad2.cache_text = False
+    # growing shapes retire workspace blocks; trim() frees them and the next forward still reproduces the result
+    big = [torch.cat([x, x]) for x in d0]
+    ad2(big, num_frames=1, timestep=ts[0], encoder_hidden_states=torch.cat([ehs_a, ehs_a]))
+    ad2.trim(); controlnet.trim()
+    o_after, _ = ad2(d0, num_frames=1, timestep=ts[0], encoder_hidden_states=ehs_a)
+    assert all(torch.equal(a, b) for a, b in zip(o_after, ref[0][13:]))
     # separate calls leave REUSE in the plans; a fused step with ANOTHER prompt of the same shape must not read the
     # old prompt's K / V^T (controlled_step now sets the cache modes from its own tensors)
     ehs2 = (ehs * 0.5 + 0.25).contiguous()
