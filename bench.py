@@ -362,6 +362,7 @@ def main():
                   "bound": 1e-3, "ok": bool(worst <= 1e-3 and zeros_ok),
                   "what": "HIP step (these plans, these %d distinct inputs) vs fp32 oracle -> oracle chain" % n}
 
+    out = None
     if rank == 0:
         flops_step = step_flops(w, n)       # this rank's share (clip split: N / world frames)
         if kernels or per_kernel:
@@ -394,7 +395,18 @@ def main():
         if len(out) > 2000:                          # the driver keeps an 8 KB tail of stdout: the headline must fit
             line.pop("next_kernels", None)
             out = json.dumps(line)
-        sys.stdout.flush()
+    # The headline must be the LAST thing on stdout.  Libraries write there through C stdio, which is block-buffered on a
+    # pipe and flushed at process exit -- RCCL prints a version banner that way when its first communicator is created, and
+    # it landed AFTER the JSON line of the first --clip-split run.  So: every rank pushes its C stdio out, all ranks meet, and
+    # only then rank 0 prints.
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    dp.barrier(sync_cuda=False)
+    if rank == 0:
         print(out, flush=True)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

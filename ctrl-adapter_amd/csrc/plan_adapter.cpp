@@ -780,6 +780,11 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     DeviceGuard dg(h->device);
     bool capturing = false;
     TRY(h->enter(s, &capturing));
+    // a KEEP forward that still has to allocate its text K/V buffers cannot be recorded into a hipGraph: refuse up front,
+    // before any lane is forked (an error in the middle of a capture leaves unjoined streams behind)
+    CTRL_CHECK(!(capturing && h->kvc.mode == KvCache::KEEP && h->kvc.slots.empty()),
+               "text K/V cache: the first KEEP forward allocates its buffers and cannot run under stream capture -- run it "
+               "eagerly once, then capture");
     const int* map_dev = nullptr;
     if (frame_pos) {
         CTRL_CHECK(N_out >= N && N_out <= ctrl_adapter::kMaxMap, "adapter_forward_scatter: need N <= N_out <= 1024");

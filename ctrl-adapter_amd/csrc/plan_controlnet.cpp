@@ -484,6 +484,11 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     DeviceGuard dg(h->device);
     bool capturing = false;
     TRY(h->enter(s, &capturing));
+    // a KEEP forward that still has to allocate its text K/V buffers cannot be recorded into a hipGraph: refuse up front,
+    // before any lane is forked (an error in the middle of a capture leaves unjoined streams behind)
+    CTRL_CHECK(!(capturing && h->kvc.mode == KvCache::KEEP && h->kvc.slots.empty()),
+               "text K/V cache: the first KEEP forward allocates its buffers and cannot run under stream capture -- run it "
+               "eagerly once, then capture");
     CTRL_CHECK(N >= 1 && N <= 4096 && Hs >= 1 && Ws >= 1 && Lk >= 1, "controlnet_forward: bad sizes");
     CTRL_CHECK(Hs % 8 == 0 && Ws % 8 == 0, "controlnet_forward: latent height/width must be multiples of 8 (3 stride-2 stages)");
     CTRL_CHECK(t_count == 1 || t_count == N, "controlnet_forward: need 1 or N timesteps");

@@ -523,7 +523,8 @@ def test_text_kv_cache_and_discard_when_off(P, controlnet, gpu):
     # a KEEP forward that must allocate cannot be recorded into a hipGraph -- refused with a message, not a crash
     ad2 = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
     d0, _ = controlnet(sample, ts[0], ehs, cond, return_dict=False)
-    ad2(d0, num_frames=1, timestep=ts[0], encoder_hidden_states=ehs_a)                # plan + workspace exist, cache buffers do not
+    t_dev = ts[0].to(gpu)                      # (a host timestep would be an H2D copy inside the capture)
+    ad2(d0, num_frames=1, timestep=t_dev, encoder_hidden_states=ehs_a)                # plan + workspace exist, cache buffers do not
     ad2.cache_text = True
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -531,7 +532,7 @@ def test_text_kv_cache_and_discard_when_off(P, controlnet, gpu):
     with pytest.raises(RuntimeError, match="stream capture"):
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
-                ad2(d0, num_frames=1, timestep=ts[0], encoder_hidden_states=ehs_a)
+                ad2(d0, num_frames=1, timestep=t_dev, encoder_hidden_states=ehs_a)
     torch.cuda.synchronize()
     ad2.cache_text = False
     # growing shapes retire workspace blocks; trim() frees them and the next forward still reproduces the result
