@@ -24,11 +24,11 @@
 
 namespace {
 
-enum { AO_NEGM = 1, AO_SGB = 2, AO_PRIO = 4, AO_DEFER = 8, AO_MINI = 16, AO_DEFER8 = 32 };
+enum { AO_NEGM = 1, AO_SGB = 2, AO_PRIO = 4, AO_DEFER = 8, AO_MINI = 16, AO_DEFER8 = 32, AO_VPRIO = 64 };
 
 template <int QB, int NW, int OPT, int NSTAGE = 3>
 __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_kernel(AttnArgs a, const half_t* zeros) {
-    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth 2 or 3");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth 2 .. 4");
     constexpr int TILEB = 64 * 64 * 2;                 // bytes of one K (or V^T) tile
     constexpr int VOFF = NSTAGE * TILEB;               // V^T ring behind the K ring
     constexpr int PASSES = 512 / (NW * 64);            // 16-byte chunks of a tile per lane
@@ -161,6 +161,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
                     }
                 }
             if constexpr (OPT & AO_PRIO) __builtin_amdgcn_s_setprio(0);
+            if constexpr (OPT & AO_VPRIO) __builtin_amdgcn_s_setprio(1);     // the softmax section wins the VALU arbitration
             // register r of block mb holds key  kt0 + 32*mb + 16*(r>>3) + 8*hi + (r&7)
             // ---- online softmax (exp2 domain; sacc = s - m_run already) ----
             h8 pf[QB][KB][2];
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
             }
 
             // ---- O^T += V^T . P^T ----
+            if constexpr (OPT & AO_VPRIO) __builtin_amdgcn_s_setprio(0);
             if constexpr (OPT & AO_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mi = 0; mi < KB; ++mi)
@@ -244,6 +246,16 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
         }
         if (t < ntiles) { tile(std::integral_constant<int, 0>{}, t); ++t; }
         if (t < ntiles) { tile(std::integral_constant<int, 1>{}, t); ++t; }
+    } else if constexpr (NSTAGE == 4) {
+        for (; t + 4 <= ntiles; t += 4) {
+            tile(std::integral_constant<int, 0>{}, t);
+            tile(std::integral_constant<int, 1>{}, t + 1);
+            tile(std::integral_constant<int, 2>{}, t + 2);
+            tile(std::integral_constant<int, 3>{}, t + 3);
+        }
+        if (t < ntiles) { tile(std::integral_constant<int, 0>{}, t); ++t; }
+        if (t < ntiles) { tile(std::integral_constant<int, 1>{}, t); ++t; }
+        if (t < ntiles) { tile(std::integral_constant<int, 2>{}, t); ++t; }
     } else {
         for (; t + 2 <= ntiles; t += 2) {
             tile(std::integral_constant<int, 0>{}, t);
@@ -658,6 +670,9 @@ int op_flash_attn_d64(const AttnArgs& a, hipStream_t s, int variant) {
         case 9: return launch_d64p<AO_DEFER>(a, s);
         case 10: return launch_d64p<AO_MINI | AO_DEFER>(a, s);
         case 11: return launch_d64<1, 8, AO_MINI | AO_NEGM | AO_DEFER>(a, s);
+        case 12: return launch_d64<1, 8, AO_DEFER, 4>(a, s);
+        case 13: return launch_d64<2, 8, AO_DEFER>(a, s);
+        case 14: return launch_d64<1, 8, AO_DEFER | AO_VPRIO>(a, s);
         default: CTRL_FAIL("flash_attn: unknown variant " + std::to_string(variant));
     }
 }

@@ -255,7 +255,7 @@ def test_flash_attn_d64_variants(ops, gpu):
     vt = v.half().permute(0, 2, 1).contiguous()
     ks = (k * (1.4426950408889634 / math.sqrt(D))).half()
     try:
-        for variant in range(0, 12):
+        for variant in range(0, 15):
             ops.set_attn_variant(variant)
             out = ops.flash_attn(q.half().reshape(B * L, Cc).to(gpu), Cc, ks.reshape(B * L, Cc).to(gpu), Cc, vt.to(gpu), L,
                                  B, heads, D, L, L, k_prescaled=True)

@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
     if (argc > 2) {
         for (char* tok = strtok(argv[2], ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
     } else {
-        for (int v = 0; v <= 11; ++v) variants.push_back(v);
+        for (int v = 0; v <= 14; ++v) variants.push_back(v);
     }
     hipStream_t st;
     CK(hipStreamCreate(&st));
