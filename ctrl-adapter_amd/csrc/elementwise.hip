@@ -228,6 +228,28 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(const void* __restrict_
     }
 }
 
+// y = x + v[idx(row)], rows ordered (clip, frame, pixel) [(b f p)], idx = (b*L + p) % B: the reference hands the temporal
+// transformer a time context ordered (pixel, clip) -- broadcast_to(h*w, batch, 1, C).reshape(h*w*batch, 1, C),
+// model/adapter_spatial_temporal.py:246-249 -- while diffusers' TemporalBasicTransformerBlock orders its rows (clip, pixel):
+// row i = b*L + p of the block attends context row i, which is clip i % B.  With one key per row the cross-attention term is
+// that clip's to_out(to_v(context)) vector.
+__global__ __launch_bounds__(256) void add_rowvec_clip_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ v, long ldv,
+                                                              void* __restrict__ y, int y_dt, size_t nchunks, int C, int F, int L, int B) {
+    const int lpr = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / lpr;
+        const int c0 = (int)(i - row * lpr) * 8;
+        const size_t b = row / ((size_t)F * L), p = row % L;
+        const size_t idx = (b * L + p) % B;
+        float a[8];
+        ld8(x, i, x_dt, a);
+        const float* vp = v + idx * ldv + c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += vp[j];
+        st8(y, i, y_dt, a);
+    }
+}
+
 struct MergeArgs {
     const void* x[8];
     int widx[8];
@@ -412,6 +434,13 @@ int op_add_rowvec(const void* x, int x_dt, const float* v, long ldv, void* y, in
     CTRL_CHECK(x_dt != DT_BF16 && y_dt != DT_BF16, "add_rowvec: fp16 / fp32 only");
     const size_t nch = M * (size_t)(C / 8);
     LAUNCH("add_rowvec", add_rowvec_kernel, dim3(grid_for(nch)), dim3(256), 0, s, x, x_dt, v, ldv, y, y_dt, nch, C, rows_per_img, vmod);
+    return 0;
+}
+int op_add_rowvec_clip(const void* x, int x_dt, const float* v, long ldv, void* y, int y_dt, int B, int F, int L, int C, hipStream_t s) {
+    CTRL_CHECK(C % 8 == 0, "add_rowvec_clip: C must be a multiple of 8");
+    CTRL_CHECK(x_dt != DT_BF16 && y_dt != DT_BF16, "add_rowvec_clip: fp16 / fp32 only");
+    const size_t nch = (size_t)B * F * L * (size_t)(C / 8);
+    LAUNCH("add_rowvec_clip", add_rowvec_clip_kernel, dim3(grid_for(nch)), dim3(256), 0, s, x, x_dt, v, ldv, y, y_dt, nch, C, F, L, B);
     return 0;
 }
 int op_upsample2x_nhwc(const half_t* x, half_t* y, int N, int H, int W, int C, hipStream_t s) {

@@ -90,6 +90,8 @@ int op_linear_small_group(const SmallLin* probs, int count, hipStream_t s);
 int op_blend(const void* x_spatial, int xs_dt, const void* x_temporal, int xt_dt, const float* mix_factor, void* y, int y_dt, size_t n, hipStream_t s);
 // y[m][c] = x[m][c] + v[(m / rows_per_img) % vmod][c]   (fp32 per-image vector broadcast add)
 int op_add_rowvec(const void* x, int x_dt, const float* v, long ldv, void* y, int y_dt, size_t M, int C, int rows_per_img, int vmod, hipStream_t s);
+// rows (clip, frame, pixel): y = x + v[(b*L + p) % B]  (per-clip time context of the temporal transformer, see the kernel)
+int op_add_rowvec_clip(const void* x, int x_dt, const float* v, long ldv, void* y, int y_dt, int B, int F, int L, int C, hipStream_t s);
 // nearest x2 up-sampling of an NHWC fp16 map
 int op_upsample2x_nhwc(const half_t* x, half_t* y, int N, int H, int W, int C, hipStream_t s);
 // fill fp16/any

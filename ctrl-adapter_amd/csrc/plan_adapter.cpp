@@ -229,7 +229,7 @@ int precompute_small(Ctx& cx, const ctrl_adapter_config& c, const std::vector<co
             auto one_key = [&](const AttnW& w, const EhsCtx& e, std::vector<float*>* dst) {
                 float* v = cx.f((size_t)e.batch * w.inner);
                 float* o = cx.f((size_t)e.batch * INNER);
-                L1.push_back({e.f32, e.cross, w.v.w, nullptr, v, w.inner, e.batch, w.inner, e.cross, 0, 0});
+                L1.push_back({e.f32, e.row_ld ? e.row_ld : (long)e.cross, w.v.w, nullptr, v, w.inner, e.batch, w.inner, e.cross, 0, 0});
                 L2.push_back({v, w.inner, w.out.w, w.out.b, o, INNER, e.batch, INNER, w.inner, 0, 0});
                 dst->push_back(o);
             };
@@ -339,7 +339,13 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
     // (note N5), added by the out-projection's epilogue.  Rows are (b f p) and the context is the broadcast vector or
     // the first frame of the only clip: the same vector for every row.
     TV x2 = stream_alloc(cx, (size_t)M * dim, false);
-    TRY(run_linear(cx, w.attn1.out, o, Ci, x2, dim, M, x0, dim, ov, dim, M, nullptr, TV(), &w.norm3, xn));
+    if (a.e_first.batch > 1) {
+        // one context per clip: the vector of row (b f p) is the one of clip (b*L + p) % B (the reference's pairing, see
+        // add_rowvec_clip_kernel); it joins the residual before the out-projection adds it
+        RUN(cx, op_add_rowvec_clip(x0.p, x0.dt, ov, dim, x0.p, x0.dt, a.B, a.F, L, dim, cx.s));
+        ov = nullptr;
+    }
+    TRY(run_linear(cx, w.attn1.out, o, Ci, x2, dim, M, x0, dim, ov, ov ? dim : 0, ov ? M : 0, nullptr, TV(), &w.norm3, xn));
     // x = ff(norm3(x)) + x
     half_t* mid2 = mid;
     TRY(run_linear(cx, w.ff1, xn, dim, tv16(mid2), 4 * dim, M, TV(), 0));
@@ -616,12 +622,15 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     }
     if (c.add_temporal_transformer) {
         // time_context = first frame of each clip (:246-249).  With broadcast encoder states (batch 1, what the
-        // pipelines pass) every clip shares it; per-sample states are supported for a single clip only, because the
-        // reference pairs (pixel, clip) rows in a different order for >1 clip (see DESIGN.md "known quirks").
+        // pipelines pass) every clip shares it.  Per-sample states: one context row per clip (row b*F of the states); with
+        // more than one clip the reference hands them to the block ordered (pixel, clip) while the block's rows are
+        // (clip, pixel) -- reproduced by op_add_rowvec_clip in run_temporal_tb (DESIGN.md "known quirks").
         CTRL_CHECK(k.Lk == 1, "adapter: the temporal transformer path requires single-token encoder_hidden_states");
-        CTRL_CHECK(k.ehs_batch == 1 || a.B == 1, "adapter: per-sample encoder_hidden_states with >1 clip is not supported");
+        CTRL_CHECK(k.ehs_batch == 1 || !k.comm,
+                   "adapter: a frame-sharded clip needs broadcast encoder_hidden_states ([1,1,C]): the first frame's context lives on one rank");
         a.e_first = a.e;
-        a.e_first.batch = 1;       // row 0 = first frame of the (only) clip, or the broadcast vector
+        a.e_first.batch = k.ehs_batch == 1 ? 1 : a.B;      // row b = first frame of clip b, or the broadcast vector
+        a.e_first.row_ld = (long)a.F * cross;
     }
     // SD-1.5 pyramid below (H0, W0)
     static const int slot_c[12] = {320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280};

@@ -463,7 +463,8 @@ int run_linear(Ctx& cx, const Lin& l, const half_t* x, long ldx, const TV& y, lo
 int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int H, int W, int up,
                const float* temb_proj, int temb_ld, float eps);
 // Encoder-hidden-state context prepared once per forward: fp16 copy [B*Lk][cross] (+ fp32 copy when Lk == 1)
-struct EhsCtx { const half_t* h16 = nullptr; const float* f32 = nullptr; int batch = 1, Lk = 0, cross = 0; };
+struct EhsCtx { const half_t* h16 = nullptr; const float* f32 = nullptr; int batch = 1, Lk = 0, cross = 0;
+                long row_ld = 0;   /* floats between the batch rows of f32 (0 = dense, Lk * cross) */ };
 // K / V^T projections of the text states of one cross-attention, computed ahead of the block that uses them (they depend
 // on encoder_hidden_states only): project_text_kv enqueues the two GEMMs on cx.s (or takes the plan's text cache)
 struct PreKV { half_t* k = nullptr; half_t* vt = nullptr; };

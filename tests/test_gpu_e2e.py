@@ -246,6 +246,38 @@ def test_fourteen_frames_and_single_clip_per_sample_context(P, gpu):
         assert out[i].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("clips,frames", [(2, 4), (3, 2)])
+def test_per_sample_context_with_several_clips(P, gpu, clips, frames):
+    """Per-frame encoder states with MORE than one clip: the temporal transformer's time context is the first frame of each
+    clip, handed over ordered (pixel, clip) while the block's rows are (clip, pixel)
+    (model/adapter_spatial_temporal.py:246-249) -- row b*hw + p attends the context of clip (b*hw + p) % clips.  The oracle
+    restates that line for line; 3 clips on 64 pixels makes the pairing differ from every simpler rule (64 % 3 != 0), and
+    the clips' contexts differ by construction."""
+    from oracle.adapter import ControlNetAdapterOracle
+    torch.set_grad_enabled(False)
+    N = clips * frames
+    cfg = dict(cases.ADAPTER_VIDEO)
+    cfg.update(add_adapter_location_B=False, add_adapter_location_C=False, add_adapter_location_D=False, add_adapter_location_M=False)
+    ad = seeded_init(P.ControlNetAdapter(**cfg), seed=36).to(gpu)
+    oa = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=36)
+    downs, _ = cases.pyramid_inputs(N=N, h0=8, seed=810, with_mid=False)
+    ehs = seeded_tensor((N, 1, 1024), 811)
+    ehs = ehs * (1.0 + torch.arange(N).div(frames, rounding_mode="floor").view(N, 1, 1))      # clip b scaled by (1 + b)
+    ts = torch.full((N,), 500.0)
+    out, _ = ad([d.half().to(gpu) for d in downs], num_frames=frames, timestep=ts.to(gpu), encoder_hidden_states=ehs.half().to(gpu))
+    ro, _ = oa(downs, num_frames=frames, timestep=ts, encoder_hidden_states=ehs.half().float())
+    errs = [rel_inf(a, b) for a, b in zip(out[:3], ro[:3])]
+    # the pairing matters at this tolerance: running the clips one by one (every row of a clip gets its OWN clip's context,
+    # which is NOT what the reference computes for a batch of clips) lands far outside it
+    sep = [ad([d[b * frames:(b + 1) * frames].half().to(gpu) for d in downs], num_frames=frames, timestep=ts[:frames].to(gpu),
+              encoder_hidden_states=ehs[b * frames:(b + 1) * frames].half().to(gpu))[0] for b in range(clips)]
+    sens = max(rel_inf(torch.cat([sep[b][i] for b in range(clips)]), out[i]) for i in range(3))
+    print("PARITY %d clips x %d frames, per-sample context rel_inf: %s (vs clips run one by one: %.2e)"
+          % (clips, frames, " ".join("%.2e" % e for e in errs), sens))
+    assert sens > 1e-2
+    assert max(errs) <= 1e-3
+
+
 def test_sparse_to_dense_scatter_and_clip_layout(P, gpu):
     """SURVEY.md 8f row 1 (residual hand-over to the UNet): writing the adapter results straight into the dense
     `(bs nf)` frame grid and returning `bs c nf h w` views must equal, bit for bit, what the pipelines build with
