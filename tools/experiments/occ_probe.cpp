@@ -39,6 +39,22 @@ int main(int argc, char** argv) {
         hipMemcpy(dst, h.data(), n * 2, hipMemcpyHostToDevice);
     };
     const char* names[4] = {"Q = K = V = 0", "Q, K random, V = 0", "Q = K = 0, V random", "Q, K, V random"};
+    if (argc > 4 && !strcmp(argv[2], "loop")) {      // occ_probe out.txt loop <cfg 0|3> <launches>: a long run to read the clocks beside
+        const int c = atoi(argv[3]), n = atoi(argv[4]);
+        if (c & 1) { fill(q, (size_t)B * LqMax * C, 1.f, 1); fill(kk, (size_t)B * Lk * C, 0.18f, 2); }
+        if (c & 2) fill(v, (size_t)B * Lk * C, 1.f, 3);
+        ctrl_attn_desc d; memset(&d, 0, sizeof d);
+        d.Q = q; d.ldq = C; d.K = kk; d.ldk = C; d.Vt = v; d.Lkpad = Lk; d.kvB = B; d.O = out; d.ldo = C;
+        d.B = B; d.heads = H; d.D = 64; d.Lq = 32768; d.Lk = Lk; d.scale = 0.125f; d.k_prescaled = 1;
+        hipEventRecord(e0, st);
+        for (int i = 0; i < n; ++i) ctrl_op_flash_attn(&d, st);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        snprintf(buf, sizeof buf, "loop %-18s %d launches %.1f ms  %.1f TFLOP/s\n", names[c & 3], n, ms, 4.0 * B * H * 32768.0 * Lk * 64 * n / ms * 1e-9);
+        say(buf);
+        if (f) fclose(f);
+        return 0;
+    }
     for (int cfg = 0; cfg < 5; ++cfg) {
         const int c = cfg % 4;
         if (c & 1) { fill(q, (size_t)B * LqMax * C, 1.f, 1); fill(kk, (size_t)B * Lk * C, 0.18f, 2); }

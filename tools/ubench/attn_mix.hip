@@ -14,6 +14,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 #define MFMA(acc) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define MFMA16(acc4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4) : "v"(a), "v"(b))
 #define EXP(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
 #define CVT(d, x, y) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "+v"(d) : "v"(x), "v"(y))
 #define MAX3(d, x, y) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(d) : "v"(x), "v"(y))
@@ -43,7 +44,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int i = 0; i < 2; ++i) ld[i] = f4v{0.f, 0.f, 0.f, 0.f};
     h8 a = {1, 1, 1, 1, 1, 1, 1, 1}, b = a;
     f16v acc[4] = {{0}, {0}, {0}, {0}};
-    if (MODE == 9 || MODE == 11) {       // pseudo-random operands (what real activations look like to the multipliers)
+    f4v acc16[8];
+    for (int k = 0; k < 8; ++k) acc16[k] = f4v{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 9 || MODE == 11 || MODE == 13) {       // pseudo-random operands (what real activations look like to the multipliers)
         unsigned h = (threadIdx.x + 1u) * 2654435761u + blockIdx.x * 40503u;
         for (int i = 0; i < 8; ++i) {
             h = h * 1664525u + 1013904223u; a[i] = (_Float16)(((int)(h >> 16) & 4095) - 2048) * (_Float16)0.0007f;
@@ -55,7 +58,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (MODE == 10) { for (int i = 0; i < 8; ++i) { a[i] = 0; b[i] = 0; } }
     const unsigned addr = (threadIdx.x & 511) * 16;
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 0 || MODE == 9 || MODE == 10) {
+        if (MODE == 12 || MODE == 13) {      // the same FLOPs through the 16x16x32 instruction (the GEMM family's): 32 of them
+#pragma unroll
+            for (int k = 0; k < 32; ++k) MFMA16(acc16[k & 7]);
+        } else if (MODE == 0 || MODE == 9 || MODE == 10) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) MFMA(acc[k & 3]);
         } else if (MODE == 1) {
@@ -113,6 +119,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(m[i]));
     for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(t[i])); asm volatile("" ::"v"(pk[i])); }
     for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ld[i]));
+    for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(acc16[k]));
     float s = 0;
     for (int k = 0; k < 4; ++k) {
         asm volatile("" : "+v"(acc[k]));
@@ -164,6 +171,14 @@ int main(int argc, char** argv) {
         run<2>("2: 16 MFMA + 99 VALU interleaved, operands = 1.0", 2, out, base);
         run<11>("11: 16 MFMA + 99 VALU interleaved, pseudo-random operands", 2, out, base);
         run<0>("0: again", 2, out, base);
+        run<12>("12: 32 MFMA 16x16x32 alone (same FLOPs), operands = 1.0", 2, out, base);
+        run<13>("13: 32 MFMA 16x16x32 alone, pseudo-random operands", 2, out, base);
+        // how long a launch has to be for the clock to come down: the random-operand stream at 1/10 and 1/100 of the length
+        for (int div : {10, 100}) {
+            g_iters = atoi(argv[2]) / div;
+            const float b2 = run<0>(div == 10 ? "0: operands = 1.0, launch 1/10 as long" : "0: operands = 1.0, launch 1/100 as long", 2, out, 0.f);
+            run<9>(div == 10 ? "9: pseudo-random, launch 1/10 as long" : "9: pseudo-random, launch 1/100 as long", 2, out, b2);
+        }
         if (g_out) fclose(g_out);
         return 0;
     }
