@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the slowest tests in every summary: the GPU suite is dominated by the fp32 CPU oracle at full size, and the driver
+    # gives it a fixed wall-clock budget
+    if getattr(config.option, "durations", None) is None:
+        config.option.durations = 10
+        config.option.durations_min = 5.0
 
 
 def rel_inf(a, b):
