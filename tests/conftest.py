@@ -24,6 +24,15 @@ def rel_inf(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """the fp32 PyTorch oracle is fastest on <= 32 host threads (bench.py's cpu_baseline leg measured it: more threads
+    oversubscribe the memory system of the GPU box); the GPU suite spends most of its wall time in it"""
+    import torch
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    yield
+
+
 @pytest.fixture(scope="session")
 def gpu():
     import torch
