@@ -1,0 +1,100 @@
+"""The measurement tools that turn rocprofv3 output into the numbers bench.py quotes (`roofline.traffic`) -- run here on a
+small synthetic counter dump: symbol spelling, the gfx950 FETCH_SIZE x2 correction, per-launch division, and the join of
+counter rows with the library's per-launch dump by position inside a step.  CPU only."""
+import csv
+import importlib.util
+import json
+import os
+import sys
+
+from helpers import ROOT
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ATTN = "_ZN12_GLOBAL__N_121flash_attn_d64_kernelILi1ELi8ELi8ELi3EEEv14ctrl_attn_descPKDF16_"
+GEMM = "_ZN12_GLOBAL__N_112igemm_kernelILi256ELi128ELi32ELi4ELi2ELi3ELi0ELb1EEEv15ctrl_igemm_desciiPKDF16_ii"
+POOL = "_ZN12_GLOBAL__N_114avgpool_kernelEPKvPvii"
+
+
+def test_symbol_spelling_matches_the_library_profiler():
+    t = _load("pmc_traffic")
+    assert t.symbol_of(ATTN) == "flash_attn_d64_kernel<1, 8, 8, 3>"
+    assert t.symbol_of(GEMM) == "igemm_kernel<256, 128, 32, 4, 2, 3, 0, true>"
+    assert t.symbol_of("void (anonymous namespace)::igemm_kernel<256,128,32,4,2,3,0,true>(ctrl_igemm_desc, int)") == \
+        "igemm_kernel<256, 128, 32, 4, 2, 3, 0, true>"
+    assert t.symbol_of(POOL) == "avgpool_kernel"
+    assert t.kernel_class(GEMM) == "igemm_rows" and t.kernel_class(ATTN) == "flash_attn"
+    assert t.kernel_class("some_torch_elementwise_kernel") is None        # torch's own kernels are not counted
+
+
+def _write_pass(directory, counter, steps):
+    os.makedirs(os.path.join(directory, "host", "1"), exist_ok=True)
+    with open(os.path.join(directory, "host", "1", "1_counter_collection.csv"), "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=["Dispatch_Id", "Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"])
+        wr.writeheader()
+        did = 0
+        for st in steps:
+            for name, grid, val in st:
+                did += 1
+                wr.writerow(dict(Dispatch_Id=did, Kernel_Name=name, Grid_Size=grid, Counter_Name=counter, Counter_Value=val))
+                wr.writerow(dict(Dispatch_Id=did, Kernel_Name=name, Grid_Size=grid, Counter_Name="OTHER", Counter_Value=1e9))
+
+
+def test_traffic_json_from_a_synthetic_counter_dump(tmp_path, monkeypatch, capsys):
+    t = _load("pmc_traffic")
+    # two steps: avgpool, the self-attention (1000 KiB fetched as reported, 300 KiB written), the cross-attention launch of the
+    # SAME symbol and grid (10 / 30 KiB), one GEMM; a torch kernel in between is ignored
+    def step(f_or_w):
+        a, c, g = ((1000.0, 10.0, 400.0) if f_or_w == "F" else (300.0, 30.0, 800.0))
+        return [(POOL, 4096, 1.0), (ATTN, 1310720, a), ("at_native_copy_kernel", 64, 7777.0), (ATTN, 1310720, c), (GEMM, 524288, g)]
+    fdir, wdir = str(tmp_path / "f"), str(tmp_path / "w")
+    _write_pass(fdir, "FETCH_SIZE", [step("F"), step("F")])
+    _write_pass(wdir, "WRITE_SIZE", [step("W"), step("W")])
+    tsv = tmp_path / "launches.tsv"
+    with open(tsv, "w") as fh:
+        for _ in range(2):
+            fh.write("0\t0\t0\t\tavgpool_kernel\t0.01\n")
+            fh.write("0\t0\t0\tB8 h5 D64 Lq16384 Lk16384\tflash_attn_d64_kernel<1, 8, 8, 3>\t2.7\n")
+            fh.write("0\t0\t0\tB8 h5 D64 Lq16384 Lk77\tflash_attn_d64_kernel<1, 8, 8, 3>\t0.06\n")
+            fh.write("0\t0\t0\tM131072 N4096 K512 taps1 geglu\tigemm_kernel<256, 128, 32, 4, 2, 3, 0, true>\t0.77\n")
+    out = tmp_path / "traffic.json"
+    monkeypatch.setattr(sys, "argv", ["pmc_traffic.py", fdir, wdir, "2", str(out), str(tsv)])
+    t.main()
+    capsys.readouterr()
+    doc = json.load(open(out))
+    # per class: FETCH x2 + WRITE, KiB -> bytes, per step / per launch
+    fa = doc["classes"]["flash_attn"]
+    assert fa["launches_per_step"] == 2.0
+    assert fa["hbm_bytes_per_step_corrected"] == round((2 * 1010.0 + 330.0) * 1024)
+    assert doc["classes"]["igemm_rows"]["hbm_bytes_per_launch_corrected"] == round((2 * 400.0 + 800.0) * 1024)
+    assert "avgpool" in doc["classes"] and len(doc["classes"]) == 3
+    # per (symbol, grid): the two attention launches cannot be told apart ...
+    k = doc["kernels"]["flash_attn_d64_kernel<1, 8, 8, 3>|1310720"]
+    assert k["launches_per_step"] == 2.0 and k["hbm_bytes_per_launch_corrected"] == round((2 * 505.0 + 165.0) * 1024)
+    # ... the join with the per-launch dump can: this is the entry bench.py's roofline.traffic looks up
+    s = doc["kernels_by_shape"]["flash_attn_d64_kernel<1, 8, 8, 3> B8 h5 D64 Lq16384 Lk16384"]
+    assert s["hbm_bytes_per_launch_corrected"] == round((2 * 1000.0 + 300.0) * 1024)
+    x = doc["kernels_by_shape"]["flash_attn_d64_kernel<1, 8, 8, 3> B8 h5 D64 Lq16384 Lk77"]
+    assert x["hbm_bytes_per_launch_corrected"] == round((2 * 10.0 + 30.0) * 1024)
+    assert doc["total_hbm_bytes_per_step_corrected"] == sum(c["hbm_bytes_per_step_corrected"] for c in doc["classes"].values())
+
+
+def test_committed_traffic_file_is_what_bench_reads():
+    """the committed PMC summary resolves the headline kernel of the committed bench line (same spelling on both sides)"""
+    import glob
+    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")))[-1]
+    # (the bench line of the profile call itself precedes its PMC passes; the HEAD check taken afterwards carries the look-up)
+    bf = os.path.join(ROOT, "profiles", os.path.basename(tf).split("_pmc_")[0] + "_bench_head_check.json")
+    doc = json.load(open(tf))
+    line = json.loads(open(bf).read().strip().splitlines()[-1])
+    roof = line["roofline"]
+    ent = doc["kernels_by_shape"][roof["kernel"]]
+    assert ent["hbm_bytes_per_launch_corrected"] == roof["traffic"]
+    assert roof["traffic_source"] == os.path.basename(tf)
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
