@@ -101,3 +101,31 @@ def test_committed_traffic_file_is_what_bench_reads():
     assert ent["hbm_bytes_per_launch_corrected"] == roof["traffic"]
     assert roof["traffic_source"] == os.path.basename(tf)
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+
+
+def test_kernel_trace_summary_on_a_synthetic_trace(tmp_path, monkeypatch, capsys):
+    """per (symbol, grid) durations of a rocprofv3 --kernel-trace run: the file the bench line's avg_launch_ms is checked against"""
+    os.makedirs(tmp_path / "t" / "host", exist_ok=True)
+    with open(tmp_path / "t" / "host" / "9_kernel_trace.csv", "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=["Kernel_Name", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z", "Start_Timestamp", "End_Timestamp"])
+        wr.writeheader()
+        t0 = 1000
+        for _ in range(3):                     # three steps: two attention launches of 2.0 / 3.0 ms, one GEMM of 0.5 ms, a torch kernel
+            for name, gx, ns in ((ATTN, 1310720, 2_000_000), (ATTN, 1310720, 3_000_000), (GEMM, 524288, 500_000), ("torch_fill", 64, 9_000_000)):
+                wr.writerow(dict(Kernel_Name=name, Grid_Size_X=gx, Grid_Size_Y=1, Grid_Size_Z=1, Start_Timestamp=t0, End_Timestamp=t0 + ns))
+                t0 += ns + 10
+    out = tmp_path / "per_kernel.csv"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        k = _load("kernel_trace_summary")
+        monkeypatch.setattr(sys, "argv", ["kernel_trace_summary.py", str(tmp_path / "t"), "3", str(out)])
+        k.main()
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tools"))
+    capsys.readouterr()
+    rows = list(csv.DictReader(open(out)))
+    assert [r["symbol"] for r in rows] == ["flash_attn_d64_kernel<1, 8, 8, 3>", "igemm_kernel<256, 128, 32, 4, 2, 3, 0, true>"]   # by total time
+    a = rows[0]
+    assert int(a["calls"]) == 6 and float(a["calls_per_step"]) == 2.0
+    assert float(a["avg_ms"]) == 2.5 and float(a["min_ms"]) == 2.0 and float(a["max_ms"]) == 3.0 and float(a["ms_per_step"]) == 5.0
+    assert float(rows[1]["avg_ms"]) == 0.5 and int(rows[1]["grid_work_items"]) == 524288
