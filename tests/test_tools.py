@@ -17,6 +17,14 @@ def _load(name):
     return mod
 
 
+def _load_with_tools_path(name):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        return _load(name)
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tools"))
+
+
 ATTN = "_ZN12_GLOBAL__N_121flash_attn_d64_kernelILi1ELi8ELi8ELi3EEEv14ctrl_attn_descPKDF16_"
 GEMM = "_ZN12_GLOBAL__N_112igemm_kernelILi256ELi128ELi32ELi4ELi2ELi3ELi0ELb1EEEv15ctrl_igemm_desciiPKDF16_ii"
 POOL = "_ZN12_GLOBAL__N_114avgpool_kernelEPKvPvii"
@@ -129,3 +137,18 @@ def test_kernel_trace_summary_on_a_synthetic_trace(tmp_path, monkeypatch, capsys
     assert int(a["calls"]) == 6 and float(a["calls_per_step"]) == 2.0
     assert float(a["avg_ms"]) == 2.5 and float(a["min_ms"]) == 2.0 and float(a["max_ms"]) == 3.0 and float(a["ms_per_step"]) == 5.0
     assert float(rows[1]["avg_ms"]) == 0.5 and int(rows[1]["grid_work_items"]) == 524288
+
+
+def test_isa_mix_classifier_and_block_split():
+    m = _load_with_tools_path("isa_mix")
+    assert m.classify("v_mfma_f32_32x32x16_f16") == "mfma" and m.classify("v_exp_f32_e32") == "valu_trans"
+    assert m.classify("v_cvt_pk_f16_f32") == "valu" and m.classify("ds_read_b128") == "lds"
+    assert m.classify("global_load_lds_dwordx4") == "lds_dma" and m.classify("global_store_dwordx4") == "vmem"
+    assert m.classify("scratch_load_dword") == "spill" and m.classify("s_waitcnt") == "s_waitcnt" and m.classify("s_add_i32") == "salu"
+    asm = "\n_ZN12_GLOBAL__N_114avgpool_kernelEPKvPvii: ; @x\n\ts_load_dword s0, s[0:1], 0\n.LBB0_1:\n\tv_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[8:11], v[0:3]\n" \
+          "\tv_add_f32_e32 v1, v2, v3\n\ts_cbranch_scc1 .LBB0_1\n.Lfunc_end0:\n\t.amdhsa_kernel x\namdhsa.kernels:\n  - .agpr_count: 0\n" \
+          "    .group_segment_fixed_size: 0\n    .name: _ZN12_GLOBAL__N_114avgpool_kernelEPKvPvii\n    .private_segment_fixed_size: 0\n" \
+          "    .sgpr_count: 10\n    .vgpr_count: 12\n"
+    bodies, meta = m.kernels(asm)
+    assert list(bodies) == ["_ZN12_GLOBAL__N_114avgpool_kernelEPKvPvii"] and "v_mfma" in bodies[list(bodies)[0]]
+    assert meta["_ZN12_GLOBAL__N_114avgpool_kernelEPKvPvii"]["vgpr_count"] == 12
