@@ -74,6 +74,24 @@ ADAPTER_VARIANTS = {
 }
 
 
+# ---- per-frame encoder states with MORE than one clip: the reference hands the temporal transformer a time context ordered
+# (pixel, clip) while the block's rows are (clip, pixel) (model/adapter_spatial_temporal.py:246-249) -- goldens made by the
+# reference's own file pin the oracle's restatement of that pairing (CPU); the HIP path is held against the oracle on the
+# same inputs by tests/test_gpu_e2e.py::test_per_sample_context_with_several_clips ----
+PER_CLIP_CONTEXT = {"video_per_clip_context_2x4": (2, 4), "video_per_clip_context_3x2": (3, 2)}
+
+
+def per_clip_context_inputs(tag):
+    clips, frames = PER_CLIP_CONTEXT[tag]
+    N = clips * frames
+    cfg = dict(ADAPTER_VIDEO)
+    cfg.update(add_adapter_location_B=False, add_adapter_location_C=False, add_adapter_location_D=False, add_adapter_location_M=False)
+    downs, _ = pyramid_inputs(N=N, h0=8, seed=810, with_mid=False)
+    ehs = seeded_tensor((N, 1, 1024), 811)
+    ehs = ehs * (1.0 + torch.arange(N).div(frames, rounding_mode="floor").view(N, 1, 1))      # clip b scaled by (1 + b)
+    return cfg, clips, frames, downs, ehs, torch.full((N,), 500.0)
+
+
 def variant_inputs(tag, seed=500):
     cfg, io = ADAPTER_VARIANTS[tag]
     downs, mid = pyramid_inputs(N=io["N"], h0=8, seed=seed, with_mid=io["mid"])

@@ -36,10 +36,27 @@ def digest(t, full=False):
     return d
 
 
+def per_clip_context(out_dir):
+    """G3c: per-frame encoder states with several clips (tests/golden/cases.py:PER_CLIP_CONTEXT), location A of the video adapter"""
+    from model.ctrl_adapter import ControlNetAdapter
+    gq = {}
+    for tag in cases.PER_CLIP_CONTEXT:
+        cfg, clips, frames, downs, ehs, ts = cases.per_clip_context_inputs(tag)
+        ad = seeded_init(ControlNetAdapter(**cfg).eval(), seed=36)
+        out, mid = ad(downs, sparsity_masking=None, num_frames=frames, timestep=ts, encoder_hidden_states=ehs)
+        assert mid is None
+        gq[tag] = {"keys": sorted(ad.state_dict().keys()), "out": [digest(o, full=(i == 0)) for i, o in enumerate(out)]}
+        del ad
+    torch.save(gq, os.path.join(out_dir, "adapter_per_clip_context.pt"))
+    print("per-clip context: %s" % ", ".join(gq))
+
+
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    if len(sys.argv) > 1 and sys.argv[1] == "per_clip_context":      # only this file (the others are unchanged)
+        return per_clip_context(out_dir)
 
     from controlnet.controlnet import ControlNetModel
     from model.ctrl_adapter import ControlNetAdapter
@@ -111,6 +128,7 @@ def main():
     g4["equal"] = dict(down=dw.clone(), mid=mw.clone())
     torch.save(g4, os.path.join(out_dir, "router.pt"))
     print("router ok")
+    per_clip_context(out_dir)
 
 
 if __name__ == "__main__":

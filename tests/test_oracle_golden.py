@@ -105,6 +105,25 @@ def test_adapter_variant_golden(tag):
         check_digest(t, d, TOL, "%s out %d" % (tag, i))
 
 
+@pytest.mark.parametrize("tag", sorted(cases.PER_CLIP_CONTEXT))
+def test_adapter_per_clip_context_golden(tag):
+    """per-frame encoder states with several clips: the time context reaches the temporal transformer ordered (pixel, clip)
+    while its rows are (clip, pixel) (model/adapter_spatial_temporal.py:246-249) -- the oracle's restatement against goldens
+    made by the reference's own file; and the pairing is NOT the natural one (each clip run alone differs by > 1e-1)"""
+    torch.set_grad_enabled(False)
+    g = load_golden("adapter_per_clip_context.pt")[tag]
+    cfg, clips, frames, downs, ehs, ts = cases.per_clip_context_inputs(tag)
+    ad = seeded_init(ControlNetAdapterOracle(**cfg).eval(), seed=36)
+    assert sorted(ad.state_dict().keys()) == g["keys"]
+    out, m = ad(downs, num_frames=frames, timestep=ts, encoder_hidden_states=ehs)
+    assert m is None
+    for i, (t, d) in enumerate(zip(out, g["out"])):
+        check_digest(t, d, TOL, "%s out %d" % (tag, i))
+    alone = ad([d[:frames] for d in downs], num_frames=frames, timestep=ts[:frames], encoder_hidden_states=ehs[:frames])[0][0]
+    full0 = g["out"][0]["full"][:frames]
+    assert ((alone - full0).abs().max() / full0.abs().max()).item() > 1e-1 or clips == 1
+
+
 def test_controlnet_nonsquare_single_image_golden(controlnet):
     g = load_golden("controlnet_sd15.pt")["nonsquare_n1"]
     inp = cases.controlnet_inputs_nonsquare()
