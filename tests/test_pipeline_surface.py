@@ -65,3 +65,26 @@ def test_module_protocol_used_by_inference_py():
         assert issubclass(cls, torch.nn.Module)
         assert "torch_dtype" in inspect.signature(cls.from_pretrained).parameters or \
             any(p.kind == p.VAR_KEYWORD for p in inspect.signature(cls.from_pretrained).parameters.values())
+
+
+def test_loading_calls_of_inference_py(tmp_path):
+    """the literal call forms of inference.py:218-252 -- from_pretrained(<dir>, subfolder=..., low_cpu_mem_usage=False,
+    device_map=None), then .to(data_type) / .eval() -- on checkpoints laid out like the training script writes them
+    (<root>/adapter_<step>/, <root>/router_<step>/), incl. data_type = bfloat16 (the script's --mixed_precision bf16)"""
+    from oracle.init import seeded_init
+    cfg = dict(cases.ADAPTER_SDXL)
+    cfg.update(add_adapter_location_B=False, add_adapter_location_C=False)          # one location: a small file
+    ad = seeded_init(P.ControlNetAdapter(**cfg), seed=5)
+    ad.save_pretrained(str(tmp_path / "adapter_70000"))
+    r = seeded_init(P.ControlNetRouter(num_experts=3, router_type="simple_weights", num_routers=12), seed=6)
+    r.save_pretrained(str(tmp_path / "router_70000"))
+    for data_type in (torch.float32, torch.half, torch.bfloat16):
+        a2 = P.ControlNetAdapter.from_pretrained(str(tmp_path), subfolder="adapter_70000", low_cpu_mem_usage=False, device_map=None)
+        a2 = a2.to(data_type)
+        a2.eval()
+        assert a2.dtype == data_type and sorted(a2.state_dict()) == sorted(ad.state_dict())
+        k = next(iter(ad.state_dict()))
+        assert torch.equal(a2.state_dict()[k].float(), ad.state_dict()[k].to(data_type).float())
+    r2 = P.ControlNetRouter.from_pretrained(str(tmp_path), subfolder="router_70000", low_cpu_mem_usage=False, device_map=None)
+    assert r2.router_type == "simple_weights" and r2.num_experts == 3
+    assert all(torch.equal(a, b) for a, b in zip(r2.state_dict().values(), r.state_dict().values()))
