@@ -1,5 +1,7 @@
 """The standalone oracle restatements (oracle/*.py) against the golden vectors produced by the reference's OWN
 files run over the diffusers shim (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import pytest
 import torch
 
@@ -130,3 +132,15 @@ def test_controlnet_nonsquare_single_image_golden(controlnet):
     down, mid = controlnet(inp["sample"], inp["timestep"], inp["encoder_hidden_states"], inp["controlnet_cond"])
     for i, (t, d) in enumerate(zip(list(down) + [mid], g)):
         check_digest(t, d, TOL, "controlnet[nonsquare] out %d" % i)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_oracle_against_the_reference_files_live_random_configurations():
+    """beyond the fixed goldens: randomly drawn adapter / ControlNet configurations, the reference's own files (over the diffusers
+    shim) against the oracle on the same seeded weights and inputs -- tests/golden/live_check.py, in its own process because it
+    installs the shim as `diffusers`"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "live_check.py"), "8", "3000"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "LIVE CHECK OK: 8 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
