@@ -104,6 +104,31 @@ def controlnet_case(rng, seed):
     return "controlnet N=%d pool %d %s" % (inp["sample"].shape[0], gp, " ".join("%s=%s" % kv for kv in sorted(kw.items()))), max(errs)
 
 
+def multi_case(rng, seed):
+    """controlnet/multicontrolnet.py:45-99 (per-net lists, no summation) against MultiControlNetOracle: two nets, two images, two scales"""
+    from controlnet.multicontrolnet import MultiControlNetModel
+    from oracle.controlnet import MultiControlNetOracle
+    for gp in (False, True):
+        if gp not in _nets:
+            controlnet_case(random.Random(seed), seed)      # builds the missing flavour as a side effect (cached)
+            if gp not in _nets:
+                from controlnet.controlnet import ControlNetModel
+                from oracle.controlnet import ControlNetOracle
+                kw = dict(cases.CONTROLNET_KW, global_pool_conditions=gp)
+                _nets[gp] = (seeded_init(ControlNetModel(**kw).eval(), seed=11), seeded_init(ControlNetOracle(**kw).eval(), seed=11))
+    ref = MultiControlNetModel([_nets[False][0], _nets[True][0]])
+    ora = MultiControlNetOracle([_nets[False][1], _nets[True][1]])
+    inp = cases.controlnet_inputs()
+    conds = [inp["controlnet_cond"], seeded_tensor(tuple(inp["controlnet_cond"].shape), seed + 5).abs()]
+    scales = [rng.choice([1.0, 0.5]), rng.choice([1.0, 2.0])]
+    skip = rng.random() < 0.5
+    rd, rm = ref(inp["sample"], inp["timestep"], inp["encoder_hidden_states"], conds, scales, return_dict=False, skip_conv_in=skip)
+    od, om = ora(inp["sample"], inp["timestep"], inp["encoder_hidden_states"], conds, scales, skip_conv_in=skip)
+    assert len(rd) == len(od) == 2 and len(rm) == len(om) == 2
+    errs = [rel(a, b) for k in range(2) for a, b in zip(list(od[k]) + [om[k]], list(rd[k]) + [rm[k]])]
+    return "multi-controlnet 2 nets scales %s skip_conv_in %d" % (scales, skip), max(errs)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -112,7 +137,7 @@ def main():
     for i in range(n):
         seed = first + 17 * i
         rng = random.Random(seed)
-        desc, err = (controlnet_case if i % 4 == 3 else adapter_case)(rng, seed)
+        desc, err = (multi_case if i % 8 == 7 else controlnet_case if i % 4 == 3 else adapter_case)(rng, seed)
         worst = max(worst, err)
         print("%-120s rel_inf %.2e%s" % (desc, err, "" if err <= TOL else "   MISMATCH"), flush=True)
         if not err <= TOL:
