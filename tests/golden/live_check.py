@@ -129,6 +129,27 @@ def multi_case(rng, seed):
     return "multi-controlnet 2 nets scales %s skip_conv_in %d" % (scales, skip), max(errs)
 
 
+def router_case(rng, seed):
+    """model/ctrl_router.py:49-112 against RouterOracle: expert count, router type, number of routers, random sparse masks"""
+    from model.ctrl_router import ControlNetRouter
+    from oracle.router import RouterOracle
+    E, rt, nr = rng.choice([2, 3, 5]), rng.choice(["simple_weights", "equal_weights"]), rng.choice([9, 12])
+    ref = seeded_init(ControlNetRouter(num_experts=E, router_type=rt, num_routers=nr).eval(), seed=seed)
+    ora = seeded_init(RouterOracle(num_experts=E, router_type=rt, num_routers=nr).eval(), seed=seed)
+    assert sorted(ref.state_dict()) == sorted(ora.state_dict()), "router state-dict keys differ"
+    worst = 0.0
+    for _ in range(4):
+        mask = [rng.randrange(2) for _ in range(E)]
+        if not any(mask):
+            mask[rng.randrange(E)] = 1
+        mask = rng.choice([mask, None])
+        rd, rm = ref(sparse_mask=mask)
+        od, om = ora(sparse_mask=mask)
+        assert rd.shape == od.shape == (nr, E) and rm.shape == om.shape == (E,)
+        worst = max(worst, (rd - od).abs().max().item(), (rm - om).abs().max().item())
+    return "router E=%d %s routers %d, 4 masks" % (E, rt, nr), worst
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -137,7 +158,7 @@ def main():
     for i in range(n):
         seed = first + 17 * i
         rng = random.Random(seed)
-        desc, err = (multi_case if i % 8 == 7 else controlnet_case if i % 4 == 3 else adapter_case)(rng, seed)
+        desc, err = (multi_case if i % 8 == 7 else controlnet_case if i % 4 == 3 else router_case if i % 4 == 1 else adapter_case)(rng, seed)
         worst = max(worst, err)
         print("%-120s rel_inf %.2e%s" % (desc, err, "" if err <= TOL else "   MISMATCH"), flush=True)
         if not err <= TOL:
