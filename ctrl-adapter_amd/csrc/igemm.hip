@@ -52,7 +52,7 @@ __device__ __forceinline__ int chunk_swz(int row) {
 
 // 128x256 / 256x128 tiles of 8 waves keep two workgroups resident per CU (72 KiB of LDS ring, <= 128 VGPRs per wave): one
 // workgroup's epilogue (HBM-bound fp32 stream traffic, GEGLU math) overlaps the other one's k-loop
-template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (NW == 8 && BM * BN == 128 * 256) ? 4 : 1; };
+template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (BM * BN == 128 * 256) ? (NW == 8 ? 4 : (NW == 4 ? 2 : 1)) : 1; };
 
 // (A persistent-workgroup form -- one workgroup per CU walking its tiles with one LDS ring running across them -- was built
 // in round 2 and measured again at the start of round 3 after the epilogue fetch hoisting: 0.72-1.03x the one-tile form on
@@ -909,6 +909,8 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
         if (can_swap(a) && MODE == IG_ROWS) {
             if (!strcmp(f, "128x256")) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
             if (!strcmp(f, "256x128")) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
+            if (!strcmp(f, "4w256x128")) return launch_cfg2<256, 128, 32, 2, 2, 3, MODE, true>(a, s);      // 4 waves x 256 registers, two workgroups per CU
+            if (!strcmp(f, "4w128x256")) return launch_cfg2<128, 256, 32, 1, 4, 3, MODE, true>(a, s);
         }
     }
     // Epilogue-heavy token GEMMs at large M (measured, tools/tile_experiment.py -> profiles/r02_tile_experiment.log): two
