@@ -54,6 +54,333 @@ __device__ __forceinline__ int chunk_swz(int row) {
 // workgroup's epilogue (HBM-bound fp32 stream traffic, GEGLU math) overlaps the other one's k-loop
 template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (BM * BN == 128 * 256) ? (NW == 8 ? 4 : (NW == 4 ? 2 : 1)) : 1; };
 
+// ---------------- epilogue of an accumulated tile (m0, n0), shared by every main loop of this file ----------------
+// acc[mi][ni]: the 16x16 fragments of the wave tile (WM x WN at wave position (wm, wn)); epi_smem: the workgroup's LDS, dead
+// as a k-loop ring when this runs (the caller has NOT synchronised: the first thing the staged forms do is a barrier).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP, int MINW>
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16], const int m0, const int n0,
+                                               const int wm, const int wn, const int lane, const int wave, const int split, char* const epi_smem) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    const half_t* Rptr = (const half_t*)e.res;
+    if constexpr (SWAP) {
+        // Operands were swapped (D = W.A^T): a lane owns ONE output row (lane&15) and FOUR consecutive columns
+        // (lane>>4)*4+i of each 16x16 fragment.  Bias / time vector / GEGLU / SiLU are applied in registers; the
+        // 16-row slab of the wave tile then goes through a wave-private LDS staging area (the k-loop ring is dead) and
+        // leaves as whole 16-byte pieces of full output rows: residual reads and result writes are coalesced 128-byte+
+        // row segments instead of 8-byte fragments scattered over 16 rows.
+        __syncthreads();           // every wave is done with the ring
+        if (e.seg[0].fmt == SEG_TRANSPOSED) {
+            // One transposed segment (NCHW result / V^T operand): out[(img*ncols + c)*ld + tok].  Everything that is
+            // indexed by (row, column) -- bias, time vector, SiLU, residual, scale -- is applied in the fragment layout;
+            // a 16-channel slab of the wave tile (16 x WM tokens) is then transposed through the wave's LDS area and
+            // leaves as 16-byte pieces of WM-token runs of one channel (256 B contiguous for WM = 128) instead of the
+            // natural orientation's isolated 8-byte stores.
+            constexpr int SLT = WM + 4;                    // 4*SLT = 16 (mod 64 banks): the 4 channel groups of a write hit distinct banks
+            float* stg = (float*)epi_smem + wave * (16 * SLT);
+            const IGemmSeg sg = e.seg[0];
+            const int erow = lane & 15, ecol = (lane >> 4) * 4;
+            const int wrow0 = m0 + wm * WM;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int pcb = n0 + wn * WN + ni * 16;
+                if (pcb < e.Nout) {
+                    const int pcol = pcb + ecol;
+                    f4 b4 = f4{0.f, 0.f, 0.f, 0.f};
+                    if (e.bias) b4 = *(const f4*)(e.bias + pcol);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int row_w = wrow0 + mi * 16 + erow;
+                        f4 x = acc[mi][ni] + b4;
+                        if (row_w < e.M) {
+                            if (e.rowvec) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcol);
+                            if (e.act == 1) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
+                            }
+                            if (Rptr) {
+                                if (e.res_f32) {
+                                    x += *(const f4*)((const float*)e.res + (size_t)row_w * e.ldres + pcol);
+                                } else {
+                                    const h4 rr = *(const h4*)(Rptr + (size_t)row_w * e.ldres + pcol);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) x[i] += (float)rr[i];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) stg[(ecol + i) * SLT + mi * 16 + erow] = x[i] * e.scale;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    constexpr int CH8 = WM / 8;
+                    for (int idx = lane; idx < 16 * CH8; idx += 64) {
+                        const int ch = idx / CH8, c8 = idx - ch * CH8;
+                        const int row = wrow0 + c8 * 8;
+                        if (row >= e.M) continue;
+                        int img = row / sg.L;
+                        const int tok = row - img * sg.L;
+                        if (sg.img_map) img = sg.img_map[img];
+                        const size_t o = ((size_t)img * sg.ncols + (pcb - sg.col_begin) + ch) * sg.ld + tok;
+                        const f4 v0 = *(const f4*)(stg + ch * SLT + c8 * 8), v1 = *(const f4*)(stg + ch * SLT + c8 * 8 + 4);
+                        if (sg.dtype == DT_F16) {
+                            h8 pk = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
+                                     (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
+                            *(h8*)((half_t*)sg.out + o) = pk;
+                        } else if (sg.dtype == DT_F32) {
+                            *(f4*)((float*)sg.out + o) = v0;
+                            *(f4*)((float*)sg.out + o + 4) = v1;
+                        } else {
+                            typedef u16 us8 __attribute__((ext_vector_type(8)));
+                            us8 pk = {f32_to_bf16(v0[0]), f32_to_bf16(v0[1]), f32_to_bf16(v0[2]), f32_to_bf16(v0[3]),
+                                      f32_to_bf16(v1[0]), f32_to_bf16(v1[1]), f32_to_bf16(v1[2]), f32_to_bf16(v1[3])};
+                            *(us8*)((u16*)sg.out + o) = pk;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        } else {
+            constexpr int OWMAX = WN;                          // output columns of the wave tile (half of it with GEGLU)
+            constexpr int SLD = OWMAX + 4;                     // floats; +16 B keeps the b128 accesses conflict-light
+            float* stg = (float*)epi_smem + wave * (16 * SLD);
+            const int erow = lane & 15, ecol = (lane >> 4) * 4;
+            const int OW = e.geglu ? WN / 2 : WN;
+            const int OWC = OW >> 3;                           // 8-column chunks per row
+            const int wcol0 = e.geglu ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN);     // first output column of the wave tile
+            const int nout_eff = e.geglu ? (e.Nout >> 1) : e.Nout;
+            // the bias depends on the column only: one load per fragment column, issued together up front -- fetched
+            // inside the mi loop, every 16-row slab stalled on its own load (and on every store before it: one vmcnt)
+            f4 bias_v[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int pcb = n0 + wn * WN + ni * 16;
+                bias_v[ni] = (e.bias && pcb < e.Nout) ? *(const f4*)(e.bias + pcb + ecol) : f4{0.f, 0.f, 0.f, 0.f};
+            }
+            // fp32 residual (the fp32 stream updates, HBM-bound): the 8-column pieces a lane adds are fetched one slab
+            // AHEAD, each refill issued before the stores of its own slab, so that waiting for it never means waiting
+            // for a store (loads and stores share one in-order counter)
+            constexpr int RT = (16 * (OWMAX / 8) + 63) / 64;       // pieces per lane per 16-row slab
+            // ... fetched ahead: the wide one-workgroup-per-CU tiles only (256 registers per wave; the two-workgroup
+            // tiles live in 128 and overlap their epilogue with the other workgroup's k-loop instead); the 80-wide wave
+            // tile (three pieces per lane, 160 accumulator registers) has room for one
+            constexpr bool RES_AHEAD = (WM * WN >= 128 * 64) && MINW == 1;
+            constexpr int RTP = !RES_AHEAD ? 0 : (RT > 2 ? 1 : RT);
+            f4 rf0[RTP ? RTP : 1], rf1[RTP ? RTP : 1];
+#pragma unroll
+            for (int t = 0; t < RTP; ++t) {
+                rf0[t] = rf1[t] = f4{0.f, 0.f, 0.f, 0.f};
+                const int idx = lane + 64 * t;
+                if (Rptr && e.res_f32 && idx < 16 * OWC) {
+                    const int r = idx / OWC, c8 = idx - r * OWC;
+                    const int row = m0 + wm * WM + r, ocol = wcol0 + c8 * 8;
+                    if (row < e.M && ocol < nout_eff) {
+                        const float* rp = (const float*)e.res + res_row_of(e, row) * e.ldres + ocol;
+                        rf0[t] = *(const f4*)rp;
+                        rf1[t] = *(const f4*)(rp + 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row_w = m0 + wm * WM + mi * 16 + erow;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (e.geglu && (ni & 1)) continue;
+                    const int pcb = n0 + wn * WN + ni * 16;
+                    if (pcb >= e.Nout) continue;
+                    const int pcol = pcb + ecol;
+                    f4 x = acc[mi][ni];
+                    if (e.bias) x += bias_v[ni];
+                    if (e.rowvec && row_w < e.M) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcol);
+                    if (e.geglu) {
+                        f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)];
+                        if (e.bias) g += bias_v[ni + 1 < NI ? ni + 1 : ni];      // the gate's columns = the next fragment's
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
+                    }
+                    if (e.act == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
+                    }
+                    const int lcol = (e.geglu ? (ni >> 1) * 16 : ni * 16) + ecol;
+                    *(f4*)(stg + erow * SLD + lcol) = x;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are in order; pin compiler order
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const int idx = lane + 64 * t;
+                    if (idx >= 16 * OWC) continue;
+                    const int r = idx / OWC, c8 = idx - r * OWC;
+                    const int row = m0 + wm * WM + mi * 16 + r;
+                    const int ocol = wcol0 + c8 * 8;
+                    if (row >= e.M || ocol >= nout_eff) continue;
+                    const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
+                    float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (Rptr) {
+                        if (e.res_f32) {
+                            if (t < RTP) {
+                                const int tp = t < RTP ? t : 0;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { x[i] += rf0[tp][i]; x[4 + i] += rf1[tp][i]; }
+                                if (mi + 1 < MI && row + 16 < e.M) {       // refill for the same piece of the next slab
+                                    const float* rp = (const float*)e.res + res_row_of(e, row + 16) * e.ldres + ocol;
+                                    rf0[tp] = *(const f4*)rp;
+                                    rf1[tp] = *(const f4*)(rp + 4);
+                                }
+                            } else {
+                                const float* rp = (const float*)e.res + res_row_of(e, row) * e.ldres + ocol;
+                                const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { x[i] += r0[i]; x[4 + i] += r1[i]; }
+                            }
+                        } else {
+                            const h8 rr = *(const h8*)(Rptr + res_row_of(e, row) * e.ldres + ocol);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
+                        }
+                    }
+                    {
+                        // an 8-column chunk never straddles scale2_from (a multiple of 8, checked by op_igemm)
+                        const float sc = (e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[i] *= sc;
+                    }
+                    if (e.blend_mix) {   // AlphaBlender fold: (1-a) * this branch + a * the other branch
+                        const float al = __builtin_amdgcn_rcpf(1.0f + __expf(-e.blend_mix[0]));
+                        float bx[8];
+                        if (e.blend_f32) {
+                            const float* bp = (const float*)e.blend_x + (size_t)row * e.ld_blend + ocol;
+                            const f4 b0 = *(const f4*)bp, b1 = *(const f4*)(bp + 4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { bx[i] = b0[i]; bx[4 + i] = b1[i]; }
+                        } else {
+                            const h8 bb = *(const h8*)((const half_t*)e.blend_x + (size_t)row * e.ld_blend + ocol);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) bx[i] = (float)bb[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
+                    }
+                    if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
+                        h8 pk;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
+                        *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + ocol) = pk;
+                        if (e.out16_lo_off) {      // split operand: the rounding residual rides along (hi + lo == x to ~2^-22)
+                            h8 lo;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) lo[i] = (half_t)(x[i] - (float)pk[i]);
+                            *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + e.out16_lo_off + ocol) = lo;
+                        }
+                    }
+                    // Segment of this 8-column piece (the last one whose first column is <= ocol).  The descriptors are
+                    // kernel arguments, i.e. scalars: selected FIELD by FIELD they stay in scalar registers.  Selecting the
+                    // struct (`seg[si]`, si per lane) made every lane load its copy from memory and wait for it -- and, the
+                    // counter being shared and in order, for every store issued before it -- once per 16-byte piece.
+                    const bool in1 = e.nseg > 1 && ocol >= e.seg[1].col_begin, in2 = e.nseg > 2 && ocol >= e.seg[2].col_begin;
+                    void* const sg_out = in2 ? e.seg[2].out : (in1 ? e.seg[1].out : e.seg[0].out);
+                    const int64_t sg_ld = in2 ? e.seg[2].ld : (in1 ? e.seg[1].ld : e.seg[0].ld);
+                    const int sg_cb = in2 ? e.seg[2].col_begin : (in1 ? e.seg[1].col_begin : e.seg[0].col_begin);
+                    const int sg_dt = in2 ? e.seg[2].dtype : (in1 ? e.seg[1].dtype : e.seg[0].dtype);
+                    const size_t o = (size_t)row * sg_ld + (ocol - sg_cb) + (size_t)split * e.M * e.Nout;   // split > 0 only for fp32 slabs
+                    if (sg_dt == DT_F16) {
+                        h8 pk;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
+                        *(h8*)((half_t*)sg_out + o) = pk;
+                    } else if (sg_dt == DT_F32) {
+                        *(f4*)((float*)sg_out + o) = f4{x[0], x[1], x[2], x[3]};
+                        *(f4*)((float*)sg_out + o + 4) = f4{x[4], x[5], x[6], x[7]};
+                    } else {
+                        typedef u16 us8 __attribute__((ext_vector_type(8)));
+                        us8 pk;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
+                        *(us8*)((u16*)sg_out + o) = pk;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
+            }
+        }
+    } else {
+        // C/D fragment map of v_mfma_f32_16x16x32: row = (lane>>4)*4 + i, col = lane&15
+        const int erow = (lane >> 4) * 4, ecol = lane & 15;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            if (e.geglu && (ni & 1)) continue;           // odd fragments are the gates of the even ones
+            const int pcb = n0 + wn * WN + ni * 16;      // packed column block start
+            if (pcb >= e.Nout) continue;
+            const int pcol = pcb + ecol;                 // packed column (bias index)
+            const int ocol = e.geglu ? ((pcb >> 5) << 4) + ecol : pcol;   // output column
+            const int ocb = ocol - ecol;
+            // segment lookup (segment boundaries are multiples of 16 -> uniform per fragment)
+            int si = 0;
+#pragma unroll
+            for (int k = 1; k < 3; ++k)
+                if (k < e.nseg && ocb >= e.seg[k].col_begin) si = k;
+            const IGemmSeg sg = si == 0 ? e.seg[0] : (si == 1 ? e.seg[1] : e.seg[2]);   // (constant indices: a dynamic one pins the whole descriptor in scratch)
+            const int scol = ocol - sg.col_begin;
+            const float bh = e.bias ? e.bias[pcol] : 0.f;
+            const float bg = (e.geglu && e.bias) ? e.bias[pcol + 16] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int rbase = m0 + wm * WM + mi * 16 + erow;
+                if (rbase >= e.M) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = rbase + i;
+                    float x = acc[mi][ni][i] + bh;
+                    if (e.rowvec && row < e.M) x += e.rowvec[(size_t)(row / e.rows_per_img) * e.rowvec_ld + pcol];
+                    if (e.geglu) {
+                        const float g = acc[mi][ni + (NI > 1 ? 1 : 0)][i] + bg;
+                        x = x * gelu_erf_f(g);
+                    }
+                    if (e.act == 1) x = silu_f(x);
+                    if (Rptr && row < e.M)
+                        x += e.res_f32 ? ((const float*)e.res)[res_row_of(e, row) * e.ldres + ocol] : (float)Rptr[res_row_of(e, row) * e.ldres + ocol];
+                    v[i] = x * ((e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale);
+                }
+                if (sg.fmt == SEG_ROW) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = rbase + i;
+                        if (row < e.M) store_from_f32(sg.out, (size_t)row * sg.ld + scol, sg.dtype, v[i]);
+                    }
+                } else {
+                    const int img = rbase / sg.L, tok = rbase - img * sg.L;
+                    const int dimg = sg.img_map ? sg.img_map[img] : img;
+                    const size_t base = ((size_t)dimg * sg.ncols + scol) * sg.ld + tok;
+                    const bool vec = ((sg.L & 3) == 0) && ((sg.ld & 3) == 0) && (rbase + 3 < e.M);
+                    if (vec) {
+                        if (sg.dtype == DT_F16) {
+                            h4 p = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                            *(h4*)((half_t*)sg.out + base) = p;
+                        } else if (sg.dtype == DT_F32) {
+                            *(f4*)((float*)sg.out + base) = f4{v[0], v[1], v[2], v[3]};
+                        } else {
+                            typedef u16 us4 __attribute__((ext_vector_type(4)));
+                            us4 p = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
+                            *(us4*)((u16*)sg.out + base) = p;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = rbase + i;
+                            if (row >= e.M) break;
+                            const int im = row / sg.L, tk = row - im * sg.L;
+                            const int dm = sg.img_map ? sg.img_map[im] : im;
+                            store_from_f32(sg.out, ((size_t)dm * sg.ncols + scol) * sg.ld + tk, sg.dtype, v[i]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+}
+
 // (A persistent-workgroup form -- one workgroup per CU walking its tiles with one LDS ring running across them -- was built
 // in round 2 and measured again at the start of round 3 after the epilogue fetch hoisting: 0.72-1.03x the one-tile form on
 // every shape of the path, profiles/r03_gemm_persistent_form.txt.  It is gone from the product.)
@@ -337,327 +664,341 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
 
     }
 
-    {
-        {
-        // ---------------- epilogue of the accumulated tile (m0, n0) ----------------
-            const IGemmArgs& e = a;
-            if constexpr (SWAP) {
-                // Operands were swapped (D = W.A^T): a lane owns ONE output row (lane&15) and FOUR consecutive columns
-                // (lane>>4)*4+i of each 16x16 fragment.  Bias / time vector / GEGLU / SiLU are applied in registers; the
-                // 16-row slab of the wave tile then goes through a wave-private LDS staging area (the k-loop ring is dead) and
-                // leaves as whole 16-byte pieces of full output rows: residual reads and result writes are coalesced 128-byte+
-                // row segments instead of 8-byte fragments scattered over 16 rows.
-                __syncthreads();           // every wave is done with the ring
-                if (e.seg[0].fmt == SEG_TRANSPOSED) {
-                    // One transposed segment (NCHW result / V^T operand): out[(img*ncols + c)*ld + tok].  Everything that is
-                    // indexed by (row, column) -- bias, time vector, SiLU, residual, scale -- is applied in the fragment layout;
-                    // a 16-channel slab of the wave tile (16 x WM tokens) is then transposed through the wave's LDS area and
-                    // leaves as 16-byte pieces of WM-token runs of one channel (256 B contiguous for WM = 128) instead of the
-                    // natural orientation's isolated 8-byte stores.
-                    constexpr int SLT = WM + 4;                    // 4*SLT = 16 (mod 64 banks): the 4 channel groups of a write hit distinct banks
-                    float* stg = (float*)epi_smem + wave * (16 * SLT);
-                    const IGemmSeg sg = e.seg[0];
-                    const int erow = lane & 15, ecol = (lane >> 4) * 4;
-                    const int wrow0 = m0 + wm * WM;
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const int pcb = n0 + wn * WN + ni * 16;
-                        if (pcb < e.Nout) {
-                            const int pcol = pcb + ecol;
-                            f4 b4 = f4{0.f, 0.f, 0.f, 0.f};
-                            if (e.bias) b4 = *(const f4*)(e.bias + pcol);
-#pragma unroll
-                            for (int mi = 0; mi < MI; ++mi) {
-                                const int row_w = wrow0 + mi * 16 + erow;
-                                f4 x = acc[mi][ni] + b4;
-                                if (row_w < e.M) {
-                                    if (e.rowvec) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcol);
-                                    if (e.act == 1) {
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
-                                    }
-                                    if (Rptr) {
-                                        if (e.res_f32) {
-                                            x += *(const f4*)((const float*)e.res + (size_t)row_w * e.ldres + pcol);
-                                        } else {
-                                            const h4 rr = *(const h4*)(Rptr + (size_t)row_w * e.ldres + pcol);
-#pragma unroll
-                                            for (int i = 0; i < 4; ++i) x[i] += (float)rr[i];
-                                        }
-                                    }
-                                }
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) stg[(ecol + i) * SLT + mi * 16 + erow] = x[i] * e.scale;
-                            }
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            constexpr int CH8 = WM / 8;
-                            for (int idx = lane; idx < 16 * CH8; idx += 64) {
-                                const int ch = idx / CH8, c8 = idx - ch * CH8;
-                                const int row = wrow0 + c8 * 8;
-                                if (row >= e.M) continue;
-                                int img = row / sg.L;
-                                const int tok = row - img * sg.L;
-                                if (sg.img_map) img = sg.img_map[img];
-                                const size_t o = ((size_t)img * sg.ncols + (pcb - sg.col_begin) + ch) * sg.ld + tok;
-                                const f4 v0 = *(const f4*)(stg + ch * SLT + c8 * 8), v1 = *(const f4*)(stg + ch * SLT + c8 * 8 + 4);
-                                if (sg.dtype == DT_F16) {
-                                    h8 pk = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
-                                             (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
-                                    *(h8*)((half_t*)sg.out + o) = pk;
-                                } else if (sg.dtype == DT_F32) {
-                                    *(f4*)((float*)sg.out + o) = v0;
-                                    *(f4*)((float*)sg.out + o + 4) = v1;
-                                } else {
-                                    typedef u16 us8 __attribute__((ext_vector_type(8)));
-                                    us8 pk = {f32_to_bf16(v0[0]), f32_to_bf16(v0[1]), f32_to_bf16(v0[2]), f32_to_bf16(v0[3]),
-                                              f32_to_bf16(v1[0]), f32_to_bf16(v1[1]), f32_to_bf16(v1[2]), f32_to_bf16(v1[3])};
-                                    *(us8*)((u16*)sg.out + o) = pk;
-                                }
-                            }
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        }
-                    }
-                } else {
-                    constexpr int OWMAX = WN;                          // output columns of the wave tile (half of it with GEGLU)
-                    constexpr int SLD = OWMAX + 4;                     // floats; +16 B keeps the b128 accesses conflict-light
-                    float* stg = (float*)epi_smem + wave * (16 * SLD);
-                    const int erow = lane & 15, ecol = (lane >> 4) * 4;
-                    const int OW = e.geglu ? WN / 2 : WN;
-                    const int OWC = OW >> 3;                           // 8-column chunks per row
-                    const int wcol0 = e.geglu ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN);     // first output column of the wave tile
-                    const int nout_eff = e.geglu ? (e.Nout >> 1) : e.Nout;
-                    // the bias depends on the column only: one load per fragment column, issued together up front -- fetched
-                    // inside the mi loop, every 16-row slab stalled on its own load (and on every store before it: one vmcnt)
-                    f4 bias_v[NI];
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const int pcb = n0 + wn * WN + ni * 16;
-                        bias_v[ni] = (e.bias && pcb < e.Nout) ? *(const f4*)(e.bias + pcb + ecol) : f4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    // fp32 residual (the fp32 stream updates, HBM-bound): the 8-column pieces a lane adds are fetched one slab
-                    // AHEAD, each refill issued before the stores of its own slab, so that waiting for it never means waiting
-                    // for a store (loads and stores share one in-order counter)
-                    constexpr int RT = (16 * (OWMAX / 8) + 63) / 64;       // pieces per lane per 16-row slab
-                    // ... fetched ahead: the wide one-workgroup-per-CU tiles only (256 registers per wave; the two-workgroup
-                    // tiles live in 128 and overlap their epilogue with the other workgroup's k-loop instead); the 80-wide wave
-                    // tile (three pieces per lane, 160 accumulator registers) has room for one
-                    constexpr bool RES_AHEAD = (WM * WN >= 128 * 64) && MinWaves<BM, BN, NW>::v == 1;
-                    constexpr int RTP = !RES_AHEAD ? 0 : (RT > 2 ? 1 : RT);
-                    f4 rf0[RTP ? RTP : 1], rf1[RTP ? RTP : 1];
-#pragma unroll
-                    for (int t = 0; t < RTP; ++t) {
-                        rf0[t] = rf1[t] = f4{0.f, 0.f, 0.f, 0.f};
-                        const int idx = lane + 64 * t;
-                        if (Rptr && e.res_f32 && idx < 16 * OWC) {
-                            const int r = idx / OWC, c8 = idx - r * OWC;
-                            const int row = m0 + wm * WM + r, ocol = wcol0 + c8 * 8;
-                            if (row < e.M && ocol < nout_eff) {
-                                const float* rp = (const float*)e.res + res_row_of(e, row) * e.ldres + ocol;
-                                rf0[t] = *(const f4*)rp;
-                                rf1[t] = *(const f4*)(rp + 4);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const int row_w = m0 + wm * WM + mi * 16 + erow;
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) {
-                            if (e.geglu && (ni & 1)) continue;
-                            const int pcb = n0 + wn * WN + ni * 16;
-                            if (pcb >= e.Nout) continue;
-                            const int pcol = pcb + ecol;
-                            f4 x = acc[mi][ni];
-                            if (e.bias) x += bias_v[ni];
-                            if (e.rowvec && row_w < e.M) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcol);
-                            if (e.geglu) {
-                                f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)];
-                                if (e.bias) g += bias_v[ni + 1 < NI ? ni + 1 : ni];      // the gate's columns = the next fragment's
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
-                            }
-                            if (e.act == 1) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
-                            }
-                            const int lcol = (e.geglu ? (ni >> 1) * 16 : ni * 16) + ecol;
-                            *(f4*)(stg + erow * SLD + lcol) = x;
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are in order; pin compiler order
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) {
-                            const int idx = lane + 64 * t;
-                            if (idx >= 16 * OWC) continue;
-                            const int r = idx / OWC, c8 = idx - r * OWC;
-                            const int row = m0 + wm * WM + mi * 16 + r;
-                            const int ocol = wcol0 + c8 * 8;
-                            if (row >= e.M || ocol >= nout_eff) continue;
-                            const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
-                            float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                            if (Rptr) {
-                                if (e.res_f32) {
-                                    if (t < RTP) {
-                                        const int tp = t < RTP ? t : 0;
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) { x[i] += rf0[tp][i]; x[4 + i] += rf1[tp][i]; }
-                                        if (mi + 1 < MI && row + 16 < e.M) {       // refill for the same piece of the next slab
-                                            const float* rp = (const float*)e.res + res_row_of(e, row + 16) * e.ldres + ocol;
-                                            rf0[tp] = *(const f4*)rp;
-                                            rf1[tp] = *(const f4*)(rp + 4);
-                                        }
-                                    } else {
-                                        const float* rp = (const float*)e.res + res_row_of(e, row) * e.ldres + ocol;
-                                        const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) { x[i] += r0[i]; x[4 + i] += r1[i]; }
-                                    }
-                                } else {
-                                    const h8 rr = *(const h8*)(Rptr + res_row_of(e, row) * e.ldres + ocol);
-#pragma unroll
-                                    for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
-                                }
-                            }
-                            {
-                                // an 8-column chunk never straddles scale2_from (a multiple of 8, checked by op_igemm)
-                                const float sc = (e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale;
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) x[i] *= sc;
-                            }
-                            if (e.blend_mix) {   // AlphaBlender fold: (1-a) * this branch + a * the other branch
-                                const float al = __builtin_amdgcn_rcpf(1.0f + __expf(-e.blend_mix[0]));
-                                float bx[8];
-                                if (e.blend_f32) {
-                                    const float* bp = (const float*)e.blend_x + (size_t)row * e.ld_blend + ocol;
-                                    const f4 b0 = *(const f4*)bp, b1 = *(const f4*)(bp + 4);
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) { bx[i] = b0[i]; bx[4 + i] = b1[i]; }
-                                } else {
-                                    const h8 bb = *(const h8*)((const half_t*)e.blend_x + (size_t)row * e.ld_blend + ocol);
-#pragma unroll
-                                    for (int i = 0; i < 8; ++i) bx[i] = (float)bb[i];
-                                }
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
-                            }
-                            if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
-                                h8 pk;
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
-                                *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + ocol) = pk;
-                                if (e.out16_lo_off) {      // split operand: the rounding residual rides along (hi + lo == x to ~2^-22)
-                                    h8 lo;
-#pragma unroll
-                                    for (int i = 0; i < 8; ++i) lo[i] = (half_t)(x[i] - (float)pk[i]);
-                                    *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + e.out16_lo_off + ocol) = lo;
-                                }
-                            }
-                            // Segment of this 8-column piece (the last one whose first column is <= ocol).  The descriptors are
-                            // kernel arguments, i.e. scalars: selected FIELD by FIELD they stay in scalar registers.  Selecting the
-                            // struct (`seg[si]`, si per lane) made every lane load its copy from memory and wait for it -- and, the
-                            // counter being shared and in order, for every store issued before it -- once per 16-byte piece.
-                            const bool in1 = e.nseg > 1 && ocol >= e.seg[1].col_begin, in2 = e.nseg > 2 && ocol >= e.seg[2].col_begin;
-                            void* const sg_out = in2 ? e.seg[2].out : (in1 ? e.seg[1].out : e.seg[0].out);
-                            const int64_t sg_ld = in2 ? e.seg[2].ld : (in1 ? e.seg[1].ld : e.seg[0].ld);
-                            const int sg_cb = in2 ? e.seg[2].col_begin : (in1 ? e.seg[1].col_begin : e.seg[0].col_begin);
-                            const int sg_dt = in2 ? e.seg[2].dtype : (in1 ? e.seg[1].dtype : e.seg[0].dtype);
-                            const size_t o = (size_t)row * sg_ld + (ocol - sg_cb) + (size_t)split * e.M * e.Nout;   // split > 0 only for fp32 slabs
-                            if (sg_dt == DT_F16) {
-                                h8 pk;
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
-                                *(h8*)((half_t*)sg_out + o) = pk;
-                            } else if (sg_dt == DT_F32) {
-                                *(f4*)((float*)sg_out + o) = f4{x[0], x[1], x[2], x[3]};
-                                *(f4*)((float*)sg_out + o + 4) = f4{x[4], x[5], x[6], x[7]};
-                            } else {
-                                typedef u16 us8 __attribute__((ext_vector_type(8)));
-                                us8 pk;
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
-                                *(us8*)((u16*)sg_out + o) = pk;
-                            }
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
-                    }
-                }
-            } else {
-                // C/D fragment map of v_mfma_f32_16x16x32: row = (lane>>4)*4 + i, col = lane&15
-                const int erow = (lane >> 4) * 4, ecol = lane & 15;
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    if (e.geglu && (ni & 1)) continue;           // odd fragments are the gates of the even ones
-                    const int pcb = n0 + wn * WN + ni * 16;      // packed column block start
-                    if (pcb >= e.Nout) continue;
-                    const int pcol = pcb + ecol;                 // packed column (bias index)
-                    const int ocol = e.geglu ? ((pcb >> 5) << 4) + ecol : pcol;   // output column
-                    const int ocb = ocol - ecol;
-                    // segment lookup (segment boundaries are multiples of 16 -> uniform per fragment)
-                    int si = 0;
-#pragma unroll
-                    for (int k = 1; k < 3; ++k)
-                        if (k < e.nseg && ocb >= e.seg[k].col_begin) si = k;
-                    const IGemmSeg sg = si == 0 ? e.seg[0] : (si == 1 ? e.seg[1] : e.seg[2]);   // (constant indices: a dynamic one pins the whole descriptor in scratch)
-                    const int scol = ocol - sg.col_begin;
-                    const float bh = e.bias ? e.bias[pcol] : 0.f;
-                    const float bg = (e.geglu && e.bias) ? e.bias[pcol + 16] : 0.f;
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const int rbase = m0 + wm * WM + mi * 16 + erow;
-                        if (rbase >= e.M) continue;
-                        float v[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = rbase + i;
-                            float x = acc[mi][ni][i] + bh;
-                            if (e.rowvec && row < e.M) x += e.rowvec[(size_t)(row / e.rows_per_img) * e.rowvec_ld + pcol];
-                            if (e.geglu) {
-                                const float g = acc[mi][ni + (NI > 1 ? 1 : 0)][i] + bg;
-                                x = x * gelu_erf_f(g);
-                            }
-                            if (e.act == 1) x = silu_f(x);
-                            if (Rptr && row < e.M)
-                                x += e.res_f32 ? ((const float*)e.res)[res_row_of(e, row) * e.ldres + ocol] : (float)Rptr[res_row_of(e, row) * e.ldres + ocol];
-                            v[i] = x * ((e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale);
-                        }
-                        if (sg.fmt == SEG_ROW) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int row = rbase + i;
-                                if (row < e.M) store_from_f32(sg.out, (size_t)row * sg.ld + scol, sg.dtype, v[i]);
-                            }
-                        } else {
-                            const int img = rbase / sg.L, tok = rbase - img * sg.L;
-                            const int dimg = sg.img_map ? sg.img_map[img] : img;
-                            const size_t base = ((size_t)dimg * sg.ncols + scol) * sg.ld + tok;
-                            const bool vec = ((sg.L & 3) == 0) && ((sg.ld & 3) == 0) && (rbase + 3 < e.M);
-                            if (vec) {
-                                if (sg.dtype == DT_F16) {
-                                    h4 p = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                                    *(h4*)((half_t*)sg.out + base) = p;
-                                } else if (sg.dtype == DT_F32) {
-                                    *(f4*)((float*)sg.out + base) = f4{v[0], v[1], v[2], v[3]};
-                                } else {
-                                    typedef u16 us4 __attribute__((ext_vector_type(4)));
-                                    us4 p = {f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])};
-                                    *(us4*)((u16*)sg.out + base) = p;
-                                }
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    const int row = rbase + i;
-                                    if (row >= e.M) break;
-                                    const int im = row / sg.L, tk = row - im * sg.L;
-                                    const int dm = sg.img_map ? sg.img_map[im] : im;
-                                    store_from_f32(sg.out, ((size_t)dm * sg.ncols + scol) * sg.ld + tk, sg.dtype, v[i]);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
+    igemm_epilogue<BM, BN, WAVES_M, WAVES_N, SWAP, MinWaves<BM, BN, NW>::v>(a, acc, m0, n0, wm, wn, lane, wave, split, epi_smem);
+}
 
-        }
+// =====================================================================================================================
+// igemm8_kernel<NI, MODE>: the wide-tile main loop of round 4 -- 256 x (64 NI) x 64 tiles (NI = 4: 256 columns, NI = 5: 320), 8 waves
+// as 2 (M) x 4 (N), 128 x 16 NI per wave, in the 8-phase schedule of cdna_hip_programming.md ("The 256^2 8-phase template"):
+//
+//   * a k-tile (64 deep) lives in LDS as FOUR half-tiles sized by when they are consumed: A0 / A1 = the first / second 64 rows of
+//     both wave rows, B0 = fragments 0-1 and B1 = fragments 2.. of all four wave columns (fragment-major: one DMA pass = one
+//     fragment of every wave column); two buffers (k-tile parity);
+//   * a k-tile is four phases, one C quadrant each: {fragment reads of ONE sub-block (4-12 ds_read_b128), ONE half-tile of LDS-DMA
+//     for a later k-tile, barrier, 16-24 MFMAs, barrier}.  The two wave groups (wave row 0 / 1: one wave of each per SIMD) run one
+//     barrier apart, so the reads + DMA issue of one group sit under the MFMAs of the other;
+//   * the DMA queue is never drained in the loop: half-tiles are issued 5-6 phases before their first read and retired by counted
+//     s_waitcnt vmcnt(N) placed ONE phase before that read (the other group's barrier lies in between);
+//   * operands come in by buffer_load ... lds: a 32-bit byte offset per staged row (no 64-bit address arithmetic in the loop, the
+//     k offset rides in an SGPR), and a masked row -- conv halo, ragged M / N -- is an offset beyond num_records: the hardware
+//     writes zeros, no zero page, no select.
+//
+// Measured against the BK = 32 ring kernel above on the path's shapes (tools/experiments/gemm8_lab.hip, profiles/r04_gemm8_lab_*.txt):
+// 1.3-1.5x.  Accumulator fragments keep the layout of igemm_kernel, so the epilogue is shared.
+// MODE / a_split / split-K / tile order: as igemm_kernel.  Requirements (checked by the dispatcher): Cin % 64 == 0, swapped
+// epilogue, every operand tensor below 2 GiB.
+namespace g8 {
+constexpr unsigned OOB = 0x80000000u;          // voffset of a masked row: >= num_records of the descriptors below
+template <int NI> struct Lds {
+    static constexpr int NL = NI - 2;                         // fragments (and DMA passes) of the B1 sub-block
+    static constexpr int A0 = 0, A1 = 32 * 1024;              // buffer 1 of a region = its offset ^ the toggle
+    static constexpr int B0 = NI == 4 ? 64 * 1024 : 96 * 1024;
+    static constexpr int B1 = NI == 4 ? 96 * 1024 : 64 * 1024;
+    static constexpr int TOG_A = 16 * 1024, TOG_B0 = 16 * 1024, TOG_B1 = NI == 4 ? 16 * 1024 : 0x30000;      // 64K ^ 0x30000 = 128K
+    static constexpr int TOTAL = NI == 4 ? 128 * 1024 : 152 * 1024;
+};
+// position of a k-tile on the K axis (file scope: a struct local to the kernel, used as a lambda parameter, silently voids the
+// kernel's HOST stub -- the handle stays an undefined symbol that only a later executable link reports)
+struct KPos { int tap, ac, wk, hl; };
+}  // namespace g8
+
+#define G8_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define G8_PHASE_PRE()                                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_setprio(1);
+#define G8_PHASE_POST()                                    \
+    __builtin_amdgcn_s_setprio(0);                         \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_barrier();                          \
+    __builtin_amdgcn_sched_barrier(0);
+
+template <int NI, int MODE>
+__global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmArgs a, int ntm, int ntn, int splitk, int order) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef g8::Lds<NI> L;
+    constexpr int BM = 256, BN = 64 * NI, BK = 64, WN = 16 * NI, NL = L::NL;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nblk = ntm * ntn;
+    const int split = blockIdx.x / nblk;
+    const int first_bid = blockIdx.x - split * nblk;
+    int m0, n0;
+    {
+        int tile_m, tile_n;
+        tileorder::tile_of(first_bid, ntm, ntn, order, &tile_m, &tile_n);
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
     }
+
+    // ---- k range of this workgroup (split-K: a contiguous range of k-tiles; a (hi, lo) pair of the split-operand walk is never cut) ----
+    const bool paired = (a.a_split == 2);
+    const int Cw = a.Cin >> 1;
+    const int nk_total = a.Ktot / BK;
+    int nk_per = (nk_total + splitk - 1) / splitk;
+    if (paired) nk_per = (nk_per + 1) & ~1;
+    const int kt_begin = split * nk_per;
+    const int nk = min(nk_per, nk_total - kt_begin);
+
+    // ---- staging coordinates.  Pass i of a half-tile: this wave writes LDS rows (i*8 + wave)*8 + lane/8, 16-byte chunk lane%8 ----
+    const int lrow = lane >> 3, lpos = lane & 7;
+    // the chunk swizzle of LDS row j is (j >> 1) & 7 = ((wave & 1) * 4 + lrow / 2) & 7 for every pass: one swizzled source chunk per lane
+    const int c8b = ((lpos ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7)) * 8) * 2;        // bytes
+    const int pad = (a.taps == 9) ? 1 : 0;
+    const int VH = a.Hin * a.up, VW = a.Win * a.up;
+    const int ushift = (a.up == 2) ? 1 : 0;
+    const int lda2 = (int)a.lda * 2;
+    // per staged A row (sub-block sb, pass i = wave row): tile row i*128 + sb*64 + wave*8 + lane/8
+    //   ROWS     a_st = byte offset of the row's chunk, or OOB beyond M
+    //   TEMPORAL a_st = that offset (a multiple of 16) | bit t set when frame tap t of the row exists (bit 1 = the row itself)
+    //   CONV2D   a_st = image << 24 | (oy*stride - pad + 1) << 12 | (ox*stride - pad + 1)   (y field 0xfff beyond M: never in bounds);
+    //            a_cur = the offsets of the tap being walked (recomputed when a sub-block's tap changes: once per Cin / 64 k-tiles)
+    unsigned a_st[2][2], a_cur[2][2];
+    int cur_tap[2] = {-1, -1};
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + i * 128 + sb * 64 + wave * 8 + lrow;
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            a_cur[sb][i] = g8::OOB;
+            if (MODE == IG_ROWS) {
+                a_st[sb][i] = ok ? (unsigned)(mm * lda2 + c8b) : g8::OOB;
+            } else if (MODE == IG_CONV2D) {
+                const int hw = a.Hout * a.Wout;
+                const int n = mm / hw, rem = mm - n * hw;
+                const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+                const int yf = ok ? oy * a.stride - pad + 1 : 0xfff;
+                a_st[sb][i] = ((unsigned)n << 24) | ((unsigned)yf << 12) | (unsigned)(ox * a.stride - pad + 1);
+            } else {
+                const int fr = mm / a.HW;
+                unsigned base, bits;
+                if (a.t_pad) {
+                    // frame-sharded clip: A is the padded operand [clip][F + 2][HW][lda]; slots 0 / F + 1 hold the halo frames
+                    base = (unsigned)((mm + (2 * (fr / a.F) + 1) * a.HW) * lda2 + c8b);
+                    bits = 7u;
+                } else {
+                    const int f = fr % a.F;
+                    base = (unsigned)(mm * lda2 + c8b);
+                    bits = 2u | (f >= 1 ? 1u : 0u) | (f + 1 < a.F ? 4u : 0u);
+                }
+                a_st[sb][i] = ok ? (base | bits) : 0u;
+            }
+        }
+    // weight rows: LDS row f*64 + wn*16 + r of a B sub-block = fragment f (= DMA pass f) of wave column wn, so a lane stages the
+    // SAME row of consecutive fragments in consecutive passes: one offset per sub-block, + f*16 rows through the scalar offset
+    // (Nout is a multiple of the tile width here: no masked weight rows)
+    const int ldw2 = (paired ? a.Ktot / 2 : a.Ktot) * 2;      // bytes per weight row
+    const unsigned b0_vo = (unsigned)((n0 + ((wave * 8 + lrow) >> 4) * WN + ((wave * 8 + lrow) & 15)) * ldw2 + c8b);
+    const unsigned b1_vo = b0_vo + 32u * (unsigned)ldw2;
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)0x80000000u, 0x00020000);
+
+    // position of a k-tile in the K axis: tap, channel offset of the A chunk (bytes), k offset in a weight row (bytes).  The stream
+    // is staged in order, so positions advance incrementally (no division per k-tile)
+    typedef g8::KPos KPos;
+    auto kpos_init = [&](int ktg) __attribute__((always_inline)) {
+        KPos p;
+        if (paired) {
+            const int tpt = a.Cin / BK;
+            p.tap = ktg / tpt;
+            const int r = ktg - p.tap * tpt, pr = r >> 1;
+            p.hl = r & 1;
+            p.ac = (pr * BK + p.hl * Cw) * 2;
+            p.wk = (p.tap * Cw + pr * BK) * 2;
+        } else {
+            const int k0 = ktg * BK;
+            p.tap = (MODE == IG_ROWS) ? 0 : k0 / a.Cin;
+            p.ac = (k0 - p.tap * a.Cin) * 2;
+            p.wk = k0 * 2;
+            p.hl = 0;
+        }
+        return p;
+    };
+    auto kpos_next = [&](KPos p) __attribute__((always_inline)) {
+        if (paired) {
+            if (p.hl == 0) { p.hl = 1; p.ac += Cw * 2; }
+            else {
+                p.hl = 0; p.ac += (BK - Cw) * 2; p.wk += BK * 2;
+                if (p.ac == Cw * 2) { p.ac = 0; ++p.tap; }
+            }
+        } else {
+            p.ac += BK * 2; p.wk += BK * 2;
+            if (MODE != IG_ROWS && p.ac == a.Cin * 2) { p.ac = 0; ++p.tap; }
+        }
+        return p;
+    };
+
+    // LDS is addressed by byte offset (the kernel declares no static LDS, so the dynamic segment starts at 0): fragment reads are
+    // `per-lane base + immediate`, DMA destinations scalar arithmetic -- no relocation adds in the loop
+    typedef const h8 __attribute__((address_space(3)))* lds_h8_t;
+#define G8_LDS_DST(off) ((lptr_t)(size_t)(unsigned)(off))        // (a lambda returning an LDS pointer silently voids the host stub)
+    // A half-tile sb of the k-tile at p -> buffer buf
+    auto stage_a = [&](const int sb, const KPos p, const int buf) __attribute__((always_inline)) {
+        const int dst = ((sb ? L::A1 : L::A0) ^ (buf ? L::TOG_A : 0)) + wave * 1024;
+        if (MODE == IG_CONV2D && p.tap != cur_tap[sb]) {
+            cur_tap[sb] = p.tap;
+            int ky = 0, kx = 0;
+            if (a.taps == 9) { ky = (p.tap * 11) >> 5; kx = p.tap - 3 * ky; }
+            const int hwin = a.Hin * a.Win;
+            // (the operands are made opaque here: hoisted out of the k-loop, the unpacked fields of a_st cost eight more registers
+            // than the loop has, and their spill reloads drain the DMA queue)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int c8u = (((ln & 7) ^ ((((wave & 1) << 2) + (ln >> 4)) & 7)) * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned st = a_st[sb][i];
+                asm volatile("" : "+v"(st));
+                const int vy = (int)((st >> 12) & 0xfff) - 1 + ky, vx = (int)(st & 0xfff) - 1 + kx;
+                const bool ok = (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW;
+                const int pix = (int)(st >> 24) * hwin + (vy >> ushift) * a.Win + (vx >> ushift);
+                a_cur[sb][i] = ok ? (unsigned)(pix * lda2 + c8u) : g8::OOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned vo;
+            if (MODE == IG_ROWS) {
+                vo = a_st[sb][i];
+            } else if (MODE == IG_CONV2D) {
+                vo = a_cur[sb][i];
+            } else {
+                const unsigned st = a_st[sb][i];
+                vo = ((st >> p.tap) & 1u) ? (st & ~15u) + (unsigned)((p.tap - 1) * a.HW * lda2) : g8::OOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, G8_LDS_DST(dst + i * 8192), 16, vo, p.ac, 0, 0);
+        }
+    };
+    auto stage_b0 = [&](const KPos p, const int buf) __attribute__((always_inline)) {
+        const int dst = (L::B0 ^ (buf ? L::TOG_B0 : 0)) + wave * 1024;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, G8_LDS_DST(dst + f * 8192), 16, b0_vo, p.wk + f * 16 * ldw2, 0, 0);
+    };
+    auto stage_b1 = [&](const KPos p, const int buf) __attribute__((always_inline)) {
+        const int dst = (L::B1 ^ (buf ? L::TOG_B1 : 0)) + wave * 1024;
+#pragma unroll
+        for (int f = 0; f < NL; ++f) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, G8_LDS_DST(dst + f * 8192), 16, b1_vo, p.wk + f * 16 * ldw2, 0, 0);
+    };
+
+    // ---- fragment reads: one per-lane base per operand and k-step (second k-step = logical chunk + 4 = address ^ 64), everything
+    //      else an immediate; the buffer toggles by XOR ----
+    const int frow = lane & 15, fch = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    int ra0 = (wm * 64 + frow) * 128 + ((fch ^ sw) << 4);                           // + A0 | A1 + mi*2048
+    int rb00 = L::B0 + (wn * 16 + frow) * 128 + ((fch ^ sw) << 4);                  // + f*8192
+    int rb10 = L::B1 + (wn * 16 + frow) * 128 + ((fch ^ sw) << 4);                  // + f*8192
+    int ra1 = ra0 ^ 64, rb01 = rb00 ^ 64, rb11 = rb10 ^ 64;
+
+    f4 acc[8][NI];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+
+    h8 af[2][4], b0f[2][2], b1f[2][NL];       // [k-step][fragment]
+    auto read_a = [&](const int sb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *(lds_h8_t)(size_t)(unsigned)((kk ? ra1 : ra0) + (sb ? L::A1 : L::A0) + mi * 2048);
+    };
+    auto read_b0 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) b0f[kk][f] = *(lds_h8_t)(size_t)(unsigned)((kk ? rb01 : rb00) + f * 8192);
+    };
+    auto read_b1 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int f = 0; f < NL; ++f) b1f[kk][f] = *(lds_h8_t)(size_t)(unsigned)((kk ? rb11 : rb10) + f * 8192);
+    };
+    // one C quadrant: rows as*64.. of the wave tile x fragments of one B sub-block (operands swapped: D = W . A^T)
+    auto mma_b0 = [&](const int as) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+                    acc[as * 4 + mi][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0f[kk][f], af[kk][mi], acc[as * 4 + mi][f], 0, 0, 0);
+    };
+    auto mma_b1 = [&](const int as) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int f = 0; f < NL; ++f)
+                    acc[as * 4 + mi][2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1f[kk][f], af[kk][mi], acc[as * 4 + mi][2 + f], 0, 0, 0);
+    };
+
+    // Issue order of the half-tiles: A0, B0, B1, A1 of k-tile 0, A0, B0 of k-tile 1 (prologue), then one per phase --
+    //   phase 0 of k-tile e: B1[e+1]   phase 1: A1[e+1]   phase 2: A0[e+2]   phase 3: B0[e+2]
+    // -- each into a region whose last read lies at least two phases back (the other wave group's reads of phase p are only known
+    // complete after ITS second barrier of phase p).  Reads: A0[e], B0[e] in phase 0, B1[e] in phase 1, A1[e] in phase 2; b0 stays in
+    // registers for phase 3.  A half-tile is waited for ONE phase before its first read: B1[e] in phase 0, A1[e] in phase 1,
+    // A0 / B0[e+1] in phase 3.  The counter retires in order, so "at most n younger loads in flight" = the wanted one has landed;
+    // the younger ones are always four half-tiles = 6 + NL loads while the stream lasts (n1: k-tile e+1 exists, n2: e+2 exists).
+    // (the immediates are spelled out per NL: an "n" operand that depends on a template parameter silently voids the HOST stub of
+    // the kernel -- the handle stays an undefined symbol and only the tools' link step notices)
+#define G8_VMCNT_W4() do { if constexpr (NL == 2) G8_VMCNT(8); else G8_VMCNT(9); } while (0)     /* four half-tiles: 6 + NL loads */
+#define G8_VMCNT_W2() do { if constexpr (NL == 2) G8_VMCNT(4); else G8_VMCNT(5); } while (0)     /* B1 + A1: NL + 2 loads */
+    KPos p1, p2;                              // positions of k-tiles e+1 and e+2
+    {
+        const KPos p0 = kpos_init(kt_begin);
+        stage_a(0, p0, 0); stage_b0(p0, 0); stage_b1(p0, 0); stage_a(1, p0, 0);
+        p1 = kpos_next(p0);
+        if (nk > 1) { stage_a(0, p1, 1); stage_b0(p1, 1); G8_VMCNT_W4(); } else G8_VMCNT_W2();
+        p2 = kpos_next(p1);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // the second wave group runs one barrier behind
+
+    for (int e = 0; e < nk; ++e) {
+        const bool n1 = e + 1 < nk, n2 = e + 2 < nk;
+        const int nb = (e + 1) & 1;                     // buffer of k-tile e+1; k-tile e+2 goes where k-tile e is
+        // phase 0: a0, b0 | stage B1[e+1] | wait B1[e]
+        read_b0();
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(0);
+        if (n1) { stage_b1(p1, nb); G8_VMCNT_W4(); } else G8_VMCNT(2);
+        G8_PHASE_PRE();
+        mma_b0(0);
+        G8_PHASE_POST();
+        // phase 1: b1 | stage A1[e+1] | wait A1[e]
+        read_b1();
+        if (n1) { stage_a(1, p1, nb); G8_VMCNT_W4(); } else G8_VMCNT(0);
+        G8_PHASE_PRE();
+        mma_b1(0);
+        G8_PHASE_POST();
+        // phase 2: a1 | stage A0[e+2]
+        read_a(1);
+        if (n2) stage_a(0, p2, nb ^ 1);
+        G8_PHASE_PRE();
+        mma_b1(1);
+        G8_PHASE_POST();
+        // phase 3: (b0 still in registers) | stage B0[e+2] | wait A0[e+1], B0[e+1]
+        if (n2) { stage_b0(p2, nb ^ 1); G8_VMCNT_W4(); } else if (n1) G8_VMCNT_W2();
+        G8_PHASE_PRE();
+        mma_b0(1);
+        G8_PHASE_POST();
+        ra0 ^= L::TOG_A; ra1 ^= L::TOG_A; rb00 ^= L::TOG_B0; rb01 ^= L::TOG_B0; rb10 ^= L::TOG_B1; rb11 ^= L::TOG_B1;
+        p1 = p2;
+        p2 = kpos_next(p2);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+
+    igemm_epilogue<BM, BN, 2, 4, true, 1>(a, acc, m0, n0, wm, wn, lane, wave, split, smem_raw);
 }
 
 // split-K tail: out = epilogue( sum_s slab[s] ), 8 consecutive columns per thread (row-major outputs only)
@@ -848,6 +1189,69 @@ bool can_swap(const IGemmArgs& a) {
     return swap;
 }
 
+// the 8-phase wide-tile kernel (igemm8_kernel) can take this problem: swapped epilogue, whole 64-deep k-tiles per tap, 32-bit offsets
+// CTRL_IGEMM8: "0" never, "force" whenever the problem is eligible (any grid size: the parity tests run their small shapes
+// through it this way), default = where the grid fills the chip
+int igemm8_mode() {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("CTRL_IGEMM8"); mode = !e ? 1 : (e[0] == '0' ? 0 : (!strcmp(e, "force") ? 2 : 1)); }
+    return mode;
+}
+bool can_use8(const IGemmArgs& a) {
+    if (!igemm8_mode() || !can_swap(a)) return false;
+    if (a.Cin % 64 != 0 || (a.a_split == 2 && ((a.Cin / 2) % 64 != 0 || a.mode == IG_TEMPORAL))) return false;
+    // conv rows are packed as image (8 bits) | y + 1 (12 bits) | x + 1 (12 bits)
+    if (a.mode == IG_CONV2D && ((double)a.M / ((double)a.Hout * a.Wout) > 256.0 || a.Hin * a.up > 4000 || a.Win * a.up > 4000 ||
+                                 a.Hout * a.stride > 4000 || a.Wout * a.stride > 4000)) return false;
+    double abytes;
+    if (a.mode == IG_CONV2D) abytes = (double)a.M / ((double)a.Hout * a.Wout) * a.Hin * a.Win * a.lda * 2.0;
+    else if (a.mode == IG_TEMPORAL && a.t_pad) abytes = ((double)a.M + 2.0 * a.HW * ((double)a.M / ((double)a.F * a.HW))) * a.lda * 2.0;
+    else abytes = (double)a.M * a.lda * 2.0;
+    return abytes < 2147483648.0 && (double)a.Nout * a.Ktot * 2.0 < 2147483648.0;
+}
+
+template <int NI, int MODE>
+int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
+    constexpr int BM = 256, BN = 64 * NI;
+    constexpr size_t ring = g8::Lds<NI>::TOTAL;
+    constexpr int stage_w = 128 > 16 * NI ? 128 : 16 * NI;                                            // row / transposed staging of the shared epilogue
+    constexpr size_t stage_bytes = (size_t)8 * 16 * (stage_w + 4) * sizeof(float);
+    constexpr size_t smem = ring > stage_bytes ? ring : stage_bytes;
+    static bool attr_done[kMaxDevices] = {};
+    const int dev = cur_device();
+    if (!attr_done[dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)igemm8_kernel<NI, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done[dev] = true;
+    }
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
+    const int order = plan_order(a, BM, BN, ntm, ntn);
+    const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
+    PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
+    prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
+    const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
+    const auto sym = [&]() { prof_symbol("igemm8_kernel<%d, %d>", NI, MODE); };
+    if (splitk > 1) {
+        IGemmArgs p = a;
+        p.bias = nullptr; p.rowvec = nullptr; p.res = nullptr; p.res_f32 = 0; p.act = 0; p.scale = 1.f; p.out16 = nullptr;
+        p.blend_mix = nullptr; p.blend_x = nullptr;
+        p.nseg = 1;
+        p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
+        prof_detail("M%d N%d K%d taps%d%s splitk%d", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
+        sym();
+        LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn * splitk), dim3(512), smem, s, p, ntm, ntn, splitk, order);
+        const size_t total = (size_t)a.M * (a.Nout / 8);
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        PROF_WORK(0, 4.0 * splitk * a.M * a.Nout);
+        prof_detail("M%d N%d splitk%d", a.M, a.Nout, splitk);
+        LAUNCH("splitk_finish", splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)a.splitk_ws, splitk);
+        return 0;
+    }
+    sym();
+    LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn, 1, order);
+    return 0;
+}
+
 }  // namespace
 
 // number of K splits op_igemm will use for this problem (1 = none); callers size splitk_ws = factor*M*Nout*4 bytes
@@ -901,6 +1305,8 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     {
         const int sk = (a.splitk_ws && can_swap(a)) ? igemm_splitk_factor(a) : 1;
         if (sk > 1 && (size_t)a.splitk_ws_bytes >= (size_t)sk * a.M * a.Nout * sizeof(float) && (((uintptr_t)a.splitk_ws & 15) == 0)) {
+            if (can_use8(a) && a.Nout % 320 == 0) return launch8<5, MODE>(a, s, sk);
+            if (can_use8(a) && a.Nout % 256 == 0) return launch8<4, MODE>(a, s, sk);
             if (a.Nout % 320 == 0) return launch_cfg2<256, 320, 32, 2, 4, 4, MODE, true>(a, s, sk);
             return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
         }
@@ -917,13 +1323,22 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     // resident workgroups per CU let one's epilogue -- the GEGLU math, or the HBM-bound fp32 residual read + fp32 master +
     // fp16 mirror write of a stream update -- run under the other's k-loop.  GEGLU 512->4096 at M = 131072: 562 -> 677
     // TFLOP/s (256x128); stream updates K = 320: 182 -> 217 (128x256), K = 2048: 551 -> 603 (256x128).
-    if (MODE == IG_ROWS && a.M >= 65536 && can_swap(a) && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && a.Nout % 128 == 0) {
+    // Epilogue-heavy token GEMMs at large M with a SHORT k-loop (measured, tools/tile_experiment.py -> profiles/r02_tile_experiment.log,
+    // re-measured against the 8-phase kernel in round 4, profiles/r04_step_old_vs_8phase.txt): two resident workgroups per CU let
+    // one's epilogue -- the GEGLU math, or the HBM-bound fp32 residual read + fp32 master + fp16 mirror write of a stream update --
+    // run under the other's k-loop, which the one-workgroup-per-CU wide tile cannot.  GEGLU 512 -> 4096 at M = 131072: 653 (256x128
+    // pair) vs 635 TFLOP/s (8-phase); stream update K = 320: 273 vs 221.  From K = 2048 on the 8-phase loop wins (815 vs 740).
+    const bool force8 = igemm8_mode() == 2;
+    if (!force8 && MODE == IG_ROWS && a.M >= 65536 && can_swap(a) && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && a.Nout % 256 == 0) {
         const bool f32_stream = a.seg[0].dtype == DT_F32 || (a.res && a.res_f32);      // fp32 rows written and / or read per element
-        if (a.geglu && a.Nout % 256 == 0) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
-        if (f32_stream && a.Nout % 256 == 0) {
-            if (a.Ktot > 1024) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
-            return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
-        }
+        if (a.geglu) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
+        if (f32_stream && a.Ktot <= 1024) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
+    }
+    // the 8-phase wide tiles wherever the grid fills the chip with them (1.3-1.5x the BK = 32 ring kernel on plain epilogues and
+    // long k-loops: convolutions 543 -> 671 TFLOP/s as a class)
+    if (can_use8(a) && (getenv("CTRL_IGEMM_FORCE") == nullptr)) {
+        if (a.Nout % 320 == 0 && (tiles(256, 320) >= 160 || force8) && !a.geglu) return launch8<5, MODE>(a, s);
+        if (a.Nout % 256 == 0 && (tiles(256, 256) >= 200 || force8)) return launch8<4, MODE>(a, s);
     }
     // (vector-epilogue variant only: the scalar-epilogue one does not fit the register file at this tile size)
     if (tiles(256, 256) >= 200 && eff(256) > 0.9 && can_swap(a)) return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s);
