@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
@@ -53,6 +54,28 @@ __device__ __forceinline__ int chunk_swz(int row) {
 // 128x256 / 256x128 tiles of 8 waves keep two workgroups resident per CU (72 KiB of LDS ring, <= 128 VGPRs per wave): one
 // workgroup's epilogue (HBM-bound fp32 stream traffic, GEGLU math) overlaps the other one's k-loop
 template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (BM * BN == 128 * 256) ? (NW == 8 ? 4 : (NW == 4 ? 2 : 1)) : 1; };
+
+// Eight residual values of output row `row` from column `col` on, as fp32 (the fp32 stream or an fp16 tensor; `up2`: held at half
+// the output resolution and read through a nearest x2 up-sampling, see res_row_of).  32-bit element offsets (checked by op_igemm).
+struct ResSrc { const void* p; unsigned ld; bool f32, up2; int hw, w, hh, wh; };
+__device__ __forceinline__ void res_fetch8(const ResSrc& r, int row, int col, f4& a0, f4& a1) {
+    unsigned rrow = (unsigned)row;
+    if (r.up2) {
+        const int n = row / r.hw, rem = row - n * r.hw;
+        const int oy = rem / r.w, ox = rem - oy * r.w;
+        rrow = (unsigned)((n * r.hh + (oy >> 1)) * r.wh + (ox >> 1));
+    }
+    const unsigned o = rrow * r.ld + (unsigned)col;
+    if (r.f32) {
+        const float* rp = (const float*)r.p + o;
+        a0 = *(const f4*)rp;
+        a1 = *(const f4*)(rp + 4);
+    } else {
+        const h8 rr = *(const h8*)((const half_t*)r.p + o);
+        a0 = f4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
+        a1 = f4{(float)rr[4], (float)rr[5], (float)rr[6], (float)rr[7]};
+    }
+}
 
 // ---------------- epilogue of an accumulated tile (m0, n0), shared by every main loop of this file ----------------
 // acc[mi][ni]: the 16x16 fragments of the wave tile (WM x WN at wave position (wm, wn)); epi_smem: the workgroup's LDS, dead
@@ -141,167 +164,185 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                 }
             }
         } else {
+            // Row-major outputs.  Per 16-row slab of the wave tile: bias / time vector / GEGLU / SiLU in the fragment layout, the slab
+            // through a wave-private LDS area, then 8-column pieces of full rows: residual, scale, blend, mirror, store.  Everything a
+            // piece needs that does not depend on the slab -- its row and column inside the slab (a division by a COMPILE-TIME piece
+            // count: the run-time one cost ~40 VALU per piece), its segment, its scale, its byte offsets -- is computed once per tile;
+            // with one workgroup per CU nothing overlaps this code, and its instruction count is the per-tile fixed cost of every
+            // short-K GEMM of the path (round 4: 22 -> ~10 us per 256x256 tile).
             constexpr int OWMAX = WN;                          // output columns of the wave tile (half of it with GEGLU)
             constexpr int SLD = OWMAX + 4;                     // floats; +16 B keeps the b128 accesses conflict-light
             float* stg = (float*)epi_smem + wave * (16 * SLD);
             const int erow = lane & 15, ecol = (lane >> 4) * 4;
-            const int OW = e.geglu ? WN / 2 : WN;
-            const int OWC = OW >> 3;                           // 8-column chunks per row
-            const int wcol0 = e.geglu ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN);     // first output column of the wave tile
-            const int nout_eff = e.geglu ? (e.Nout >> 1) : e.Nout;
-            // the bias depends on the column only: one load per fragment column, issued together up front -- fetched
-            // inside the mi loop, every 16-row slab stalled on its own load (and on every store before it: one vmcnt)
-            f4 bias_v[NI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int pcb = n0 + wn * WN + ni * 16;
-                bias_v[ni] = (e.bias && pcb < e.Nout) ? *(const f4*)(e.bias + pcb + ecol) : f4{0.f, 0.f, 0.f, 0.f};
-            }
-            // fp32 residual (the fp32 stream updates, HBM-bound): the 8-column pieces a lane adds are fetched one slab
-            // AHEAD, each refill issued before the stores of its own slab, so that waiting for it never means waiting
-            // for a store (loads and stores share one in-order counter)
-            constexpr int RT = (16 * (OWMAX / 8) + 63) / 64;       // pieces per lane per 16-row slab
-            // ... fetched ahead: the wide one-workgroup-per-CU tiles only (256 registers per wave; the two-workgroup
-            // tiles live in 128 and overlap their epilogue with the other workgroup's k-loop instead); the 80-wide wave
-            // tile (three pieces per lane, 160 accumulator registers) has room for one
-            constexpr bool RES_AHEAD = (WM * WN >= 128 * 64) && MINW == 1;
-            constexpr int RTP = !RES_AHEAD ? 0 : (RT > 2 ? 1 : RT);
-            f4 rf0[RTP ? RTP : 1], rf1[RTP ? RTP : 1];
-#pragma unroll
-            for (int t = 0; t < RTP; ++t) {
-                rf0[t] = rf1[t] = f4{0.f, 0.f, 0.f, 0.f};
-                const int idx = lane + 64 * t;
-                if (Rptr && e.res_f32 && idx < 16 * OWC) {
-                    const int r = idx / OWC, c8 = idx - r * OWC;
-                    const int row = m0 + wm * WM + r, ocol = wcol0 + c8 * 8;
-                    if (row < e.M && ocol < nout_eff) {
-                        const float* rp = (const float*)e.res + res_row_of(e, row) * e.ldres + ocol;
-                        rf0[t] = *(const f4*)rp;
-                        rf1[t] = *(const f4*)(rp + 4);
-                    }
-                }
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int row_w = m0 + wm * WM + mi * 16 + erow;
+            const bool gg = e.geglu != 0;
+            void* s1_out = e.seg[1].out; void* s2_out = e.seg[2].out;
+            int64_t s1_ld = e.seg[1].ld, s2_ld = e.seg[2].ld;
+            int s1_cb = e.seg[1].col_begin, s2_cb = e.seg[2].col_begin, s1_dt = e.seg[1].dtype, s2_dt = e.seg[2].dtype;
+            asm volatile("" : "+s"(s1_out), "+s"(s2_out), "+s"(s1_ld), "+s"(s2_ld), "+s"(s1_cb), "+s"(s2_cb), "+s"(s1_dt), "+s"(s2_dt));
+            const int wcol0 = gg ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN);     // first output column of the wave tile
+            const int nout_eff = gg ? (e.Nout >> 1) : e.Nout;
+            const int wrow0 = m0 + wm * WM;
+            // column-only terms, fetched once per tile (or per image): cv = bias + the per-image vector while the 16 rows of a slab
+            // share an image (slabs start at multiples of 16); ONE register vector per fragment column -- the 80-wide wave tile
+            // has no room for two
+            const bool rv_uniform = MINW == 1 && e.rowvec && (e.rows_per_img % 16) == 0;      // (MINW > 1: the 128-register tiles spill with it)
+            f4 cv[NI];
+            auto load_cv = [&](int img) __attribute__((always_inline)) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    if (e.geglu && (ni & 1)) continue;
                     const int pcb = n0 + wn * WN + ni * 16;
-                    if (pcb >= e.Nout) continue;
-                    const int pcol = pcb + ecol;
-                    f4 x = acc[mi][ni];
-                    if (e.bias) x += bias_v[ni];
-                    if (e.rowvec && row_w < e.M) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcol);
-                    if (e.geglu) {
-                        f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)];
-                        if (e.bias) g += bias_v[ni + 1 < NI ? ni + 1 : ni];      // the gate's columns = the next fragment's
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
-                    }
-                    if (e.act == 1) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
-                    }
-                    const int lcol = (e.geglu ? (ni >> 1) * 16 : ni * 16) + ecol;
-                    *(f4*)(stg + erow * SLD + lcol) = x;
+                    cv[ni] = (e.bias && pcb < e.Nout) ? *(const f4*)(e.bias + pcb + ecol) : f4{0.f, 0.f, 0.f, 0.f};
+                    if (rv_uniform && pcb < e.Nout && !(gg && (ni & 1))) cv[ni] += *(const f4*)(e.rowvec + (size_t)img * e.rowvec_ld + pcb + ecol);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are in order; pin compiler order
+            };
+            int img_cur = 0, img_rem = 0;
+            if (rv_uniform) { img_cur = wrow0 / e.rows_per_img; img_rem = wrow0 - img_cur * e.rows_per_img; }
+            int cv_img = img_cur;
+            load_cv(img_cur);
+            // the slab loop, for a compile-time number of 8-column pieces per staged row
+            auto run = [&](auto owc_) __attribute__((always_inline)) {
+                constexpr int OWC = decltype(owc_)::value;
+                constexpr int RT = (16 * OWC + 63) / 64;               // pieces per lane per slab
+                // residual pieces fetched AHEAD of their slab (depth RD), each refill issued before the stores of its own slab so that
+                // waiting for it never means waiting for a store (one in-order counter): one slab ahead left every slab stalled
+                // on a full memory latency with one workgroup per CU.  The 128-register two-workgroup tiles fetch at use.
+                constexpr int RD = (MINW > 1 || WM * WN < 128 * 64 || NI > 4) ? 0 : 2;      // (the 80-wide wave tile has no registers to spare)
+                // piece t of a lane: row pr(t) of the slab, output columns oc(t) .. + 8 (recomputed where used -- a shift or a
+                // multiply-high by a constant -- rather than kept: the 128-register two-workgroup tiles have nothing to spare)
+                auto pr = [&](int t) __attribute__((always_inline)) { return (lane + 64 * t) / OWC; };
+                auto oc = [&](int t) __attribute__((always_inline)) { const int idx = lane + 64 * t; return wcol0 + (idx - (idx / OWC) * OWC) * 8; };
+                auto pv = [&](int t) __attribute__((always_inline)) { return lane + 64 * t < 16 * OWC && oc(t) < nout_eff; };
+                const bool has_res = Rptr != nullptr;
+                f4 rf[RD ? RD : 1][RT][2];
+                const ResSrc rs = {e.res, (unsigned)e.ldres, e.res_f32 != 0, e.res_up == 2, e.Hout * e.Wout, e.Wout, e.Hout >> 1, e.Wout >> 1};
+                if (has_res) {
 #pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    const int idx = lane + 64 * t;
-                    if (idx >= 16 * OWC) continue;
-                    const int r = idx / OWC, c8 = idx - r * OWC;
-                    const int row = m0 + wm * WM + mi * 16 + r;
-                    const int ocol = wcol0 + c8 * 8;
-                    if (row >= e.M || ocol >= nout_eff) continue;
-                    const f4 v0 = *(const f4*)(stg + r * SLD + c8 * 8), v1 = *(const f4*)(stg + r * SLD + c8 * 8 + 4);
-                    float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    if (Rptr) {
-                        if (e.res_f32) {
-                            if (t < RTP) {
-                                const int tp = t < RTP ? t : 0;
+                    for (int d = 0; d < RD; ++d)
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) { x[i] += rf0[tp][i]; x[4 + i] += rf1[tp][i]; }
-                                if (mi + 1 < MI && row + 16 < e.M) {       // refill for the same piece of the next slab
-                                    const float* rp = (const float*)e.res + res_row_of(e, row + 16) * e.ldres + ocol;
-                                    rf0[tp] = *(const f4*)rp;
-                                    rf1[tp] = *(const f4*)(rp + 4);
-                                }
+                        for (int t = 0; t < RT; ++t) {
+                            rf[d][t][0] = rf[d][t][1] = f4{0.f, 0.f, 0.f, 0.f};
+                            const int row = wrow0 + d * 16 + pr(t);
+                            if (d < MI && pv(t) && row < e.M) res_fetch8(rs, row, oc(t), rf[d][t][0], rf[d][t][1]);
+                        }
+                }
+                const float al = e.blend_mix ? __builtin_amdgcn_rcpf(1.0f + __expf(-e.blend_mix[0])) : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int row_w = wrow0 + mi * 16 + erow;
+                    if (rv_uniform) {
+                        if (img_cur != cv_img) { cv_img = img_cur; load_cv(img_cur); }      // (wave-uniform) the slab starts a new image
+                        img_rem += 16;
+                        if (img_rem >= e.rows_per_img) { img_rem -= e.rows_per_img; ++img_cur; }
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        if (gg && (ni & 1)) continue;
+                        const int pcb = n0 + wn * WN + ni * 16;
+                        if (pcb >= e.Nout) continue;
+                        f4 x = acc[mi][ni] + cv[ni];
+                        if (!rv_uniform && e.rowvec && row_w < e.M) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcb + ecol);
+                        if (gg) {
+                            const f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)] + cv[ni + 1 < NI ? ni + 1 : ni];      // the gate's columns = the next fragment's
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
+                        }
+                        if (e.act == 1) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
+                        }
+                        const int lcol = (gg ? (ni >> 1) * 16 : ni * 16) + ecol;
+                        *(f4*)(stg + erow * SLD + lcol) = x;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS ops are in order; pin compiler order
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        const int prt = pr(t);
+                        const int row = wrow0 + mi * 16 + prt;
+                        if (!pv(t) || row >= e.M) continue;
+                        const int ocol = oc(t);
+                        const int c8o = (ocol - wcol0);
+                        const f4 v0 = *(const f4*)(stg + prt * SLD + c8o), v1 = *(const f4*)(stg + prt * SLD + c8o + 4);
+                        float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        if (has_res) {
+                            f4 r0, r1;
+                            if constexpr (RD > 0) {
+                                r0 = rf[mi % RD][t][0];
+                                r1 = rf[mi % RD][t][1];
+                                if (mi + RD < MI && row + 16 * RD < e.M) res_fetch8(rs, row + 16 * RD, ocol, rf[mi % RD][t][0], rf[mi % RD][t][1]);     // refill: same piece, RD slabs on
                             } else {
-                                const float* rp = (const float*)e.res + res_row_of(e, row) * e.ldres + ocol;
-                                const f4 r0 = *(const f4*)rp, r1 = *(const f4*)(rp + 4);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) { x[i] += r0[i]; x[4 + i] += r1[i]; }
+                                res_fetch8(rs, row, ocol, r0, r1);
                             }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { x[i] += r0[i]; x[4 + i] += r1[i]; }
+                        }
+                        {
+                            // an 8-column chunk never straddles scale2_from (a multiple of 8, checked by op_igemm)
+                            const float sc = (e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) x[i] *= sc;
+                        }
+                        if (e.blend_mix) {   // AlphaBlender fold: (1-a) * this branch + a * the other branch
+                            float bx[8];
+                            if (e.blend_f32) {
+                                const float* bp = (const float*)e.blend_x + (unsigned)((unsigned)row * (unsigned)e.ld_blend + (unsigned)ocol);
+                                const f4 b0 = *(const f4*)bp, b1 = *(const f4*)(bp + 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { bx[i] = b0[i]; bx[4 + i] = b1[i]; }
+                            } else {
+                                const h8 bb = *(const h8*)((const half_t*)e.blend_x + (unsigned)((unsigned)row * (unsigned)e.ld_blend + (unsigned)ocol));
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) bx[i] = (float)bb[i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
+                        }
+                        if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
+                            h8 pk;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
+                            const unsigned o16 = (unsigned)row * (unsigned)e.ld16 + (unsigned)ocol;
+                            *(h8*)((half_t*)e.out16 + o16) = pk;
+                            if (e.out16_lo_off) {      // split operand: the rounding residual rides along (hi + lo == x to ~2^-22)
+                                h8 lo;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) lo[i] = (half_t)(x[i] - (float)pk[i]);
+                                *(h8*)((half_t*)e.out16 + e.out16_lo_off + o16) = lo;
+                            }
+                        }
+                        // Segment of this 8-column piece (the last one whose first column is <= ocol): its fields selected VALUE by
+                        // value from scalars (s1_* / s2_*, made opaque above: left to itself the compiler turns "select between two
+                        // loaded kernel-argument fields" into "load from a selected address", which moves the whole descriptor to
+                        // scratch for the entire kernel -- every argument read then waits on vmcnt)
+                        const bool in1 = e.nseg > 1 && ocol >= s1_cb, in2 = e.nseg > 2 && ocol >= s2_cb;
+                        void* const sg_out = in2 ? s2_out : (in1 ? s1_out : e.seg[0].out);
+                        const int64_t sg_ld = in2 ? s2_ld : (in1 ? s1_ld : e.seg[0].ld);
+                        const int sg_cb = in2 ? s2_cb : (in1 ? s1_cb : e.seg[0].col_begin);
+                        const int sg_dt = in2 ? s2_dt : (in1 ? s1_dt : e.seg[0].dtype);
+                        // 32-bit element offsets off the (scalar) bases: checked on the host (op_igemm: every row-major operand of the epilogue
+                        // spans < 2^32 elements); 64-bit per-lane addresses cost the 80-wide wave tile its last registers
+                        const unsigned o = (unsigned)row * (unsigned)sg_ld + (unsigned)(ocol - sg_cb);
+                        if (sg_dt == DT_F16) {
+                            h8 pk;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
+                            *(h8*)((half_t*)sg_out + o) = pk;
+                        } else if (sg_dt == DT_F32) {
+                            float* const op = (float*)sg_out + (size_t)split * e.M * e.Nout;       // split > 0 only for fp32 slabs
+                            *(f4*)(op + o) = f4{x[0], x[1], x[2], x[3]};
+                            *(f4*)(op + o + 4) = f4{x[4], x[5], x[6], x[7]};
                         } else {
-                            const h8 rr = *(const h8*)(Rptr + res_row_of(e, row) * e.ldres + ocol);
+                            typedef u16 us8 __attribute__((ext_vector_type(8)));
+                            us8 pk;
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) x[i] += (float)rr[i];
+                            for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
+                            *(us8*)((u16*)sg_out + o) = pk;
                         }
                     }
-                    {
-                        // an 8-column chunk never straddles scale2_from (a multiple of 8, checked by op_igemm)
-                        const float sc = (e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) x[i] *= sc;
-                    }
-                    if (e.blend_mix) {   // AlphaBlender fold: (1-a) * this branch + a * the other branch
-                        const float al = __builtin_amdgcn_rcpf(1.0f + __expf(-e.blend_mix[0]));
-                        float bx[8];
-                        if (e.blend_f32) {
-                            const float* bp = (const float*)e.blend_x + (size_t)row * e.ld_blend + ocol;
-                            const f4 b0 = *(const f4*)bp, b1 = *(const f4*)(bp + 4);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { bx[i] = b0[i]; bx[4 + i] = b1[i]; }
-                        } else {
-                            const h8 bb = *(const h8*)((const half_t*)e.blend_x + (size_t)row * e.ld_blend + ocol);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) bx[i] = (float)bb[i];
-                        }
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
-                    }
-                    if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
-                        h8 pk;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
-                        *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + ocol) = pk;
-                        if (e.out16_lo_off) {      // split operand: the rounding residual rides along (hi + lo == x to ~2^-22)
-                            h8 lo;
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) lo[i] = (half_t)(x[i] - (float)pk[i]);
-                            *(h8*)((half_t*)e.out16 + (size_t)row * e.ld16 + e.out16_lo_off + ocol) = lo;
-                        }
-                    }
-                    // Segment of this 8-column piece (the last one whose first column is <= ocol).  The descriptors are
-                    // kernel arguments, i.e. scalars: selected FIELD by FIELD they stay in scalar registers.  Selecting the
-                    // struct (`seg[si]`, si per lane) made every lane load its copy from memory and wait for it -- and, the
-                    // counter being shared and in order, for every store issued before it -- once per 16-byte piece.
-                    const bool in1 = e.nseg > 1 && ocol >= e.seg[1].col_begin, in2 = e.nseg > 2 && ocol >= e.seg[2].col_begin;
-                    void* const sg_out = in2 ? e.seg[2].out : (in1 ? e.seg[1].out : e.seg[0].out);
-                    const int64_t sg_ld = in2 ? e.seg[2].ld : (in1 ? e.seg[1].ld : e.seg[0].ld);
-                    const int sg_cb = in2 ? e.seg[2].col_begin : (in1 ? e.seg[1].col_begin : e.seg[0].col_begin);
-                    const int sg_dt = in2 ? e.seg[2].dtype : (in1 ? e.seg[1].dtype : e.seg[0].dtype);
-                    const size_t o = (size_t)row * sg_ld + (ocol - sg_cb) + (size_t)split * e.M * e.Nout;   // split > 0 only for fp32 slabs
-                    if (sg_dt == DT_F16) {
-                        h8 pk;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) pk[i] = (half_t)x[i];
-                        *(h8*)((half_t*)sg_out + o) = pk;
-                    } else if (sg_dt == DT_F32) {
-                        *(f4*)((float*)sg_out + o) = f4{x[0], x[1], x[2], x[3]};
-                        *(f4*)((float*)sg_out + o + 4) = f4{x[4], x[5], x[6], x[7]};
-                    } else {
-                        typedef u16 us8 __attribute__((ext_vector_type(8)));
-                        us8 pk;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) pk[i] = f32_to_bf16(x[i]);
-                        *(us8*)((u16*)sg_out + o) = pk;
-                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slab reads retired before the next slab is written
-            }
+            };
+            if (gg) run(std::integral_constant<int, (OWMAX / 16 > 0 ? OWMAX / 16 : 1)>{});
+            else run(std::integral_constant<int, OWMAX / 8>{});
         }
     } else {
         // C/D fragment map of v_mfma_f32_16x16x32: row = (lane>>4)*4 + i, col = lane&15
@@ -319,7 +360,24 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
 #pragma unroll
             for (int k = 1; k < 3; ++k)
                 if (k < e.nseg && ocb >= e.seg[k].col_begin) si = k;
-            const IGemmSeg sg = si == 0 ? e.seg[0] : (si == 1 ? e.seg[1] : e.seg[2]);   // (constant indices: a dynamic one pins the whole descriptor in scratch)
+            // (field by field, from opaque scalars: "select between loaded kernel-argument fields" otherwise becomes "load from a selected
+            // address" and pins the whole descriptor in scratch for the entire kernel)
+            void* q_out[3] = {e.seg[0].out, e.seg[1].out, e.seg[2].out};
+            int64_t q_ld[3] = {e.seg[0].ld, e.seg[1].ld, e.seg[2].ld};
+            int q_cb[3] = {e.seg[0].col_begin, e.seg[1].col_begin, e.seg[2].col_begin}, q_nc[3] = {e.seg[0].ncols, e.seg[1].ncols, e.seg[2].ncols};
+            int q_fmt[3] = {e.seg[0].fmt, e.seg[1].fmt, e.seg[2].fmt}, q_dt[3] = {e.seg[0].dtype, e.seg[1].dtype, e.seg[2].dtype}, q_L[3] = {e.seg[0].L, e.seg[1].L, e.seg[2].L};
+            const int32_t* q_map[3] = {e.seg[0].img_map, e.seg[1].img_map, e.seg[2].img_map};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(q_out[k]), "+s"(q_ld[k]), "+s"(q_cb[k]), "+s"(q_nc[k]), "+s"(q_fmt[k]), "+s"(q_dt[k]), "+s"(q_L[k]), "+s"(q_map[k]));
+            IGemmSeg sg;
+            sg.out = si == 0 ? q_out[0] : (si == 1 ? q_out[1] : q_out[2]);
+            sg.ld = si == 0 ? q_ld[0] : (si == 1 ? q_ld[1] : q_ld[2]);
+            sg.col_begin = si == 0 ? q_cb[0] : (si == 1 ? q_cb[1] : q_cb[2]);
+            sg.ncols = si == 0 ? q_nc[0] : (si == 1 ? q_nc[1] : q_nc[2]);
+            sg.fmt = si == 0 ? q_fmt[0] : (si == 1 ? q_fmt[1] : q_fmt[2]);
+            sg.dtype = si == 0 ? q_dt[0] : (si == 1 ? q_dt[1] : q_dt[2]);
+            sg.L = si == 0 ? q_L[0] : (si == 1 ? q_L[1] : q_L[2]);
+            sg.img_map = si == 0 ? q_map[0] : (si == 1 ? q_map[1] : q_map[2]);
             const int scol = ocol - sg.col_begin;
             const float bh = e.bias ? e.bias[pcol] : 0.f;
             const float bg = (e.geglu && e.bias) ? e.bias[pcol + 16] : 0.f;
@@ -1224,7 +1282,11 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         attr_done[dev] = true;
     }
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
-    const int order = plan_order(a, BM, BN, ntm, ntn);
+    // Tile walk: the legacy one (every XCD a contiguous range of the M-major list) unless an order is forced.  The grouped
+    // weight-panel walk that pays for the BK = 32 kernels re-fetches every activation panel once per group, and at this kernel's
+    // rate that traffic is the limiter: M131072 N2048 K2048 1.52 ms grouped vs 1.07 ms legacy (profiles/r04_gemm_tile_order_8phase.txt)
+    (void)plan_order(a, BM, BN, ntm, ntn);          // (parses CTRL_IGEMM_ORDER on first use)
+    const int order = g_order_spec.kind == 2 ? tileorder::make_order(g_order_spec.mode, g_order_spec.group) : 0;
     const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
     PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
     prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
@@ -1348,7 +1410,8 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
         if (tiles(128, 128) >= 192) return launch_cfg<128, 128, 32, 2, 2, 3, MODE>(a, s);
         return launch_cfg<64, 64, 32, 2, 2, 3, MODE>(a, s);
     }
-    if (tiles(256, 128) >= 400 && eff(128) > 0.8) return launch_cfg<256, 128, 64, 4, 2, 3, MODE>(a, s);
+    // (a 256x128x64 tile at two workgroups per CU stood here: every instantiation spilled inside its MFMA loop -- 128 registers do
+    // not hold a 64-deep fragment set -- and the shapes it served now run on the 8-phase tiles; removed in round 4)
     if (tiles(128, 128) >= 192 && eff(128) > 0.8) return launch_cfg<128, 128, 64, 2, 4, 4, MODE>(a, s);
     if (tiles(128, 64) >= 192) return launch_cfg<128, 64, 64, 2, 2, 3, MODE>(a, s);
     return launch_cfg<64, 64, 64, 2, 2, 3, MODE>(a, s);

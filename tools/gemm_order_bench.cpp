@@ -294,12 +294,107 @@ static int check() {
     return bad ? 4 : 0;
 }
 
+// The path's heaviest GEMM / convolution shapes with their real epilogue kinds (profiles/r0N_per_kernel_*.json), random
+// operands, median of 9 launches each -- the table the round-4 review's "done" criteria read (M131072 N512 K2048, M32768 N640
+// K5760 taps9, M131072 N4096 K512 geglu, ...).  `CTRL_IGEMM8=0 gemm_order_bench out.txt shapes` times the round-3 kernels.
+static int shapes_mode() {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    // kind: 0 plain fp16 rows, 1 geglu, 2 fp32 stream update (fp32 residual in, fp32 master + fp16 mirror out), 3 fp16 rows with an
+    //       fp32 residual in (operand of the next GEMM), 4 transposed fp16 output (V^T), 5 conv 3x3 (taps 9) fp16 rows + time vector
+    struct S { const char* name; int M, N, K, kind, hw, up; };
+    const S ss[] = {
+        {"ff1 geglu 512->4096 @128^2", 131072, 4096, 512, 1, 0, 0},
+        {"attn out 320->512 stream @128^2", 131072, 512, 320, 2, 0, 0},
+        {"ff2 2048->512 stream @128^2", 131072, 512, 2048, 2, 0, 0},
+        {"q proj 512->320 @128^2", 131072, 320, 512, 0, 0, 0},
+        {"v proj 512->320 transposed @128^2", 131072, 320, 512, 4, 16384, 0},
+        {"q|k proj 512->640 @128^2", 131072, 640, 512, 0, 0, 0},
+        {"conv 320->320 @128^2", 131072, 320, 2880, 5, 128, 1},
+        {"conv 320->320 @64^2 up2 -> 128^2", 131072, 320, 2880, 5, 128, 2},
+        {"conv 640->640 @64^2", 32768, 640, 5760, 5, 64, 1},
+        {"conv 1280->1280 @32^2", 8192, 1280, 11520, 5, 32, 1},
+        {"ff1 geglu 512->4096 @64^2", 32768, 4096, 512, 1, 0, 0},
+        {"ff2 2048->512 stream @64^2", 32768, 512, 2048, 2, 0, 0},
+        {"attn out 640->512 stream @64^2", 32768, 512, 640, 2, 0, 0},
+        {"q|k 512->1280 @64^2", 32768, 1280, 512, 0, 0, 0},
+        {"ControlNet ff1 geglu 640->5120 @32^2", 8192, 5120, 640, 1, 0, 0},
+        {"plain 2048-deep operand out", 131072, 512, 2048, 3, 0, 0},
+    };
+    say("\npath shapes (median of 9, random fp16 operands; TFLOP/s = algorithmic 2 M N K / t)\n");
+    for (const S& sh : ss) {
+        const int on = sh.kind == 1 ? sh.N / 2 : sh.N;
+        const bool conv = sh.kind == 5;
+        const int cin = conv ? sh.K / 9 : sh.K;
+        const int hin = conv ? sh.hw / sh.up : 1;
+        const int nimg = conv ? sh.M / (sh.hw * sh.hw) : 1;
+        const size_t a_elems = conv ? (size_t)nimg * hin * hin * cin : (size_t)sh.M * sh.K;
+        void* A = dev_half(a_elems, 1);
+        void* W = dev_half((size_t)sh.N * sh.K, 2);
+        std::vector<float> hb(sh.N, 0.01f);
+        float* bias = nullptr;
+        CK(hipMalloc((void**)&bias, sh.N * 4));
+        CK(hipMemcpy(bias, hb.data(), sh.N * 4, hipMemcpyHostToDevice));
+        const bool f32out = sh.kind == 2;
+        const size_t out_bytes = (size_t)sh.M * on * (f32out ? 4 : 2) + (sh.kind == 4 ? 4096 : 0);
+        void *out = nullptr, *res = nullptr, *mirror = nullptr;
+        float* rowvec = nullptr;
+        CK(hipMalloc(&out, out_bytes));
+        if (sh.kind == 2 || sh.kind == 3) {
+            CK(hipMalloc(&res, (size_t)sh.M * on * 4));
+            CK(hipMemset(res, 0, (size_t)sh.M * on * 4));
+        }
+        if (sh.kind == 2) CK(hipMalloc(&mirror, (size_t)sh.M * on * 2));
+        if (conv) { CK(hipMalloc((void**)&rowvec, (size_t)nimg * sh.N * 4)); CK(hipMemset(rowvec, 0, (size_t)nimg * sh.N * 4)); }
+        ctrl_igemm_desc d;
+        memset(&d, 0, sizeof d);
+        d.A = A; d.lda = cin; d.mode = conv ? 1 : 0; d.Cin = cin; d.taps = conv ? 9 : 1;
+        d.Hin = d.Win = hin; d.Hout = d.Wout = conv ? sh.hw : 1; d.stride = 1; d.up = conv ? sh.up : 1;
+        d.W = W; d.M = sh.M; d.Nout = sh.N; d.Ktot = sh.K;
+        d.bias = bias; d.rows_per_img = conv ? sh.hw * sh.hw : 1; d.scale = 1.f; d.geglu = sh.kind == 1;
+        if (conv) { d.rowvec = rowvec; d.rowvec_ld = sh.N; d.act = 0; }
+        if (res) { d.res = res; d.ldres = on; d.res_f32 = 1; }
+        if (mirror) { d.out16 = mirror; d.ld16 = on; }
+        d.nseg = 1;
+        d.seg[0].out = out; d.seg[0].col_begin = 0; d.seg[0].ncols = on;
+        if (sh.kind == 4) { d.seg[0].fmt = 1; d.seg[0].ld = sh.hw; d.seg[0].L = sh.hw; d.seg[0].dtype = CTRL_F16; }
+        else { d.seg[0].fmt = 0; d.seg[0].ld = on; d.seg[0].L = 1; d.seg[0].dtype = f32out ? CTRL_F32 : CTRL_F16; }
+        std::vector<float> t;
+        bool failed = false;
+        for (int i = 0; i < 2 && !failed; ++i)
+            if (ctrl_op_igemm(&d, st) != 0) { say("  %-40s launch failed: %s\n", sh.name, ctrl_last_error()); failed = true; }
+        for (int i = 0; i < 9 && !failed; ++i) {
+            CK(hipEventRecord(e0, st));
+            ctrl_op_igemm(&d, st);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            t.push_back(ms);
+        }
+        if (!failed) {
+            std::sort(t.begin(), t.end());
+            say("  %-40s M%6d N%5d K%5d  %.4f ms  %5.0f TFLOP/s\n", sh.name, sh.M, sh.N, sh.K, t[4], 2.0 * sh.M * sh.N * sh.K / t[4] * 1e-9);
+        }
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(out));
+        if (res) CK(hipFree(res));
+        if (mirror) CK(hipFree(mirror));
+        if (rowvec) CK(hipFree(rowvec));
+    }
+    say("done\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1) g_out = fopen(argv[1], "w");
     say("abi %d\n", ctrl_abi_version());
     if (argc > 2 && !strcmp(argv[2], "ksweep")) return ksweep();
     if (argc > 2 && !strcmp(argv[2], "stores")) return stores();
     if (argc > 2 && !strcmp(argv[2], "check")) return check();
+    if (argc > 2 && !strcmp(argv[2], "shapes")) return shapes_mode();
     std::vector<Shape> shapes = {
         {"geglu 512->4096 @128^2 x8", 131072, 4096, 512, true, false, {"legacy", "auto", "m,8", "m,16", "m,4", "n,0"}},
         {"geglu 512->4096 @64^2 x8", 32768, 4096, 512, true, false, {"legacy", "auto", "m,8", "m,16", "n,0"}},
