@@ -40,12 +40,55 @@ def _compile(src):
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
     cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+    audit = src == "igemm.hip" and os.environ.get("CTRL_BUILD_AUDIT", "1") != "0"      # (=0: faster edit-compile cycles)
+    if audit:
+        # the register / spill audit of the implicit-GEMM kernels (tools/igemm_resources.py, tests/test_kernel_resources.py) rides on
+        # this compilation: its remarks and the device ISA it leaves behind, instead of a second three-minute compile
+        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if audit:
+        _write_audit(r.stderr)
     with open(stamp, "w") as fh:
         fh.write(dig)
     return obj, True
+
+
+def audit_digest():
+    """what the cached audit is valid for: igemm.hip, the headers, the flags (tests/test_kernel_resources.py recomputes it)"""
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".h") or f == "igemm.hip":
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    with open(os.path.join(HERE, "..", "include", "ctrl_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _write_audit(remarks):
+    import glob
+    import importlib.util
+    import json
+    try:
+        spec = importlib.util.spec_from_file_location("igemm_resources", os.path.join(HERE, "..", "tools", "igemm_resources.py"))
+        tool = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(tool)
+        asm = glob.glob(os.path.join(OBJ, "igemm*gfx950*.s"))
+        if asm:
+            res = tool.parse(remarks, open(asm[0]).read())
+            with open(os.path.join(OBJ, "igemm_resources.json"), "w") as fh:
+                json.dump({"digest": audit_digest(), "res": res}, fh)
+    except Exception as e:       # the audit is a by-product: never fail the build over it
+        print("igemm audit not written: %s" % e)
+    for f in glob.glob(os.path.join(OBJ, "igemm*.bc")) + glob.glob(os.path.join(OBJ, "igemm*.hipi")) + glob.glob(os.path.join(OBJ, "igemm*.out*")) + \
+            glob.glob(os.path.join(OBJ, "igemm*.hipfb")) + glob.glob(os.path.join(OBJ, "igemm*-host-*")) + glob.glob(os.path.join(OBJ, "igemm*gfx950*.o")):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
 
 
 def build(verbose=True):

@@ -225,6 +225,58 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                             if (d < MI && pv(t) && row < e.M) res_fetch8(rs, row, oc(t), rf[d][t][0], rf[d][t][1]);
                         }
                 }
+                // fp16 rows with nothing to add after the transposition (projections, GEGLU, convolutions without a residual): the slab is
+                // staged as PACKED fp16 -- scale and rounding happen in the fragment layout, the same fp32 operations in the same order --
+                // so a piece is one 16-byte LDS read and one store: half the LDS traffic and a third of the per-piece instructions
+                if (!has_res && !e.blend_mix && !e.out16 && e.nseg == 1 && e.seg[0].dtype == DT_F16) {
+                    constexpr int RS = OWMAX * 2 + 16;                 // bytes per staged row
+                    char* const stg16 = (char*)stg;
+                    half_t* const outp = (half_t*)e.seg[0].out;
+                    const unsigned old_ = (unsigned)e.seg[0].ld;
+                    const int ocb = e.seg[0].col_begin;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int row_w = wrow0 + mi * 16 + erow;
+                        if (rv_uniform) {
+                            if (img_cur != cv_img) { cv_img = img_cur; load_cv(img_cur); }
+                            img_rem += 16;
+                            if (img_rem >= e.rows_per_img) { img_rem -= e.rows_per_img; ++img_cur; }
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            if (gg && (ni & 1)) continue;
+                            const int pcb = n0 + wn * WN + ni * 16;
+                            if (pcb >= e.Nout) continue;
+                            f4 x = acc[mi][ni] + cv[ni];
+                            if (!rv_uniform && e.rowvec && row_w < e.M) x += *(const f4*)(e.rowvec + (size_t)(row_w / e.rows_per_img) * e.rowvec_ld + pcb + ecol);
+                            if (gg) {
+                                const f4 g = acc[mi][ni + (NI > 1 ? 1 : 0)] + cv[ni + 1 < NI ? ni + 1 : ni];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) x[i] *= gelu_erf_f(g[i]);
+                            }
+                            if (e.act == 1) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
+                            }
+                            const int lcol = (gg ? (ni >> 1) * 16 : ni * 16) + ecol;
+                            const float sc = (e.scale2_from > 0 && wcol0 + lcol >= e.scale2_from) ? e.scale2 : e.scale;
+                            const h4 pk = {(half_t)(x[0] * sc), (half_t)(x[1] * sc), (half_t)(x[2] * sc), (half_t)(x[3] * sc)};
+                            *(h4*)(stg16 + erow * RS + lcol * 2) = pk;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) {
+                            const int prt = pr(t);
+                            const int row = wrow0 + mi * 16 + prt;
+                            if (!pv(t) || row >= e.M) continue;
+                            const int ocol = oc(t);
+                            const h8 v = *(const h8*)(stg16 + prt * RS + (ocol - wcol0) * 2);
+                            *(h8*)(outp + ((unsigned)row * old_ + (unsigned)(ocol - ocb))) = v;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    return;
+                }
                 const float al = e.blend_mix ? __builtin_amdgcn_rcpf(1.0f + __expf(-e.blend_mix[0])) : 0.f;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
@@ -347,7 +399,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
     } else {
         // C/D fragment map of v_mfma_f32_16x16x32: row = (lane>>4)*4 + i, col = lane&15
         const int erow = (lane >> 4) * 4, ecol = lane & 15;
-#pragma unroll
+#pragma clang loop unroll(full)      // (a hint alone left this loop rolled once the body grew: acc[][] indexed by a register = the accumulators in scratch)
         for (int ni = 0; ni < NI; ++ni) {
             if (e.geglu && (ni & 1)) continue;           // odd fragments are the gates of the even ones
             const int pcb = n0 + wn * WN + ni * 16;      // packed column block start
