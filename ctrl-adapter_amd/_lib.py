@@ -83,11 +83,11 @@ class ClipComm(C.Structure):
 
 
 # every symbol include/ctrl_hip.h declares (tests check the library exports all of them)
-ABI_VERSION = 4       # CTRL_ABI_VERSION of include/ctrl_hip.h
+ABI_VERSION = 5       # CTRL_ABI_VERSION of include/ctrl_hip.h
 EXPORTS = [
     "ctrl_abi_version", "ctrl_last_error", "ctrl_prof_begin", "ctrl_prof_end", "ctrl_prof_count", "ctrl_prof_get",
     "ctrl_prof_launch_count", "ctrl_prof_launch_get",
-    "ctrl_op_igemm", "ctrl_igemm_set_order", "ctrl_igemm_tile_of", "ctrl_op_flash_attn", "ctrl_attn_set_variant", "ctrl_op_temporal_attn", "ctrl_op_gn_stats_floats", "ctrl_op_gn_stats", "ctrl_op_gn_apply", "ctrl_op_gn_apply_split", "ctrl_op_pack_conv_w_dup",
+    "ctrl_op_igemm", "ctrl_igemm_set_order", "ctrl_igemm_set_wide", "ctrl_igemm_tile_of", "ctrl_op_flash_attn", "ctrl_attn_set_variant", "ctrl_op_temporal_attn", "ctrl_op_gn_stats_floats", "ctrl_op_gn_stats", "ctrl_op_gn_apply", "ctrl_op_gn_apply_split", "ctrl_op_pack_conv_w_dup",
     "ctrl_op_layernorm", "ctrl_op_nchw_to_nhwc", "ctrl_op_nhwc_to_nchw", "ctrl_avgpool_nchw",
     "ctrl_op_timestep_sincos", "ctrl_op_linear_small", "ctrl_op_blend", "ctrl_op_add_rowvec",
     "ctrl_op_conv3x3_direct", "ctrl_op_pack_conv_w", "ctrl_op_pack_conv_w_direct", "ctrl_op_pack_linear_w",

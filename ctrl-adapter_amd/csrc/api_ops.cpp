@@ -11,6 +11,10 @@ int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream) {
     return op_igemm(*d, S(stream));
 }
 int ctrl_igemm_set_order(const char* spec) { return igemm_set_order(spec); }
+int ctrl_igemm_set_wide(int mode) {
+    CTRL_CHECK(mode >= -1 && mode <= 2, "igemm_set_wide: mode must be -1 (default), 0 (never), 1 (auto) or 2 (every eligible problem)");
+    return igemm_set_wide(mode);
+}
 int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n) {
     CTRL_CHECK(tile_m && tile_n && ntm > 0 && ntn > 0 && bid >= 0 && bid < ntm * ntn, "igemm_tile_of: bad arguments");
     igemm_tile_of(bid, ntm, ntn, mode, group, tile_m, tile_n);
@@ -21,7 +25,7 @@ int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream) {
     return op_flash_attn(*d, S(stream));
 }
 int ctrl_attn_set_variant(int v) {
-    CTRL_CHECK(v >= -1 && v <= 32, "attn_set_variant: variant out of range (-1 = default, 0 = round-2 kernel, 1.. = attention_d64.hip)");
+    CTRL_CHECK(v >= -1 && v <= 14, "attn_set_variant: variant out of range (-1 = default, 0 = round-2 kernel, 1..14 = attention_d64.hip)");
     return attn_set_variant(v);
 }
 int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream) {

@@ -19,6 +19,7 @@
 //     softmax / MFMA chains give the scheduler work to overlap inside one wave.
 // Requirements (checked by the dispatcher): D == 64, K pre-scaled, Lk % 64 == 0, kvB == B.
 #include "ops.h"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -653,7 +654,14 @@ bool flash_attn_d64_applies(const AttnArgs& a) {
 // how many queries a wave owns).  0 = the round-2 kernel in attention.hip; default = CTRL_ATTN_VARIANT or the best measured.
 int attn_set_variant(int v) { g_variant = v; return 0; }
 int attn_variant() {
-    if (g_variant < 0) { const char* e = getenv("CTRL_ATTN_VARIANT"); g_variant = e ? atoi(e) : 2; }
+    if (g_variant < 0) {
+        const char* e = getenv("CTRL_ATTN_VARIANT");
+        g_variant = e ? atoi(e) : 2;
+        if (g_variant < 0 || g_variant > 14) {        // (a bad value used to surface as "unknown variant" inside every long-sequence forward)
+            fprintf(stderr, "ctrl: CTRL_ATTN_VARIANT=%s is not a variant (0..14), using the default\n", e);
+            g_variant = 2;
+        }
+    }
     return g_variant;
 }
 

@@ -1302,10 +1302,10 @@ bool can_swap(const IGemmArgs& a) {
 // the 8-phase wide-tile kernel (igemm8_kernel) can take this problem: swapped epilogue, whole 64-deep k-tiles per tap, 32-bit offsets
 // CTRL_IGEMM8: "0" never, "force" whenever the problem is eligible (any grid size: the parity tests run their small shapes
 // through it this way), default = where the grid fills the chip
+int g_igemm8_mode = -1;
 int igemm8_mode() {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("CTRL_IGEMM8"); mode = !e ? 1 : (e[0] == '0' ? 0 : (!strcmp(e, "force") ? 2 : 1)); }
-    return mode;
+    if (g_igemm8_mode < 0) { const char* e = getenv("CTRL_IGEMM8"); g_igemm8_mode = !e ? 1 : (e[0] == '0' ? 0 : (!strcmp(e, "force") ? 2 : 1)); }
+    return g_igemm8_mode;
 }
 bool can_use8(const IGemmArgs& a) {
     if (!igemm8_mode() || !can_swap(a)) return false;
@@ -1369,6 +1369,12 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
 }  // namespace
 
 // number of K splits op_igemm will use for this problem (1 = none); callers size splitk_ws = factor*M*Nout*4 bytes
+
+int igemm_set_wide(int mode) {
+    if (mode < -1 || mode > 2) return 1;
+    g_igemm8_mode = mode;            // -1: back to CTRL_IGEMM8 / the default
+    return 0;
+}
 
 int igemm_set_order(const char* spec) {
     const OrderSpec sp = parse_order(spec);

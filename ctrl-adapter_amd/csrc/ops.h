@@ -19,6 +19,9 @@ int op_igemm(const IGemmArgs& a, hipStream_t s);
 int igemm_splitk_factor(const IGemmArgs& a);
 // tile walk order of the implicit GEMM (tile_order.h): "legacy" | "auto" | "m,G" | "n,G"; 0 = accepted
 int igemm_set_order(const char* spec);
+// which problems take the 8-phase wide-tile kernel (igemm8_kernel): 0 none, 1 where the grid fills the chip (default), 2 every
+// eligible problem (the parity tests run their small shapes through it this way), -1 back to CTRL_IGEMM8 / the default; 0 = accepted
+int igemm_set_wide(int mode);
 void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
 // convenience: plain linear out[M][N] (fp16 row-major) = A[M][K] * W[N][K]^T + bias
 int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, half_t* out, long ldo,

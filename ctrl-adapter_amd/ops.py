@@ -101,6 +101,12 @@ def set_igemm_order(spec):
         raise ValueError("unknown tile walk order %r" % (spec,))
 
 
+def set_igemm_wide(mode):
+    """which GEMM / convolution problems run on the 8-phase wide-tile kernel: 0 none, 1 where the grid fills the chip (default), 2 every
+    eligible problem (tests), -1 back to the default (csrc/igemm.hip)"""
+    L.check(L.lib().ctrl_igemm_set_wide(int(mode)))
+
+
 def set_attn_variant(v):
     """instruction-selection variant of the head_dim-64 long-sequence attention kernel (0 = the round-2 kernel); every
     variant computes the same function (csrc/attention_d64.hip)"""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTRL_ABI_VERSION 4
+#define CTRL_ABI_VERSION 5
 
 /* element types of boundary tensors */
 enum { CTRL_F32 = 0, CTRL_F16 = 1, CTRL_BF16 = 2 };
@@ -108,6 +108,12 @@ int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
    ctrl_igemm_tile_of: the (tile_m, tile_n) workgroup `bid` of an ntm x ntn grid computes under (mode 0|1|2, group) --
    a diagnostic the host tests use to prove every order is a bijection. */
 int ctrl_igemm_set_order(const char* spec);
+/* Which problems run on the 8-phase wide-tile kernel (csrc/igemm.hip: igemm8_kernel, 256 x 256|320 x 64 tiles): 0 none (the round-3
+   ring kernels), 1 wherever the grid fills the chip (default; also CTRL_IGEMM8=0|1|force), 2 every eligible problem whatever its
+   size -- what the parity tests use to drive their small shapes through it.  -1 restores the default.  Performance only: both
+   kernel families share one epilogue and the same accumulation order inside a k-tile; results may differ in the last fp32 bit
+   between families (different k-tile depth).  0 = accepted. */
+int ctrl_igemm_set_wide(int mode);
 int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
 
 typedef struct ctrl_attn_desc {

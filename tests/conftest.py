@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--require-real-diffusers", action="store_true", default=False,
+                     help="fail the golden-vector tests unless the goldens were made over a real `diffusers` (tests/golden/README.md)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the slowest tests in every summary: the GPU suite is dominated by the fp32 CPU oracle at full size, and the driver

@@ -16,7 +16,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
-sys.path[:0] = [os.path.join(ROOT, "oracle", "_shim"), REF, ROOT, os.path.join(ROOT, "tests", "golden")]
+sys.path[:0] = [REF, ROOT, os.path.join(ROOT, "tests", "golden")]
+import blocks_source  # noqa: E402
+BLOCKS = blocks_source.select(require_real="--require-real-diffusers" in sys.argv)      # a real diffusers when there is one, else the shim
+sys.argv = [a for a in sys.argv if a != "--require-real-diffusers"]
 torch.Tensor.cuda = lambda self, *a, **k: self
 
 from oracle.init import seeded_init, seeded_tensor  # noqa: E402
@@ -163,7 +166,7 @@ def main():
         print("%-120s rel_inf %.2e%s" % (desc, err, "" if err <= TOL else "   MISMATCH"), flush=True)
         if not err <= TOL:
             raise SystemExit(1)
-    print("LIVE CHECK OK: %d cases, worst %.2e" % (n, worst))
+    print("LIVE CHECK OK: %d cases, worst %.2e  (blocks: %s)" % (n, worst, BLOCKS))
 
 
 if __name__ == "__main__":

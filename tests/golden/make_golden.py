@@ -1,8 +1,11 @@
 """Generates tests/golden/*.pt by running the REFERENCE'S OWN hot-path files from /root/reference
 (controlnet/controlnet.py, model/ctrl_adapter.py, model/adapter_spatial_temporal.py, model/resnet_block_2d.py,
-model/ctrl_router.py) unmodified, on top of oracle/_shim (a minimal `diffusers` whose blocks are oracle/blocks.py).
+model/ctrl_router.py) unmodified, on top of a REAL `diffusers` when one is importable, else on oracle/_shim (a minimal
+`diffusers` whose blocks are oracle/blocks.py).  Every file records which (`provenance`: tests/golden/blocks_source.py,
+tests/golden/README.md has the recipe that closes the pin on a box with `pip install diffusers==0.27.2`).
 
-Run in the build container only (the GPU box has no /root/reference):   python tests/golden/make_golden.py
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py [--require-real-diffusers] [--out DIR] [per_clip_context]
 Stored per output tensor: shape, float64 sum and abs-sum, and <=4096 evenly strided fp32 samples; for a selection of
 outputs of every case (all 13 of the plain ControlNet run, the largest / deepest adapter slots, every mid block) the
 WHOLE fp32 tensor as well, so those are pinned element by element.  Inputs and weights are regenerated from seeds (tests/golden/cases.py,
@@ -15,7 +18,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
-sys.path[:0] = [os.path.join(ROOT, "oracle", "_shim"), REF, ROOT, os.path.join(ROOT, "tests", "golden")]
+sys.path[:0] = [REF, ROOT, os.path.join(ROOT, "tests", "golden")]
+import blocks_source  # noqa: E402
+ARGS = [a for a in sys.argv[1:]]
+BLOCKS = blocks_source.select(require_real="--require-real-diffusers" in ARGS)      # prepares sys.path for `import diffusers`
 
 torch.Tensor.cuda = lambda self, *a, **k: self        # model/ctrl_router.py:21,38 hard-code .cuda()
 
@@ -47,15 +53,21 @@ def per_clip_context(out_dir):
         assert mid is None
         gq[tag] = {"keys": sorted(ad.state_dict().keys()), "out": [digest(o, full=(i == 0)) for i, o in enumerate(out)]}
         del ad
+    gq["__provenance__"] = blocks_source.provenance(BLOCKS)
     torch.save(gq, os.path.join(out_dir, "adapter_per_clip_context.pt"))
-    print("per-clip context: %s" % ", ".join(gq))
+    print("per-clip context: %s" % ", ".join(k for k in gq if not k.startswith("__")))
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    if "--out" in ARGS:
+        out_dir = os.path.abspath(ARGS[ARGS.index("--out") + 1])
+        os.makedirs(out_dir, exist_ok=True)
+    print("blocks: %s" % BLOCKS)
+    prov = blocks_source.provenance(BLOCKS)
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
-    if len(sys.argv) > 1 and sys.argv[1] == "per_clip_context":      # only this file (the others are unchanged)
+    if "per_clip_context" in ARGS:      # only this file (the others are unchanged)
         return per_clip_context(out_dir)
 
     from controlnet.controlnet import ControlNetModel
@@ -66,7 +78,7 @@ def main():
     net = seeded_init(ControlNetModel(**cases.CONTROLNET_KW).eval(), seed=11)
     nparams = sum(p.numel() for p in net.parameters())
     keys = sorted(net.state_dict().keys())
-    g1 = {"n_params": nparams, "keys": keys, "runs": {}}
+    g1 = {"n_params": nparams, "keys": keys, "runs": {}, "provenance": prov}
     inp = cases.controlnet_inputs()
     for tag, kw in {"plain": {}, "scale0.5": dict(conditioning_scale=0.5), "skip_conv_in": dict(skip_conv_in=True),
                     "skip_time_emb": dict(skip_time_emb=True), "guess": dict(guess_mode=True)}.items():
@@ -87,7 +99,7 @@ def main():
     ehs = cases.seeded_tensor((2, 77, 2048), 290)
     out, mid = ad(downs, sparsity_masking=None, num_frames=1, timestep=torch.tensor(749.0), encoder_hidden_states=ehs)
     assert mid is None
-    torch.save({"n_params": sum(p.numel() for p in ad.parameters()), "keys": sorted(ad.state_dict().keys()),
+    torch.save({"n_params": sum(p.numel() for p in ad.parameters()), "keys": sorted(ad.state_dict().keys()), "provenance": prov,
                 "out": [digest(o, full=(i in (0, 4, 8))) for i, o in enumerate(out)]}, os.path.join(out_dir, "adapter_sdxl.pt"))
     print("adapter sdxl: %.1f M params" % (sum(p.numel() for p in ad.parameters()) / 1e6))
     del ad
@@ -98,7 +110,7 @@ def main():
     ehs = cases.seeded_tensor((1, 1, 1024), 390)
     out, mid = ad(downs, mid_block_res_sample=midin, sparsity_masking=None, num_frames=4,
                   timestep=torch.tensor(961.0), encoder_hidden_states=ehs)
-    torch.save({"n_params": sum(p.numel() for p in ad.parameters()), "keys": sorted(ad.state_dict().keys()),
+    torch.save({"n_params": sum(p.numel() for p in ad.parameters()), "keys": sorted(ad.state_dict().keys()), "provenance": prov,
                 "out": [digest(o, full=(i in (0, 5, 8, 11))) for i, o in enumerate(out)] + [digest(mid, full=True)]},
                os.path.join(out_dir, "adapter_video.pt"))
     print("adapter video: %.1f M params" % (sum(p.numel() for p in ad.parameters()) / 1e6))
@@ -114,12 +126,13 @@ def main():
         gv[tag] = {"keys": sorted(ad.state_dict().keys()), "n_params": sum(p.numel() for p in ad.parameters()),
                    "out": [digest(o, full=(o.abs().max() > 0 and o.numel() <= 50000)) for o in out] + ([digest(mid, full=True)] if mid is not None else [])}
         del ad
+    gv["__provenance__"] = prov
     torch.save(gv, os.path.join(out_dir, "adapter_variants.pt"))
-    print("adapter variants: %s" % ", ".join(gv))
+    print("adapter variants: %s" % ", ".join(k for k in gv if not k.startswith("__")))
 
     # ---- G4: router ----
     r = seeded_init(ControlNetRouter(num_experts=3, router_type="simple_weights", num_routers=12).eval(), seed=44)
-    g4 = {"keys": sorted(r.state_dict().keys()), "runs": {}}
+    g4 = {"keys": sorted(r.state_dict().keys()), "runs": {}, "provenance": prov}
     for tag, mask in {"all": [1, 1, 1], "m101": [1, 0, 1], "none": None}.items():
         dw, mw = r(sparse_mask=mask)
         g4["runs"][tag] = dict(down=dw.clone(), mid=mw.clone())

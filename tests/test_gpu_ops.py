@@ -507,3 +507,88 @@ def test_tile_walk_orders_are_bit_identical(ops, gpu):
             ops.set_igemm_order("sideways")
     finally:
         ops.set_igemm_order("auto")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The 8-phase wide-tile kernel (csrc/igemm.hip: igemm8_kernel).  The dispatcher only picks it where the grid fills the chip,
+# i.e. for none of the small shapes above: ctrl_igemm_set_wide(2) routes every eligible problem through it.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def wide(ops):
+    ops.set_igemm_wide(2)
+    yield
+    ops.set_igemm_wide(-1)
+
+
+@pytest.mark.parametrize("name", ["test_linear", "test_conv3x3", "test_conv3x3_splitk", "test_split_operand_conv", "test_linear_geglu",
+                                  "test_linear_f32_stream", "test_conv1x1_nchw_out_scaled", "test_conv3x3_with_half_resolution_residual",
+                                  "test_single_transposed_output_epilogue", "test_qkv_segments", "test_conv1x1_upsampled_shortcut"])
+def test_wide_tile_kernel_runs_the_op_tests(ops, gpu, wide, name):
+    """every parametrisation of the GEMM / convolution op tests above, through igemm8_kernel (rows, conv2d with stride / folded
+    up-sampling / half-resolution residual, split-K, both split-operand walks, GEGLU, fp32 streams, transposed outputs, segments)"""
+    fn = globals()[name]
+    marks = [m for m in getattr(fn, "pytestmark", []) if m.name == "parametrize"]
+    if not marks:
+        fn(ops, gpu)
+        return
+    assert len(marks) == 1
+    names = [n.strip() for n in marks[0].args[0].split(",")]
+    for vals in marks[0].args[1]:
+        vals = vals if isinstance(vals, (tuple, list)) else (vals,)
+        fn(ops, gpu, **dict(zip(names, vals)))
+
+
+@pytest.mark.parametrize("Cc,Fr,HW,b", [(320, 5, 48, 2), (640, 16, 16, 2), (256, 3, 100, 1)])
+def test_wide_tile_temporal_conv(ops, gpu, wide, Cc, Fr, HW, b):
+    """Conv3d (3,1,1) over frames at the adapters' channel counts (the op test above has C = 64, below the wide tile): NI = 5 (320, 640)
+    and NI = 4 (256) tiles, clips whose first / last frames have no neighbour, ragged M"""
+    x = rnd(b, Cc, Fr, HW, 1, seed=1)
+    w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=0.03)
+    bias = rnd(Cc, seed=3)
+    ref = F.conv3d(x, w, bias, padding=(1, 0, 0))
+    xr = x[..., 0].permute(0, 2, 3, 1).contiguous().reshape(b * Fr * HW, Cc)
+    wp = ops.pack_conv_w(w.reshape(Cc, Cc, 3, 1).to(gpu))
+    out = torch.empty(b * Fr * HW, Cc, dtype=torch.float16, device=gpu)
+    ops.igemm(xr.half().to(gpu), Cc, wp, b * Fr * HW, Cc, Cc, taps=3, mode=ops.IG_TEMPORAL, bias=bias.to(gpu),
+              segs=[(out, Cc, 0, Cc, ops.SEG_ROW, 1)], F=Fr, HW=HW)
+    refr = ref[..., 0].permute(0, 2, 3, 1).reshape(b * Fr * HW, Cc)
+    report("wide-tile temporal conv3 C%d F%d" % (Cc, Fr), rel_inf(out, refr))
+
+
+def test_wide_tile_frame_sharded_conv3d_matches_unsharded(ops, gpu, wide):
+    """the halo-padded operand of a frame-sharded clip (ctrl_igemm_desc.t_pad) through the wide tile: bit-identical to the
+    unsharded convolution of the same kernel"""
+    Bc, Fr, HW, W, Cc = 2, 16, 24, 4, 320
+    Fl = Fr // W
+    x = rnd(Bc * Fr * HW, Cc, seed=6).half().to(gpu)
+    w = rnd(Cc, Cc, 3, 1, 1, seed=2, scale=0.03)
+    bias = rnd(Cc, seed=3).to(gpu)
+    wp = ops.pack_conv_w(w.reshape(Cc, Cc, 3, 1).to(gpu))
+    ref = torch.empty(Bc * Fr * HW, Cc, dtype=torch.float16, device=gpu)
+    ops.igemm(x, Cc, wp, Bc * Fr * HW, Cc, Cc, taps=3, mode=ops.IG_TEMPORAL, bias=bias, segs=[(ref, Cc, 0, Cc, ops.SEG_ROW, 1)], F=Fr, HW=HW)
+    ref = ref.reshape(Bc, Fr, HW, Cc)
+    x5 = x.reshape(Bc, Fr, HW, Cc)
+    for r in range(W):
+        pad = torch.zeros(Bc, Fl + 2, HW, Cc, dtype=torch.float16, device=gpu)
+        lo, hi = r * Fl - 1, (r + 1) * Fl + 1
+        pad[:, (1 if lo < 0 else 0):(Fl + 1 if hi > Fr else Fl + 2)] = x5[:, max(lo, 0):min(hi, Fr)]
+        out = torch.empty(Bc * Fl * HW, Cc, dtype=torch.float16, device=gpu)
+        ops.igemm(pad, Cc, wp, Bc * Fl * HW, Cc, Cc, taps=3, mode=ops.IG_TEMPORAL, bias=bias, segs=[(out, Cc, 0, Cc, ops.SEG_ROW, 1)],
+                  F=Fl, HW=HW, t_pad=True)
+        assert torch.equal(out.reshape(Bc, Fl, HW, Cc), ref[:, r * Fl:(r + 1) * Fl]), "rank %d" % r
+
+
+def test_wide_tile_is_bit_reproducible_and_close_to_the_ring_kernels(ops, gpu):
+    """same problem through both kernel families: each bit-identical run to run; between them the fp32 summation order differs
+    (64- vs 32-deep k-tiles), so the fp16 outputs agree to one rounding"""
+    M, N, K = 2048, 640, 1280
+    x = rnd(M, K, seed=3).half().to(gpu)
+    w = rnd(N, K, seed=4, scale=0.03)
+    wp = ops.pack_linear_w(w.to(gpu))
+    outs = []
+    for mode in (0, 2, 2):
+        ops.set_igemm_wide(mode)
+        outs.append(ops.linear(x, wp))
+    ops.set_igemm_wide(-1)
+    assert torch.equal(outs[1], outs[2])
+    report("wide tile vs ring kernel", rel_inf(outs[1], outs[0].float().cpu()), 1e-3)

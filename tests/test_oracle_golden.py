@@ -1,5 +1,7 @@
 """The standalone oracle restatements (oracle/*.py) against the golden vectors produced by the reference's OWN
-files run over the diffusers shim (tests/golden/make_golden.py).  CPU only."""
+files (tests/golden/make_golden.py) -- over a real `diffusers` or over the shim oracle/_shim: every golden file says which
+(`provenance`), test_golden_provenance prints it and `pytest --require-real-diffusers` fails on the shim
+(tests/golden/README.md).  CPU only."""
 import os
 
 import pytest
@@ -13,6 +15,24 @@ from oracle.adapter import ControlNetAdapterOracle
 from oracle.router import RouterOracle, merge_inference, merge_training
 
 TOL = 2e-5   # fp32 vs fp32, different op grouping only
+
+GOLDEN_FILES = ("controlnet_sd15.pt", "adapter_sdxl.pt", "adapter_video.pt", "adapter_variants.pt", "adapter_per_clip_context.pt", "router.pt")
+
+
+def test_golden_provenance(request):
+    """every golden file records what made it: the reference's files over `diffusers==<version>` or over the shim whose blocks are
+    oracle/blocks.py (then the diffusers arithmetic is pinned by restatement only: "parity partially pinned")"""
+    kinds = set()
+    for f in GOLDEN_FILES:
+        g = load_golden(f)
+        p = g.get("provenance") or g.get("__provenance__")
+        assert p and p.get("blocks") and p.get("generator") == "tests/golden/make_golden.py", "%s carries no provenance" % f
+        assert p["blocks"].startswith("diffusers==") or p["blocks"].startswith("oracle-shim"), p
+        print("GOLDEN %-32s blocks: %s (torch %s)" % (f, p["blocks"], p.get("torch")))
+        kinds.add(p["blocks"])
+    assert len(kinds) == 1, "golden files of mixed provenance: %s" % sorted(kinds)
+    if request.config.getoption("--require-real-diffusers"):
+        assert next(iter(kinds)).startswith("diffusers=="), "goldens were made over the shim, not a real diffusers: %s" % sorted(kinds)
 
 
 @pytest.fixture(scope="module")
