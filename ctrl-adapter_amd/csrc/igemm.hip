@@ -826,7 +826,7 @@ struct KPos { int tap, ac, wk, hl; };
     __builtin_amdgcn_sched_barrier(0);
 
 template <int NI, int MODE>
-__global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmArgs a, int ntm, int ntn, int splitk, int order) {
+__global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmArgs a, int ntm, int ntn, int splitk, int order, float* red_ws, int* red_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     typedef g8::Lds<NI> L;
     constexpr int BM = 256, BN = 64 * NI, BK = 64, WN = 16 * NI, NL = L::NL;
@@ -1108,7 +1108,57 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmArgs a, int ntm, in
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
 
-    igemm_epilogue<BM, BN, 2, 4, true, 1>(a, acc, m0, n0, wm, wn, lane, wave, split, smem_raw);
+    int slab = split;
+    if (red_cnt != nullptr) {
+        // In-launch split-K reduction (2..4 splits; cdna_hip_programming.md "in-launch split-K reduction", MI355X_MICROARCH.md
+        // "Workgroup dispatch ... inter-workgroup visibility"): every split writes its accumulators to its slab of the tile in
+        // FRAGMENT layout (16 bytes per lane, 8 KiB contiguous per instruction), publishes them (write-through stores, drained) and takes a
+        // ticket; the workgroup that draws the last ticket acquires once, adds the slabs in split order -- a fixed order whoever arrives
+        // last, so the result is bit-reproducible -- and runs the full epilogue.  No workgroup waits for another: the others just exit.
+        // It replaces the fp32 row slabs + splitk_finish_kernel launch of the higher split factors (round 3: 36 launches, 1.1 ms per step).
+        const int tile = first_bid;
+        constexpr int NF = 8 * NI;
+        f4* const tile_ws = (f4*)red_ws + (size_t)tile * splitk * NF * 512;
+        // The slab leaves by WRITE-THROUGH stores (sc1) and is published by draining them: a release fence writes back every
+        // dirty line of the XCD's L2 -- with 320 KB freshly written by each of the XCD's 32 workgroups that cost 40-66 us per launch
+        // (MI355X_MICROARCH.md price list, "publish-large"), more than the finish kernel it replaces.
+        {
+            const __amdgpu_buffer_rsrc_t ws_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tile_ws + (size_t)split * NF * 512), 0, NF * 512 * 16, 0x00020000);
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    u4 v;
+                    __builtin_memcpy(&v, &acc[mi][ni], 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ws_rs, ((mi * NI + ni) * 512 + tid) * 16, 0, /*sc1*/ 16);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // (also: every wave is done with the LDS ring)
+        int* const flag = (int*)smem_raw;
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(&red_cnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == splitk - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *flag = ticket;
+        }
+        __syncthreads();
+        if (*flag != splitk - 1) return;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < splitk; ++sp) {
+            const f4* src = tile_ws + (size_t)sp * NF * 512 + tid;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += src[(mi * NI + ni) * 512];
+        }
+        slab = 0;
+        __syncthreads();                                       // the flag word is part of the epilogue's staging area
+    }
+    igemm_epilogue<BM, BN, 2, 4, true, 1>(a, acc, m0, n0, wm, wn, lane, wave, slab, smem_raw);
 }
 
 // split-K tail: out = epilogue( sum_s slab[s] ), 8 consecutive columns per thread (row-major outputs only)
@@ -1345,6 +1395,20 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
     const auto sym = [&]() { prof_symbol("igemm8_kernel<%d, %d>", NI, MODE); };
     if (splitk > 1) {
+        // 2..4 splits: reduced inside the launch by the last-arriving workgroup of every tile (see the kernel); the workspace then
+        // holds tile-shaped fragment slabs [tile][split][fragment][thread] + one ticket word per tile (zeroed by a memset node)
+        const size_t slabs = (size_t)ntm * ntn * splitk * BM * BN * sizeof(float);
+        const size_t need = (slabs + 255) / 256 * 256 + (size_t)ntm * ntn * sizeof(int);
+        static int inlaunch = -1;
+        if (inlaunch < 0) { const char* e = getenv("CTRL_SPLITK_INLAUNCH"); inlaunch = (e && e[0] == '0') ? 0 : 1; }
+        if (inlaunch && splitk <= 4 && (size_t)a.splitk_ws_bytes >= need) {
+            int* cnt = (int*)((char*)a.splitk_ws + (slabs + 255) / 256 * 256);
+            HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)ntm * ntn * sizeof(int), s));
+            prof_detail("M%d N%d K%d taps%d%s splitk%d in-launch", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
+            sym();
+            LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn * splitk), dim3(512), smem, s, a, ntm, ntn, splitk, order, (float*)a.splitk_ws, cnt);
+            return 0;
+        }
         IGemmArgs p = a;
         p.bias = nullptr; p.rowvec = nullptr; p.res = nullptr; p.res_f32 = 0; p.act = 0; p.scale = 1.f; p.out16 = nullptr;
         p.blend_mix = nullptr; p.blend_x = nullptr;
@@ -1352,7 +1416,7 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
         prof_detail("M%d N%d K%d taps%d%s splitk%d", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
         sym();
-        LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn * splitk), dim3(512), smem, s, p, ntm, ntn, splitk, order);
+        LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn * splitk), dim3(512), smem, s, p, ntm, ntn, splitk, order, (float*)nullptr, (int*)nullptr);
         const size_t total = (size_t)a.M * (a.Nout / 8);
         size_t blocks = (total + 255) / 256;
         if (blocks > 4096) blocks = 4096;
@@ -1362,7 +1426,7 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         return 0;
     }
     sym();
-    LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn, 1, order);
+    LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn, 1, order, (float*)nullptr, (int*)nullptr);
     return 0;
 }
 
@@ -1385,6 +1449,16 @@ int igemm_set_order(const char* spec) {
 
 void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n) {
     tileorder::tile_of(bid, ntm, ntn, tileorder::make_order(mode, group), tile_m, tile_n);
+}
+
+// bytes of split-K scratch that let op_igemm use its best form for `sk` splits: the row slabs of the finish-kernel form, or (wide
+// tiles, 2..4 splits) the tile-shaped fragment slabs + ticket words of the in-launch reduction, whichever is larger
+size_t igemm_splitk_ws_bytes(const IGemmArgs& a, int sk) {
+    const size_t rows = (size_t)sk * a.M * a.Nout * sizeof(float);
+    const int bn = (a.Nout % 320 == 0) ? 320 : 256;
+    const size_t tiles = (size_t)((a.M + 255) / 256) * ((a.Nout + bn - 1) / bn);
+    const size_t frag = (tiles * sk * 256 * bn * sizeof(float) + 255) / 256 * 256 + tiles * sizeof(int);
+    return rows > frag ? rows : frag;
 }
 
 int igemm_splitk_factor(const IGemmArgs& a) {

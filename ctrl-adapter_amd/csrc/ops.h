@@ -17,6 +17,8 @@ typedef ctrl_igemm_desc IGemmArgs;
 int op_igemm(const IGemmArgs& a, hipStream_t s);
 // K-split factor op_igemm would use given scratch (1 = no split); scratch needed = factor * M * Nout * sizeof(float)
 int igemm_splitk_factor(const IGemmArgs& a);
+// scratch bytes for that factor (>= factor * M * Nout * sizeof(float): the in-launch reduction of 2..4 splits keeps tile-shaped slabs)
+size_t igemm_splitk_ws_bytes(const IGemmArgs& a, int sk);
 // tile walk order of the implicit GEMM (tile_order.h): "legacy" | "auto" | "m,G" | "n,G"; 0 = accepted
 int igemm_set_order(const char* spec);
 // which problems take the 8-phase wide-tile kernel (igemm8_kernel): 0 none, 1 where the grid fills the chip (default), 2 every

@@ -89,7 +89,7 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
     const size_t mk = cx.mark();
     const int sk = igemm_splitk_factor(g);
     if (sk > 1) {
-        g.splitk_ws_bytes = (int64_t)sk * g.M * g.Nout * (int64_t)sizeof(float);
+        g.splitk_ws_bytes = (int64_t)igemm_splitk_ws_bytes(g, sk);
         g.splitk_ws = cx.alloc((size_t)g.splitk_ws_bytes);
     }
     RUN(cx, op_igemm(g, cx.s));

@@ -592,3 +592,27 @@ def test_wide_tile_is_bit_reproducible_and_close_to_the_ring_kernels(ops, gpu):
     ops.set_igemm_wide(-1)
     assert torch.equal(outs[1], outs[2])
     report("wide tile vs ring kernel", rel_inf(outs[1], outs[0].float().cpu()), 1e-3)
+
+
+@pytest.mark.parametrize("cin,cout,h,n,res_up", [(640, 640, 32, 8, 0), (320, 320, 64, 8, 0), (1280, 1280, 32, 8, 0), (640, 640, 32, 8, 2)])
+def test_splitk_reduced_inside_the_launch(ops, gpu, cin, cout, h, n, res_up):
+    """2..4 K-splits of the wide tile are summed by the last-arriving workgroup of every tile (agent-scope release / ticket / acquire,
+    csrc/igemm.hip) instead of a finish kernel: against the fp32 reference, and bit-identical from run to run (the slabs are added
+    in split order whoever arrives last) -- 4, 2, 2 and 4 splits here, with bias, time vector and a (half-resolution) residual"""
+    x = rnd(n, cin, h, h, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=0.02)
+    b, temb = rnd(cout, seed=3), rnd(n, cout, seed=4)
+    hr = h // 2 if res_up == 2 else h
+    r = torch.randn(n, hr, hr, cout, generator=torch.Generator().manual_seed(5))
+    r_full = r.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2) if res_up == 2 else r
+    ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + r_full.permute(0, 3, 1, 2)
+    wp = ops.pack_conv_w(w.to(gpu))
+    xh = x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    ws = torch.empty(16 * n * h * h * cout, dtype=torch.float32, device=gpu)
+    outs = []
+    for _ in range(4):
+        ws.fill_(float("nan"))                       # a slab read before it was written would poison the result
+        outs.append(ops.conv2d(xh, wp, cout, taps=9, bias=b.to(gpu), rowvec=temb.to(gpu), res=r.to(gpu), res_up=res_up, splitk_ws=ws))
+    report("in-launch split-K conv %d->%d @%d n%d" % (cin, cout, h, n), rel_inf(outs[0].permute(0, 3, 1, 2), ref))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "split-K result differs from run to run"
