@@ -159,6 +159,7 @@ class ControlNetModel(ParamTreeModule):
         with torch.cuda.device(sample.device):      # plan, stream and launches follow the tensors' device, not the current one
             self._text_cache_mode(encoder_hidden_states, L.lib().ctrl_controlnet_text_cache)
             L.check(L.lib().ctrl_controlnet_forward(self._ensure_plan(), *args, L.cur_stream()))
+            L.raise_if_out_of_range("ControlNetModel.forward")
         if pool:       # controlnet/controlnet.py:870-874: torch.mean(sample, dim=(2, 3), keepdim=True) of every output
             from . import ops
             outs = [ops.avgpool_nchw(o, 1, 1) for o in outs]

@@ -37,6 +37,9 @@ constexpr int kMaxDevices = 16;
 inline int cur_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kMaxDevices) ? d : 0; }
 // 4 KiB of zeros on the current device: source of the LDS-DMA loads that implement zero padding
 const void* device_zero_page();
+// range check of the fp16 activations (runtime.cpp): on?, and the per-device flag word the epilogues raise
+bool range_check_on();
+int* range_flag();
 
 // ---- per-kernel-class event profiler (used by bench.py's roofline leg) ----
 void prof_before(const char* tag, const char* kern_expr, long grid_threads, hipStream_t s);

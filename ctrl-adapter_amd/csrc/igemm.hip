@@ -55,6 +55,12 @@ __device__ __forceinline__ int chunk_swz(int row) {
 // workgroup's epilogue (HBM-bound fp32 stream traffic, GEGLU math) overlaps the other one's k-loop
 template <int BM, int BN, int NW> struct MinWaves { static constexpr int v = (BM * BN == 128 * 256) ? (NW == 8 ? 4 : (NW == 4 ? 2 : 1)) : 1; };
 
+// range check (ctrl_igemm_desc::nonfinite): raise the flag when a value about to be rounded to fp16 does not fit (inf / nan / |x| > 65504)
+__device__ __forceinline__ void flag_nonfinite(int32_t* flag, bool bad) {
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) *(volatile int32_t*)flag = 1;
+}
+__device__ __forceinline__ bool out_of_half(float x) { return !(fabsf(x) <= 65504.0f); }
+
 // Eight residual values of output row `row` from column `col` on, as fp32 (the fp32 stream or an fp16 tensor; `up2`: held at half
 // the output resolution and read through a nearest x2 up-sampling, see res_row_of).  32-bit element offsets (checked by op_igemm).
 struct ResSrc { const void* p; unsigned ld; bool f32, up2; int hw, w, hh, wh; };
@@ -147,6 +153,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                         const size_t o = ((size_t)img * sg.ncols + (pcb - sg.col_begin) + ch) * sg.ld + tok;
                         const f4 v0 = *(const f4*)(stg + ch * SLT + c8 * 8), v1 = *(const f4*)(stg + ch * SLT + c8 * 8 + 4);
                         if (sg.dtype == DT_F16) {
+                            if (e.nonfinite && (out_of_half(v0[0]) || out_of_half(v0[1]) || out_of_half(v0[2]) || out_of_half(v0[3]) ||
+                                                out_of_half(v1[0]) || out_of_half(v1[1]) || out_of_half(v1[2]) || out_of_half(v1[3])))
+                                *(volatile int32_t*)e.nonfinite = 1;          // (divergent code: any lane may raise the flag)
                             h8 pk = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
                                      (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
                             *(h8*)((half_t*)sg.out + o) = pk;
@@ -261,6 +270,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                             const int lcol = (gg ? (ni >> 1) * 16 : ni * 16) + ecol;
                             const float sc = (e.scale2_from > 0 && wcol0 + lcol >= e.scale2_from) ? e.scale2 : e.scale;
                             const h4 pk = {(half_t)(x[0] * sc), (half_t)(x[1] * sc), (half_t)(x[2] * sc), (half_t)(x[3] * sc)};
+                            if (e.nonfinite) flag_nonfinite(e.nonfinite, row_w < e.M && (out_of_half(x[0] * sc) || out_of_half(x[1] * sc) || out_of_half(x[2] * sc) || out_of_half(x[3] * sc)));
                             *(h4*)(stg16 + erow * RS + lcol * 2) = pk;
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -347,6 +357,12 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                             }
 #pragma unroll
                             for (int i = 0; i < 8; ++i) x[i] = al * bx[i] + (1.0f - al) * x[i];
+                        }
+                        if (e.nonfinite && (e.out16 != nullptr || e.seg[0].dtype == DT_F16)) {
+                            bool bad = false;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) bad = bad || out_of_half(x[i]);
+                            if (bad) *(volatile int32_t*)e.nonfinite = 1;     // (divergent code: any lane may raise the flag)
                         }
                         if (e.out16) {       // fp16 GEMM-operand mirror of an fp32 stream output
                             h8 pk;
@@ -1551,7 +1567,16 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+static int op_igemm_checked(const IGemmArgs& a, hipStream_t s);
 int op_igemm(const IGemmArgs& a, hipStream_t s) {
+    if (!a.nonfinite && range_check_on()) {          // debug aid: every fp16 value the epilogue writes is tested for inf / nan
+        IGemmArgs b = a;
+        b.nonfinite = range_flag();
+        return op_igemm_checked(b, s);
+    }
+    return op_igemm_checked(a, s);
+}
+static int op_igemm_checked(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(a.M > 0 && a.Nout > 0 && a.Ktot > 0, "igemm: empty problem");
     CTRL_CHECK(a.Cin % 32 == 0, "igemm: Cin must be a multiple of 32 (got " + std::to_string(a.Cin) + ")");
     CTRL_CHECK(a.Ktot == a.taps * a.Cin, "igemm: Ktot != taps*Cin");

@@ -10,6 +10,7 @@
 // Frames of a clip are kept frame-major ([(b f) h w][C], the reference's own (bf) c h w order), so the temporal
 // ops address the frame axis with a stride instead of materialising the b c f h w permutes.
 #include "plan_common.h"
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -476,6 +477,10 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
                 TV t3 = stream_alloc(cx, (size_t)M * INNER, false);
                 // frame-sharded clip: pixel shards around the temporal block when the transport can and the pixels divide
                 const bool a2a = a.comm && a.comm->all_to_all && clip_a2a_enabled() && (Lt % a.comm->world == 0);
+                if (a.comm && a.comm->all_to_all && clip_a2a_enabled() && !a2a) {
+                    static bool told = false;          // (the K|V all-gather form moves 4-27x the bytes: say so once instead of silently)
+                    if (!told) { told = true; fprintf(stderr, "ctrl: clip split: %d pixels per frame do not divide by %d ranks -- temporal transformer falls back to the K|V all-gather form\n", Lt, a.comm->world); }
+                }
                 // frame-index embedding add (:279) and the temporal block's first LayerNorm in one pass over the tokens (the
                 // pixel-sharded form normalises after its exchange instead)
                 half_t* t3_ln = a2a ? nullptr : cx.h((size_t)M * INNER);
@@ -754,6 +759,9 @@ void ctrl_adapter_destroy(ctrl_adapter* h) { delete h; }
 int ctrl_adapter_trim(ctrl_adapter* h) {
     CTRL_CHECK(h, "adapter_trim: null plan");
     DeviceGuard dg(h->device);
+    // trim synchronises the device and frees retired blocks: not while a forward of this plan is being recorded (the sync would
+    // invalidate that capture), and never concurrently with a forward on the same plan (a plan has no lock: include/ctrl_hip.h)
+    CTRL_CHECK(!h->capture_active(), "adapter_trim: a stream capture of this plan's forward is in progress");
     HIP_TRY(hipDeviceSynchronize());
     h->arena.trim();
     h->kvc.trim();
@@ -791,7 +799,9 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     TRY(h->enter(s, &capturing));
     // a KEEP forward that still has to allocate its text K/V buffers cannot be recorded into a hipGraph: refuse up front,
     // before any lane is forked (an error in the middle of a capture leaves unjoined streams behind)
-    CTRL_CHECK(!(capturing && h->kvc.mode == KvCache::KEEP && h->kvc.slots.empty()),
+    // (single-key states, Lk == 1 -- what the video pipelines pass -- never project text K/V: their slots stay empty for ever and
+    // need none)
+    CTRL_CHECK(!(capturing && needs_ehs && Lk > 1 && h->kvc.mode == KvCache::KEEP && h->kvc.slots.empty()),
                "text K/V cache: the first KEEP forward allocates its buffers and cannot run under stream capture -- run it "
                "eagerly once, then capture");
     const int* map_dev = nullptr;

@@ -247,10 +247,17 @@ struct PlanBase {
     ~PlanBase() { if (last_done) (void)hipEventDestroy(last_done); }
     // Two forwards on different streams share one workspace: the later one waits for the earlier one's last launch.
     // (Inside a stream capture nothing is recorded or waited for: a graph replay is ordered by its launch stream.)
+    hipStream_t cap_stream = nullptr;      // stream of the last forward that ran under capture (trim refuses while it still captures)
+    bool capture_active() const {
+        if (!cap_stream) return false;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        return hipStreamIsCapturing(cap_stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    }
     int enter(hipStream_t s, bool* capturing) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s, &cs);
         *capturing = (cs == hipStreamCaptureStatusActive);
+        cap_stream = *capturing ? s : nullptr;
         if (!*capturing && last_valid && last_stream != s) HIP_TRY(hipStreamWaitEvent(s, last_done, 0));
         return 0;
     }

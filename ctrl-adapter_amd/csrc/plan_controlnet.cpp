@@ -462,6 +462,7 @@ void ctrl_controlnet_destroy(ctrl_controlnet* h) { delete h; }
 int ctrl_controlnet_trim(ctrl_controlnet* h) {
     CTRL_CHECK(h, "controlnet_trim: null plan");
     DeviceGuard dg(h->device);
+    CTRL_CHECK(!h->capture_active(), "controlnet_trim: a stream capture of this plan's forward is in progress");      // see ctrl_adapter_trim
     HIP_TRY(hipDeviceSynchronize());             // nothing queued still touches a retired block
     h->arena.trim();
     h->kvc.trim();

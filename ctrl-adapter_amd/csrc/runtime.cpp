@@ -25,6 +25,38 @@ const void* device_zero_page() {
     return z[d];
 }
 
+// ---- range check of the fp16 activations (ctrl_range_check / CTRL_CHECK_FINITE) ----
+static int g_range_on = -1;
+bool range_check_on() {
+    if (g_range_on < 0) { const char* e = getenv("CTRL_CHECK_FINITE"); g_range_on = (e && e[0] == '1') ? 1 : 0; }
+    return g_range_on == 1;
+}
+int* range_flag() {
+    static int* f[kMaxDevices] = {};
+    static std::mutex mu;
+    const int d = cur_device();
+    std::lock_guard<std::mutex> lk(mu);
+    if (!f[d]) {
+        if (hipMalloc((void**)&f[d], 256) != hipSuccess) return nullptr;
+        if (hipMemset(f[d], 0, 256) != hipSuccess) return nullptr;
+    }
+    return f[d];
+}
+extern "C" int ctrl_range_check(int on) {
+    if (on == 0 || on == 1) g_range_on = on;
+    return range_check_on() ? 1 : 0;
+}
+extern "C" int ctrl_range_status(int reset) {
+    if (!range_check_on()) return 2;
+    int* f = range_flag();
+    if (!f) return 2;
+    int v = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    if (hipMemcpy(&v, f, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    if (v && reset) (void)hipMemset(f, 0, sizeof(int));
+    return v ? 1 : 0;
+}
+
 bool g_prof_on = false;
 double g_prof_flops = 0, g_prof_bytes = 0;
 namespace {

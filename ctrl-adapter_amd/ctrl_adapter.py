@@ -110,6 +110,7 @@ class ControlNetAdapter(ParamTreeModule):
                 L.check(L.lib().ctrl_adapter_forward(self._ensure_plan(), in_ptrs, in_dt, *args, L.cur_stream()))
             else:
                 L.check(L.lib().ctrl_adapter_forward_scatter(self._ensure_plan(), in_ptrs, in_dt, *args, *tail, L.cur_stream()))
+            L.raise_if_out_of_range("ControlNetAdapter.forward")
         return finish(outs, mid_out)
 
     def _launch_args(self, down_block_res_samples, mid_block_res_sample, num_frames, timestep, encoder_hidden_states,

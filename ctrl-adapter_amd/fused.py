@@ -70,4 +70,5 @@ def controlled_step(controlnet, adapter, sample, timestep, encoder_hidden_states
         L.check(L.lib().ctrl_step_forward(
             controlnet._ensure_plan(), adapter._ensure_plan(), *cn_args,
             ad_args[3], *ad_args[4:10], int(use_m and mid_out is not None), ad_args[10], ad_args[11], frame_pos, n_out, L.cur_stream()))
+        L.raise_if_out_of_range("controlled_step")
     return (down, mid), finish(outs, mid_out)

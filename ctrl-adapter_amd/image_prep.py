@@ -67,19 +67,21 @@ def _device_tables(in_size, out_size, device):
     return _tables[key]
 
 
-def _as_u8_hwc(img):
+def _as_u8_hwc(img, width=None, height=None):
     if torch.is_tensor(img):
         a = img
         if a.dtype != torch.uint8 or a.dim() != 3 or a.shape[2] != 3:
             raise ValueError("tensor images must be uint8 [H, W, 3] (RGB)")
         return a
     if hasattr(img, "convert"):                 # PIL image: do_convert_rgb
-        # bit-exactness with the reference recipe is established for RGB sources; diffusers' VaeImageProcessor resizes
-        # BEFORE convert("RGB"), so palette ("P": nearest-neighbour resize) and alpha ("RGBA"/"LA": premultiplied
-        # resampling) images would come out differently there -- refuse them instead of returning other pixels
+        # diffusers' VaeImageProcessor resizes BEFORE convert("RGB"): RGB and L sources resample identically either way (the GPU path
+        # below, bit-exact); palette ("P": nearest-neighbour resize) and alpha ("RGBA" / "LA": premultiplied resampling) sources do
+        # not, so for those the reference's own order runs on the host -- Pillow's resize in the SOURCE mode, then the conversion --
+        # and the GPU pass only does /255, layout and the repeats (they used to be refused)
         if getattr(img, "mode", "RGB") not in ("RGB", "L"):
-            raise ValueError("prepare_images: PIL mode %r is not supported (convert to RGB first; only RGB / L sources "
-                             "resample identically to the reference)" % (img.mode,))
+            if width is not None and img.size != (width, height):
+                from PIL import Image
+                img = img.resize((width, height), resample=getattr(Image, "Resampling", Image).LANCZOS)
         img = np.asarray(img.convert("RGB"))
     a = np.asarray(img)
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
@@ -94,11 +96,12 @@ def prepare_images(images, width, height, batch_size, num_images_per_prompt, dev
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("prepare_images (libctrlhip) runs on the GPU only; there is no CPU fallback")
-    if width % 8 or height % 8:
-        # diffusers' get_default_height_width rounds both down to a multiple of the VAE scale factor (8); every size the
-        # reference uses (512, 1024) already is one -- anything else would silently differ from it
-        raise ValueError("prepare_images: width and height must be multiples of 8 (got %dx%d)" % (width, height))
-    frames = [_as_u8_hwc(i) for i in images]
+    # diffusers' get_default_height_width rounds both down to a multiple of the VAE scale factor (8), as the reference does
+    # (model/ctrl_helper.py:268-296 -> VaeImageProcessor.preprocess); every size the reference's scripts use (512, 1024) already is one
+    width, height = int(width) - int(width) % 8, int(height) - int(height) % 8
+    if width <= 0 or height <= 0:
+        raise ValueError("prepare_images: width and height must be at least 8")
+    frames = [_as_u8_hwc(i, width, height) for i in images]
     if not frames or any(f.shape != frames[0].shape for f in frames):
         raise ValueError("prepare_images needs at least one image and all images of one size")
     src = torch.stack([f.to(device) for f in frames]).contiguous()        # [F][Hin][Win][3] uint8

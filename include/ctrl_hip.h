@@ -99,8 +99,18 @@ typedef struct ctrl_igemm_desc {
                            (res[img][oy/2][ox/2]); 0 | 1: res[m*ldres + n] */
     int32_t pad2_;
     ctrl_igemm_seg seg[3];
+    int32_t* nonfinite;  /* optional (device): set to 1 when an fp16 value this launch writes is inf / nan, i.e. an activation left the
+                            fp16 range (|x| > 65504).  NULL = no check; op_igemm fills it in itself while the range check is on
+                            (ctrl_range_check / CTRL_CHECK_FINITE=1) */
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
+/* Range safety of the fp16 activations (debug aid for real checkpoints: the synthetic N(0, 0.02^2) weights never leave the fp16 range).
+   ctrl_range_check(1) -- or CTRL_CHECK_FINITE=1 in the environment -- makes every GEMM / convolution epilogue OR "this fp16 value is
+   inf / nan" into a per-device flag word; ctrl_range_check(0) turns it off, ctrl_range_check(-1) only queries.  ctrl_range_status(reset)
+   synchronises the current device and returns 1 when the flag was raised since the last reset (2 = the check is off).  The Python
+   mirrors call it after every forward while the check is on and raise RuntimeError. */
+int ctrl_range_check(int on);
+int ctrl_range_status(int reset);
 /* Walk order of the GEMM's output tiles over the 8 XCDs (csrc/tile_order.h; performance only, results are identical):
    "auto" (default; also CTRL_IGEMM_ORDER: grouped walk for row GEMMs whose weights exceed an XCD's L2 share), "legacy", or
    forced "m,G" / "n,G" (XCDs split the activation panels / the weight panels, weight panels walked in groups of G tiles).
@@ -289,7 +299,9 @@ int ctrl_adapter_text_cache(ctrl_adapter* h, int mode);
 /* ---- Workspace hygiene.  A plan's workspace, text K/V buffers and conditioning cache grow by RETIRING the outgrown block
  * (never freeing it inside a forward: queued launches and captured hipGraphs keep valid addresses), so a server that sees
  * ever larger shapes keeps the sum of the earlier sizes.  ctrl_*_trim synchronises the device and frees the retired blocks;
- * call it when no captured graph that was recorded before the last growth will be replayed again. */
+ * call it when no captured graph that was recorded before the last growth will be replayed again.  A plan has no lock: trim
+ * must not run concurrently with a forward of the same plan, and it is refused (non-zero) while a stream capture of that plan's
+ * forward is still open (its device synchronisation would invalidate the capture). */
 int ctrl_controlnet_trim(ctrl_controlnet* h);
 int ctrl_adapter_trim(ctrl_adapter* h);
 
@@ -305,7 +317,11 @@ int ctrl_adapter_trim(ctrl_adapter* h);
  *   temporal GroupNorm  (TemporalResnetBlock, :226)              all_reduce_sum_f32 of the (clip, group) sums
  * The transports used are torch.distributed over RCCL (ctrl-adapter_amd/clip_parallel.py); any transport with these
  * semantics works.  Callbacks return 0 on success.  If `ws_bytes` is too small the call fails with return code 2 and
- * `ws_needed` holds the size to retry with.  Runs on the caller's stream only (no stream lanes). */
+ * `ws_needed` holds the size to retry with.  Runs on the caller's stream only (no stream lanes).
+ * Results: the all_gather form is BIT-identical to the unsharded forward; the all_to_all form is tolerance-equal (<= 3.4e-4
+ * rel-inf observed, 1e-3 asserted) -- its way back carries the temporal branch as fp16 and the AlphaBlender runs after it,
+ * where the unsharded path blends in the fp32 epilogue of the block's last GEMM.  When the pixels of a frame do not divide by
+ * the ranks the all_to_all form is dropped for that block (logged once on stderr). */
 typedef struct ctrl_clip_comm {
     int32_t rank, world;
     void* ws; int64_t ws_bytes;

@@ -616,3 +616,55 @@ def test_splitk_reduced_inside_the_launch(ops, gpu, cin, cout, h, n, res_up):
     report("in-launch split-K conv %d->%d @%d n%d" % (cin, cout, h, n), rel_inf(outs[0].permute(0, 3, 1, 2), ref))
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "split-K result differs from run to run"
+
+
+def test_range_check_flags_an_activation_beyond_fp16(ops, gpu):
+    """CTRL_CHECK_FINITE=1 / ctrl_range_check(1): a GEMM whose result leaves the fp16 range (|x| > 65504) raises the per-device flag from
+    its epilogue -- fp16 rows, the fp16 mirror of an fp32 stream and transposed fp16 outputs -- and an in-range one does not; with the
+    check off nothing is flagged.  Then the module path: a ControlNet forward on weights scaled out of range raises RuntimeError."""
+    from ctrl_adapter_amd import _lib as L
+    lib = L.lib()
+    M, N, K = 512, 320, 512
+    x = torch.full((M, K), 16.0).half().to(gpu)
+    w_small = ops.pack_linear_w(torch.full((N, K), 0.01).to(gpu))          # 16 * 0.01 * 512 = 81.9: fine
+    w_big = ops.pack_linear_w(torch.full((N, K), 16.0).to(gpu))            # 16 * 16 * 512 = 131072 > 65504
+    assert lib.ctrl_range_check(0) == 0 and lib.ctrl_range_status(1) == 2  # off: status says so
+    ops.linear(x, w_big)
+    assert lib.ctrl_range_check(1) == 1
+    try:
+        assert lib.ctrl_range_status(1) == 0                               # nothing was recorded while it was off
+        ops.linear(x, w_small)
+        assert lib.ctrl_range_status(1) == 0
+        y = ops.linear(x, w_big)
+        assert torch.isinf(y).any()
+        assert lib.ctrl_range_status(1) == 1 and lib.ctrl_range_status(1) == 0      # raised, then reset
+        for wide in (2, 0):                                                # both kernel families share the epilogue
+            ops.set_igemm_wide(wide)
+            ops.linear(x, w_big)
+            assert lib.ctrl_range_status(1) == 1, wide
+            out = torch.empty(2, N, 256, dtype=torch.float16, device=gpu)   # transposed fp16 output ([img][C][tokens])
+            ops.igemm(x, K, w_big, M, N, K, segs=[(out, 256, 0, N, ops.SEG_TRANSPOSED, 256)])
+            assert lib.ctrl_range_status(1) == 1, wide
+            o32 = torch.empty(M, N, dtype=torch.float32, device=gpu)       # fp32 stream + fp16 mirror: the mirror overflows
+            mir = torch.empty(M, N, dtype=torch.float16, device=gpu)
+            ops.igemm(x, K, w_big, M, N, K, segs=[(o32, N, 0, N, ops.SEG_ROW, 1)], out16=mir, ld16=N)
+            assert lib.ctrl_range_status(1) == 1 and torch.isfinite(o32).all() and torch.isinf(mir).any(), wide
+        ops.set_igemm_wide(-1)
+        # module level: RuntimeError from the mirror's forward
+        import helpers  # noqa: F401  (puts tests/golden on the path)
+        import ctrl_adapter_amd as P
+        import cases
+        from oracle.init import seeded_init
+        cn = seeded_init(P.ControlNetModel(**cases.CONTROLNET_KW), seed=11)
+        with torch.no_grad():
+            for p_ in cn.parameters():
+                if p_.ndim == 4 and p_.shape[1] >= 320:
+                    p_.mul_(3000.0)                                         # conv weights far out of the synthetic range
+        cn = cn.to(gpu)
+        inp = cases.controlnet_inputs(N=1, hs=8)
+        with pytest.raises(RuntimeError, match="non-finite fp16 activation"):
+            cn(inp["sample"].half().to(gpu), inp["timestep"].to(gpu), inp["encoder_hidden_states"].half().to(gpu),
+               inp["controlnet_cond"].half().to(gpu), return_dict=False)
+    finally:
+        ops.set_igemm_wide(-1)
+        lib.ctrl_range_check(0)

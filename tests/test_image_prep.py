@@ -52,7 +52,14 @@ def test_hip_prepare_images_is_bit_exact(gpu, h, w, oh, ow, dt):
     flat = P.prepare_images([torch.from_numpy(i) for i in imgs], ow, oh, 1, 1, gpu, dt)          # uint8 tensors in, no CFG
     assert torch.equal(flat.cpu(), O.prepare_images(imgs, ow, oh, 1, 1, dtype=dt))
     print("PARITY prepare_images %dx%d -> %dx%d %s: bit-exact" % (h, w, oh, ow, dt))
-    with pytest.raises(ValueError):                   # sizes diffusers would round down to a multiple of 8
-        P.prepare_images([torch.from_numpy(imgs[0])], 100, 96, 1, 1, gpu, dt)
-    with pytest.raises(ValueError):                   # palette / alpha sources resample differently in the reference's recipe
-        P.prepare_images([PIL.fromarray(imgs[0], "RGB").convert("RGBA")], ow, oh, 1, 1, gpu, dt)
+    # sizes are rounded DOWN to a multiple of 8, as diffusers' get_default_height_width does (100 x 96 -> 96 x 96)
+    r8 = P.prepare_images([torch.from_numpy(imgs[0])], 100, 96, 1, 1, gpu, dt)
+    assert r8.shape[-2:] == (96, 96) and torch.equal(r8.cpu(), O.prepare_images(imgs[:1], 96, 96, 1, 1, dtype=dt))
+    # palette / alpha sources: the reference resizes in the SOURCE mode, then converts (VaeImageProcessor.preprocess) -- written
+    # out with Pillow here
+    for mode in ("RGBA", "P", "LA"):
+        src = PIL.fromarray(imgs[0], "RGB").convert(mode)
+        want = np.array(src.resize((ow, oh), resample=PIL.Resampling.LANCZOS).convert("RGB")).astype(np.float32) / 255.0
+        want = torch.from_numpy(want).permute(2, 0, 1)[None, None].to(dt)
+        got_m = P.prepare_images([src], ow, oh, 1, 1, gpu, dt)
+        assert got_m.shape == want.shape and torch.equal(got_m.cpu(), want), mode
