@@ -202,6 +202,9 @@ def main():
                     help="video workloads: ONE clip for the whole job, its 16 frames sharded over the --gpus ranks (frame-mixing "
                          "ops exchange over RCCL: all_to_all around the temporal transformers, Conv3d halo, GroupNorm "
                          "all-reduce; SURVEY.md 8e row 2); strong scaling, eager launches (the exchanges are host callbacks)")
+    ap.add_argument("--clip-lanes", type=int, default=4, help="--clip-split, native transport: communicators = stream lanes of the adapter (1 = one stream)")
+    ap.add_argument("--clip-transport", default="rccl", choices=["rccl", "torch"],
+                    help="--clip-split: native RCCL enqueued from C++ (graph-capturable, default) or torch.distributed callbacks (eager)")
     ap.add_argument("--fused", action="store_true",
                     help="time the fused controlled_step(controlnet, adapter, ...) instead of the pipelines' two calls "
                          "controlnet(...) ; adapter(...) (same arithmetic, bit-identical results)")
@@ -234,15 +237,21 @@ def main():
     if args.clip_split:
         if not w["video"] or w["n_cn"] != 1 or nf % world:
             raise SystemExit("--clip-split: a single-ControlNet video workload whose 16 frames divide by --gpus")
-        from ctrl_adapter_amd.clip_parallel import TorchDistTransport, shard_frames
-        if world == 1 and not torch.distributed.is_initialized():      # a one-rank group still runs every exchange through RCCL
-            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
-            torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port_, rank=0, world_size=1)
-        comm = TorchDistTransport()
+        from ctrl_adapter_amd.clip_parallel import RcclTransport, TorchDistTransport, shard_frames
+        if args.clip_transport == "torch":       # round 3's Python-callback transport (eager launches only)
+            if world == 1 and not torch.distributed.is_initialized():      # a one-rank group still runs every exchange through RCCL
+                s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+                torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port_, rank=0, world_size=1)
+            comm = TorchDistTransport()
+            args.no_graph = True
+        else:                                    # native RCCL on the forward's stream (csrc/clip_rccl.cpp): hipGraph-capturable
+            comm = RcclTransport(rank=rank, world=world, lanes=args.clip_lanes) if world == 1 else RcclTransport(lanes=args.clip_lanes)
+            if args.clip_lanes > 1:
+                args.no_graph = True             # several communicators inside one capture: RCCL 2.26 refuses (hipErrorStreamCaptureUnsupported);
+                                                 # four eager lanes (59.7 ms at world 1) beat one captured lane (62.4 ms) -- profiles/r04_clip_split_world1.txt
         x = make_inputs(dev, w, n, seed=1234)          # the SAME clip on every rank ...
         x = {k: (shard_frames(v, nf, rank, world) if v.shape[0] == n else v) for k, v in x.items()}      # ... its frames sharded
         n, nf = n // world, nf // world
-        args.no_graph = True
     else:
         x = make_inputs(dev, w, n, seed=1234 + rank)   # every rank owns different images / clips (no collective)
     t = torch.tensor([499.0], device=dev)

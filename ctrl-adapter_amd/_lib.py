@@ -79,7 +79,7 @@ CB_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_v
 class ClipComm(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
                 ("all_gather", CB_GATHER), ("all_reduce_sum_f32", CB_REDUCE), ("halo_exchange", CB_HALO),
-                ("user", C.c_void_p), ("ws_needed", C.c_int64), ("all_to_all", CB_A2A)]
+                ("user", C.c_void_p), ("ws_needed", C.c_int64), ("all_to_all", CB_A2A), ("next_lane", C.c_void_p)]
 
 
 # every symbol include/ctrl_hip.h declares (tests check the library exports all of them)
@@ -97,7 +97,7 @@ EXPORTS = [
     "ctrl_adapter_param_count", "ctrl_adapter_param_spec", "ctrl_adapter_create", "ctrl_adapter_destroy",
     "ctrl_adapter_forward",
     "ctrl_adapter_forward_scatter", "ctrl_adapter_forward_clip_sharded", "ctrl_controlnet_text_cache", "ctrl_adapter_text_cache", "ctrl_controlnet_trim", "ctrl_adapter_trim",
-    "ctrl_step_forward",
+    "ctrl_step_forward", "ctrl_rccl_unique_id", "ctrl_rccl_comm_create", "ctrl_rccl_comm_destroy", "ctrl_rccl_comm_bind", "ctrl_rccl_comm_bytes_sent",
     "ctrl_router_weights", "ctrl_router_merge", "ctrl_prepare_images",
 ]
 
@@ -116,10 +116,17 @@ def lib():
         _lib.ctrl_last_error.restype = C.c_char_p
         for name in EXPORTS:
             fn = getattr(_lib, name)
-            if name not in ("ctrl_last_error", "ctrl_controlnet_destroy", "ctrl_adapter_destroy"):
+            if name not in ("ctrl_last_error", "ctrl_controlnet_destroy", "ctrl_adapter_destroy", "ctrl_rccl_comm_destroy", "ctrl_rccl_comm_bytes_sent"):
                 fn.restype = C.c_int
         _lib.ctrl_controlnet_destroy.restype = None
         _lib.ctrl_adapter_destroy.restype = None
+        _lib.ctrl_rccl_comm_destroy.restype = None
+        _lib.ctrl_rccl_comm_destroy.argtypes = [C.c_void_p]
+        _lib.ctrl_rccl_comm_bytes_sent.restype = C.c_int64
+        _lib.ctrl_rccl_comm_bytes_sent.argtypes = [C.c_void_p]
+        _lib.ctrl_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        _lib.ctrl_rccl_comm_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        _lib.ctrl_rccl_unique_id.argtypes = [C.c_void_p]
         _lib.ctrl_op_gn_stats_floats.restype = C.c_size_t
         if _lib.ctrl_abi_version() != ABI_VERSION:
             raise RuntimeError("libctrlhip ABI version mismatch")

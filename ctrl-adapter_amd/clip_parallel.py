@@ -8,8 +8,11 @@ ops of the adapter exchange data (include/ctrl_hip.h, ctrl_clip_comm):
     temporal GroupNorm   all-reduce of the 2 x 32 x clips partial sums      (TemporalResnetBlock, :226)
 The native side calls back into a *transport* with byte offsets into an exchange workspace the transport owns:
 
-    TorchDistTransport   torch.distributed: backend "nccl" (= RCCL over xGMI) on the GPUs, one process per GPU; "gloo" in
-                         the CPU tests of the transport itself.  Exchanges are enqueued on the current stream.
+    RcclTransport        the production transport: RCCL over xGMI enqueued on the forward's stream from C++ (csrc/clip_rccl.cpp), one
+                         process per GPU; the sharded forward is hipGraph-capturable with it.  torch.distributed (any backend) only
+                         carries the 128-byte communicator id at construction.
+    TorchDistTransport   torch.distributed collectives through Python callbacks: backend "nccl" on the GPUs, "gloo" in the CPU
+                         tests of the callback contract.  Exchanges are enqueued on the current stream; eager launches only.
     LoopbackTransport    `world` threads of ONE process (virtual ranks on one GPU): used by the single-GPU parity test
                          that proves frame-sharded == unsharded results.
 
@@ -155,6 +158,72 @@ class TorchDistTransport(ClipTransport):
         if ops:
             for req in d.batch_isend_irecv(ops):
                 req.wait()            # nccl: orders the current stream behind the transfer (no host block)
+
+
+class RcclTransport(ClipTransport):
+    """Native RCCL transport (include/ctrl_hip.h: ctrl_rccl_*).  `group`: the torch.distributed group of the ranks that share one clip
+    (None = the default group; any backend) -- used once, to broadcast the communicator ids from the group's rank 0.  With world == 1
+    and no process group at all pass rank=0, world=1.
+    lanes: communicators (each with its own exchange workspace) chained through ctrl_clip_comm::next_lane -- the adapter runs its four
+    pyramid levels on four HIP streams and lane l exchanges on communicator l; lanes=1 keeps the whole forward on the caller's stream."""
+
+    def __init__(self, group=None, device=None, rank=None, world=None, lanes=4):
+        import torch.distributed as dist
+        if rank is None:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.error = None
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        self.use_all_to_all = True
+        self.handles, self.wss, self._chain = [], [], []
+        for _ in range(max(1, int(lanes))):
+            idbuf = (C.c_uint8 * 128)()
+            h = C.c_void_p()
+            with torch.cuda.device(self.device):
+                if self.rank == 0:
+                    L.check(L.lib().ctrl_rccl_unique_id(idbuf))
+                if self.world > 1:
+                    t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8)
+                    t = t.to(self.device) if dist.get_backend(group) == "nccl" else t
+                    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                    idbuf = (C.c_uint8 * 128)(*t.cpu().tolist())
+                L.check(L.lib().ctrl_rccl_comm_create(idbuf, self.rank, self.world, C.byref(h)))      # collective
+            self.handles.append(h)
+        self.ws = None
+        self.ensure(1 << 20)
+
+    def ensure(self, nbytes):
+        if self.ws is None or self.ws.numel() < nbytes:
+            self.wss = [torch.empty(int(nbytes), dtype=torch.uint8, device=self.device) for _ in self.handles]
+            self.ws = self.wss[0]
+        return self.ws
+
+    @property
+    def bytes_sent(self):
+        return sum(int(L.lib().ctrl_rccl_comm_bytes_sent(h)) for h in self.handles if h)
+
+    def c_struct(self):
+        """the head of the lane chain (the structs of the chain are kept alive on self)"""
+        self._chain = [L.ClipComm() for _ in self.handles]
+        with torch.cuda.device(self.device):
+            for cs, h, ws in zip(self._chain, self.handles, self.wss):
+                L.check(L.lib().ctrl_rccl_comm_bind(h, ws.data_ptr(), ws.numel(), 1 if self.use_all_to_all else 0, C.byref(cs)))
+        for cs, nxt in zip(self._chain, self._chain[1:]):
+            cs.next_lane = C.addressof(nxt)
+        return self._chain[0]
+
+    def close(self):
+        for h in getattr(self, "handles", []):
+            if h:
+                L.lib().ctrl_rccl_comm_destroy(h)
+        self.handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LoopbackWorld:

@@ -671,8 +671,15 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
         if (f == 1 && nl > ctrl_adapter::kLevelLanes) { l = top_seen == 0 ? 0 : ctrl_adapter::kLevelLanes - 1 + top_seen; ++top_seen; }
         return l % nl;
     };
+    // frame-sharded clip: lane l exchanges through the l-th transport of the chain (ctrl_clip_comm::next_lane)
+    ctrl_clip_comm* lane_comm[ctrl_adapter::kLanes] = {};
+    {
+        ctrl_clip_comm* cc = k.comm;
+        for (int l = 0; l < ctrl_adapter::kLanes; ++l) { lane_comm[l] = cc ? cc : k.comm; if (cc) cc = cc->next_lane; }
+    }
     auto run_in_lane = [&](int lane, int slot, const AdapterBlockW& bw, const BlockPre& bp, const void* in, void* out, int h, int wd, size_t frame_elems) -> int {
         cx.s = lane == 0 ? main_s : P->side[lane - 1];
+        a.comm = lane_comm[lane];
         if (!cx.dry && k.in_ev) HIP_TRY(hipStreamWaitEvent(cx.s, k.in_ev[slot], 0));     // fused step: producer still running
         cx.ar->off = lane_base[lane];
         if (cx.dry) cx.ar->peak = lane_base[lane];
@@ -832,9 +839,18 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     static const bool split_top = getenv("CTRL_ADAPTER_SPLIT_TOP") && atoi(getenv("CTRL_ADAPTER_SPLIT_TOP")) != 0;
     static const int env_lanes = getenv("CTRL_ADAPTER_LANES") ? atoi(getenv("CTRL_ADAPTER_LANES"))
                                                               : (split_top ? (int)ctrl_adapter::kLanes : (int)ctrl_adapter::kLevelLanes);
-    // frame-sharded clips run on ONE stream: the exchanges of one communicator must be issued and executed in the same
-    // order on every rank
-    const int nlanes = (g_prof_on || comm) ? 1 : std::min(std::max(env_lanes, 1), (int)ctrl_adapter::kLanes);
+    // frame-sharded clips: the exchanges of one communicator must be issued and executed in the same order on every rank, so
+    // there are as many lanes as the caller chained transports (ctrl_clip_comm::next_lane; one = everything on the caller's stream)
+    int comm_lanes = 0;
+    for (ctrl_clip_comm* cc = comm; cc; cc = cc->next_lane) {
+        CTRL_CHECK(cc->rank == comm->rank && cc->world == comm->world && cc->all_gather && cc->all_reduce_sum_f32 && cc->halo_exchange &&
+                   (((uintptr_t)cc->ws & 255) == 0) && (!comm->all_to_all == !cc->all_to_all),
+                   "clip_sharded: the transports of a lane chain must agree in rank / world / callbacks and have 256-byte aligned workspaces");
+        ++comm_lanes;
+        CTRL_CHECK(comm_lanes <= (int)ctrl_adapter::kLanes, "clip_sharded: transport chain longer than the lanes there are (or cyclic)");
+    }
+    const int want_lanes = std::min(std::max(env_lanes, 1), (int)ctrl_adapter::kLanes);
+    const int nlanes = g_prof_on ? 1 : (comm ? std::min(want_lanes, std::min(comm_lanes, (int)ctrl_adapter::kLevelLanes)) : want_lanes);
     size_t ws_peak = 0;
     AdapterCall k = {ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states, ehs_dtype,
                      ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out, h, nlanes, in_ev, comm, &ws_peak};
@@ -845,7 +861,9 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     if (h->kvc.mode == KvCache::REUSE)
         CTRL_CHECK(h->kvc.key_batch == ehs_batch && h->kvc.key_Lk == Lk, "adapter_forward: text K/V cache was kept for another batch / prompt length");
     TRY(adapter_run(dry, h->w, k));
-    if (comm && (size_t)comm->ws_bytes < ws_peak) {
+    bool ws_small = false;
+    for (ctrl_clip_comm* cc = comm; cc; cc = cc->next_lane) ws_small = ws_small || (size_t)cc->ws_bytes < ws_peak;
+    if (comm && ws_small) {
         comm->ws_needed = (int64_t)ws_peak;
         ctrl_set_error("clip_sharded: exchange workspace too small (need " + std::to_string(ws_peak) + " bytes); retry with ws_needed");
         return 2;

@@ -340,6 +340,13 @@ typedef struct ctrl_clip_comm {
        2 + 1 KB per token and direction instead of the 2*C*2 B x world a rank RECEIVES per token in the all_gather form
         */
     int (*all_to_all)(void* user, int64_t send_off, int64_t recv_off, int64_t bytes_per_rank, void* stream);
+    /* optional: further transports (own communicator, own workspace `ws`) for the adapter's stream lanes.  The blocks of the four
+       pyramid levels are independent, and on whole clips they run on four HIP streams; with ONE transport the sharded forward stays
+       on the caller's stream (the exchanges of one communicator must be issued and executed in one order on every rank), which
+       alone costs ~17 % at world 1.  A chain of L transports lets lane l issue its exchanges on transport l: every rank walks the
+       same program, so every communicator still sees its calls in one order, and the all-to-all of a 128^2 block runs under the
+       other lanes' compute.  rank / world must agree along the chain; ws_needed is reported on the head for all of them. */
+    struct ctrl_clip_comm* next_lane;
 } ctrl_clip_comm;
 int ctrl_adapter_forward_clip_sharded(ctrl_adapter* h,
                                       const void* const* ins, int in_dtype, int N, int H0, int W0, int num_frames,
@@ -347,6 +354,18 @@ int ctrl_adapter_forward_clip_sharded(ctrl_adapter* h,
                                       const void* encoder_hidden_states, int ehs_dtype, int ehs_batch, int Lk,
                                       void* const* outs, int out_dtype, const int32_t* frame_pos, int N_out,
                                       ctrl_clip_comm* comm, void* stream);
+
+/* ---- The production transport, native: RCCL over xGMI, enqueued on the forward's stream from C++ (csrc/clip_rccl.cpp).  No host
+ * callback into Python sits between launches, so ctrl_adapter_forward_clip_sharded is hipGraph-capturable with it.  RCCL is
+ * resolved at run time (dlopen; the copy already loaded into the process wins).  Rank 0 of the clip's group draws a unique id, the
+ * caller ships its 128 bytes to the other ranks (any channel), every rank creates the communicator (collective), binds its
+ * exchange workspace and passes the filled ctrl_clip_comm to the sharded forward. */
+typedef struct ctrl_rccl_comm ctrl_rccl_comm;
+int ctrl_rccl_unique_id(void* out128);
+int ctrl_rccl_comm_create(const void* id128, int rank, int world, ctrl_rccl_comm** out);
+void ctrl_rccl_comm_destroy(ctrl_rccl_comm* c);
+int ctrl_rccl_comm_bind(ctrl_rccl_comm* c, void* ws, int64_t ws_bytes, int use_all_to_all, ctrl_clip_comm* cs);
+int64_t ctrl_rccl_comm_bytes_sent(const ctrl_rccl_comm* c);
 
 /* ---- Fused step: ctrl_controlnet_forward + ctrl_adapter_forward[_scatter] of one denoise step as one call (the two
  * back-to-back calls of the pipelines, sdxl/pipelines/sdxl_controlnet_adapter_pipeline.py:1323,1338 and
