@@ -460,6 +460,10 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             const int Lt = H * W, M = N * Lt;
             half_t* n = cx.h((size_t)M * C);
             TRY(run_groupnorm(cx, b.norm, x, n, N, Lt, 1e-6f, false));
+            // the spatial transformer's token stream: three residual updates on a stream that proj_in starts afresh, so it can be
+            // kept in fp16 where the error budget allows (adapter_tok_f16(): measured per workload)
+            const bool tok16 = st && adapter_tok_f16() && cx.f32stream;
+            if (tok16) cx.f32stream = false;
             TV tok = stream_alloc(cx, (size_t)M * INNER, false);
             // the first LayerNorm of the spatial transformer rides on proj_in's epilogue
             half_t* tok_ln = st ? cx.h((size_t)M * INNER) : nullptr;
@@ -469,10 +473,15 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
                 // no temporal block: the spatial transformer's result is read once more, as proj_out's fp16 operand -- the last
                 // GEMM writes just that (the same rounding of the same fp32 value the mirror of an fp32 master would hold: bit-
                 // identical results, one 4-byte-per-element store less); with a temporal block it stays an fp32 stream
+                if (tok16 && tt) cx.f32stream = true;      // (what leaves the block towards the temporal branch stays fp32)
                 TV t2 = tt ? stream_alloc(cx, (size_t)M * INNER, false) : tv16(cx.h((size_t)M * INNER));
-                TRY(run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e, a.e.Lk == 1 ? pre.stb_ov[i] : nullptr, nullptr, tok_ln));
+                if (tok16) cx.f32stream = false;
+                const int rc_tb = run_basic_tb(cx, Lw.stb, tok, t2, N, Lt, a.e, a.e.Lk == 1 ? pre.stb_ov[i] : nullptr, nullptr, tok_ln);
+                if (tok16) cx.f32stream = true;
+                if (rc_tb) return rc_tb;
                 tok = t2; smix = t2;
             }
+            if (tok16) cx.f32stream = true;
             if (tt) {
                 TV t3 = stream_alloc(cx, (size_t)M * INNER, false);
                 // frame-sharded clip: pixel shards around the temporal block when the transport can and the pixels divide
@@ -857,6 +866,7 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     h->arena.off = 0; h->arena.peak = 0;
     Ctx dry{&h->arena, s, true};
     dry.f32stream = stream_f32_enabled();
+    dry.h1_f16 = adapter_h1_f16();
     dry.kvc = &h->kvc; h->kvc.next = 0;
     if (h->kvc.mode == KvCache::REUSE)
         CTRL_CHECK(h->kvc.key_batch == ehs_batch && h->kvc.key_Lk == Lk, "adapter_forward: text K/V cache was kept for another batch / prompt length");
@@ -872,6 +882,7 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
     h->arena.off = 0;
     Ctx cx{&h->arena, s, false};
     cx.f32stream = dry.f32stream;
+    cx.h1_f16 = dry.h1_f16;
     cx.stats_total = dry.stats_total;
     cx.kvc = &h->kvc; h->kvc.next = 0;
     cx.capturing = capturing;

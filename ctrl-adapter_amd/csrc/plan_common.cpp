@@ -120,7 +120,7 @@ int run_resnet(Ctx& cx, const ResnetW& w, const TV& x, const TV& out, int N, int
     half_t* a = cx.h((size_t)N * H * W * w.conv1.Cin);          // 2 x Cin wide for a split-operand conv1
     TRY(run_groupnorm(cx, w.norm1, x, a, N, H * W, eps, true, w.conv1.dup));
     // conv1 output feeds only GroupNorm: keep it in the stream dtype (its statistics are taken from this copy)
-    TV h1 = stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
+    TV h1 = cx.h1_f16 ? tv16(cx.h((size_t)N * Ho * Wo * w.Cout)) : stream_alloc(cx, (size_t)N * Ho * Wo * w.Cout, false);
     ConvOpts o1; o1.up = up; o1.rowvec = temb_proj; o1.rowvec_ld = temb_ld;
     TRY(run_conv(cx, w.conv1, a, h1, N, H, W, o1));
     half_t* b = cx.h((size_t)N * Ho * Wo * w.conv2.Cin);

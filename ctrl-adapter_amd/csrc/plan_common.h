@@ -328,6 +328,7 @@ struct Ctx {
     bool dry;
     bool f32stream = true;     // residual streams kept in fp32 (set from CTRL_STREAM_F32, default on)
     bool split = false;        // GEMM-operand mirrors of the streams are split [hi | lo] rows (ControlNet, CTRL_CN_SPLIT)
+    bool h1_f16 = false;       // a ResNet's conv1 output (read by GroupNorm only) in fp16 instead of the stream dtype (adapter, adapter_h1_f16())
     KvCache* kvc = nullptr;    // text K/V cache of the plan (mode OFF: not used)
     bool capturing = false;    // the forward is being recorded into a hipGraph (no allocation may happen)
     // pooled GroupNorm statistics (zeroed once per forward with a single memset)
@@ -395,6 +396,19 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
 inline bool stream_f32_enabled() {
     const char* e = getenv("CTRL_STREAM_F32");
     return !(e && e[0] == '0');
+}
+
+// the adapter's spatial-transformer token stream in fp16 (default since round 4; CTRL_ADAPTER_TOK_F16=0: fp32 like the ControlNet's
+// and the temporal streams, which stay fp32)
+inline bool adapter_tok_f16() {
+    const char* e = getenv("CTRL_ADAPTER_TOK_F16");
+    return !(e && e[0] == '0');
+}
+
+// the adapter ResNets' conv1 -> GroupNorm intermediate in fp16 (CTRL_ADAPTER_H1_F16=1)
+inline bool adapter_h1_f16() {
+    const char* e = getenv("CTRL_ADAPTER_H1_F16");
+    return e && e[0] == '1';
 }
 
 // ------------------------------------------------------------------------------------------ tensor views

@@ -20,6 +20,9 @@ def kernel_class(name):
         re.search(r"igemm_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)      # demangled or mangled
     if m:
         return {"0": "igemm_rows", "1": "igemm_conv", "2": "igemm_temporal"}[m.group(1)]
+    m = re.search(r"igemm8_kernel<\s*\d+,\s*(\d+)>", name) or re.search(r"igemm8_kernelILi\d+ELi(\d+)E", name)      # round 4's wide tile: <NI, MODE>
+    if m:
+        return {"0": "igemm_rows", "1": "igemm_conv", "2": "igemm_temporal"}[m.group(1)]
     for key in ("splitk_finish", "flash_attn", "temporal_attn", "gn_stats", "gn_apply", "layernorm", "conv3x3_direct",
                 "linear_small", "nchw_to_nhwc", "nhwc_to_nchw", "avgpool", "sincos", "blend", "add_rowvec", "merge"):
         if key in name:
@@ -35,6 +38,9 @@ def symbol_of(name):
         tf = lambda v: "true" if v == "1" else "false"
         # (9th argument: round 2's last build = persistent-workgroup form, round 3 = fused GroupNorm partial sums; older traces lack it)
         return "igemm_kernel<%s, %s, %s, %s, %s, %s, %s, %s%s>" % (g[:7] + (tf(g[7]), ", " + tf(g[8]) if g[8] is not None else ""))
+    m = re.search(r"igemm8_kernelILi(\d+)ELi(\d+)E", name)
+    if m:
+        return "igemm8_kernel<%s, %s>" % m.groups()
     m = re.search(r"flash_attn_d64_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         return "flash_attn_d64_kernel<%s, %s, %s, %s>" % m.groups()
@@ -45,7 +51,7 @@ def symbol_of(name):
     if m:
         tf = lambda v: "true" if v == "1" else "false"
         return "flash_attn_kernel<%s, %s, %s, %s>" % (m.group(1), m.group(2), tf(m.group(3)), tf(m.group(4)))
-    m = re.search(r"((?:igemm|flash_attn|flash_attn_d64|flash_attn_d64p)_kernel<[^>]*>)", name)
+    m = re.search(r"((?:igemm8|igemm|flash_attn|flash_attn_d64|flash_attn_d64p)_kernel<[^>]*>)", name)
     if m:
         return re.sub(r",\s*", ", ", m.group(1))
     m = re.search(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+_kernel)", name) or re.search(r"([a-z0-9_]+_kernel)", name)

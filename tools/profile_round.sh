@@ -1,24 +1,23 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r03 v1 [1 = also write the pytest parity logs (adds ~15 minutes)]
+#   bash tools/profile_round.sh r04 v1 [1 = also write the pytest parity logs (adds ~13 minutes; they run LAST)]
 # Writes under gpurun_out/final/; copy what should be judged into profiles/.  ~8 minutes of box time without the tests.
 set -u
-R=${1:-r03}; V=${2:-v1}; TESTS=${3:-0}
+R=${1:-r04}; V=${2:-v1}; TESTS=${3:-0}
 O=gpurun_out/final; mkdir -p $O
 export TMPDIR=/tmp
-if [ "$TESTS" = "1" ]; then
-(python -m pytest tests/test_gpu_ops.py tests/test_image_prep.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_op_parity_${V}.log
-(python -m pytest tests/test_gpu_e2e.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_e2e_parity_${V}.log
-fi
+if [ "${ONLY_TRACES:-0}" != "1" ]; then      # ONLY_TRACES=1: just the rocprofv3 passes below
 python -c "import __graft_entry__ as g; g.smoke()" > $O/${R}_smoke_${V}.log 2>&1
 # the headline exactly as the driver runs it, then the other BASELINE configurations (no CPU leg: it is the slow part)
-python bench.py --per-kernel-out $O/${R}_per_kernel_${V}.json > $O/${R}_bench_${V}.json 2> $O/bench.err
+python bench.py --per-kernel-out $O/${R}_per_kernel_${V}.json > $O/${R}_bench_${V}.json 2> $O/bench.err      # (carries other_workloads: svd16, i2vgen16, multi3, sdxl b16)
 python bench.py --workload svd16 --steps 10 --warmup 3 --no-cpu-baseline --per-kernel-out $O/${R}_per_kernel_svd16_${V}.json > $O/${R}_bench_svd16_${V}.json 2>> $O/bench.err
 python bench.py --workload i2vgen16 --steps 10 --warmup 3 --no-cpu-baseline --per-kernel-out $O/${R}_per_kernel_i2vgen16_${V}.json > $O/${R}_bench_i2vgen16_${V}.json 2>> $O/bench.err
 python bench.py --workload multi3 --steps 10 --warmup 3 --no-cpu-baseline --per-kernel-out $O/${R}_per_kernel_multi3_${V}.json > $O/${R}_bench_multi3_${V}.json 2>> $O/bench.err
 python bench.py --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --per-kernel-out $O/${R}_per_kernel_b16_${V}.json > $O/${R}_bench_b16_${V}.json 2>> $O/bench.err
-python bench.py --workload i2vgen16 --clip-split --steps 5 --warmup 2 --per-kernel-out $O/${R}_per_kernel_clip_${V}.json > $O/${R}_bench_clip_split_world1_${V}.json 2>> $O/bench.err
+python bench.py --workload i2vgen16 --clip-split --steps 5 --warmup 2 --no-cpu-baseline --per-kernel-out $O/${R}_per_kernel_clip_${V}.json > $O/${R}_bench_clip_split_world1_${V}.json 2>> $O/bench.err
+timeout 120 tools/bin/gemm_order_bench $O/${R}_gemm_path_shapes_${V}.txt shapes > /dev/null 2>&1
 timeout 120 tools/bin/attn_bench $O/${R}_attention_variants_${V}.txt > /dev/null 2>&1
+fi
 # per-kernel time of the same command (its own run: no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 --per-kernel-out $O/tmp_pk.json > $O/stats.log 2>&1
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/${R}_rocprofv3_kernel_stats_${V}.csv
@@ -39,4 +38,10 @@ STEPS=$(grep -h avgpool $O/pmc_FETCH_SIZE/*/*counter_collection.csv | wc -l)
 python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $STEPS $O/${R}_pmc_hbm_traffic_${V}.json $O/${R}_launches_${V}.tsv
 rm -f $O/stats/*/*kernel_trace.csv $O/tmp_pk.json
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/stats $O/stats_lanes_off
-tail -n 2 $O/${R}_smoke_${V}.log; tail -c 1500 $O/${R}_bench_${V}.json
+tail -n 2 $O/${R}_smoke_${V}.log; tail -c 600 $O/${R}_bench_${V}.json
+# the parity logs last: a budget cut must not cost the measurements above
+if [ "$TESTS" = "1" ]; then
+(python -m pytest tests/test_gpu_ops.py tests/test_image_prep.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_op_parity_${V}.log
+(python -m pytest tests/test_gpu_e2e.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_e2e_parity_${V}.log
+fi
+
