@@ -1543,6 +1543,11 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
         const bool f32_stream = a.seg[0].dtype == DT_F32 || (a.res && a.res_f32);      // fp32 rows written and / or read per element
         if (a.geglu) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
         if (f32_stream && a.Ktot <= 1024) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
+        // fp16 stream updates (the adapter's token stream since round 4) with a k-loop of <= 8 k-tiles: the residual read + store of
+        // the epilogue still outweighs the loop -- M131072 N512 K320 + residual: 0.164 ms (8-phase) vs 0.128 ms (this pair tile),
+        // -0.12 ms per SDXL step, -0.27 ms fused (one call, gpurun_out/r4p); CTRL_SHORTK_PAIR=0 switches it off
+        static const bool pair16 = !(getenv("CTRL_SHORTK_PAIR") && getenv("CTRL_SHORTK_PAIR")[0] == '0');
+        if (pair16 && a.res && a.Ktot <= 512) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
     }
     // the 8-phase wide tiles wherever the grid fills the chip with them (1.3-1.5x the BK = 32 ring kernel on plain epilogues and
     // long k-loops: convolutions 543 -> 671 TFLOP/s as a class)
