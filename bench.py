@@ -433,9 +433,9 @@ def main():
                   "what": "HIP step (these plans, these %d distinct inputs) vs fp32 oracle -> oracle chain" % n}
 
     # ---- the other north-star workloads (BASELINE configs 3, 4, 5 and the CFG-doubled SDXL batch), after the headline's timed
-    #      region, default invocation only: `other_workloads` of the headline ----
+    #      region, the default single-GPU invocation only (the N > 1 scaling runs stay short): `other_workloads` of the headline ----
     others = None
-    if args.workload == "sdxl" and args.batch == 8 and comm is None and not args.no_graph and not args.fused and not args.no_other_workloads:
+    if args.workload == "sdxl" and args.batch == 8 and world == 1 and comm is None and not args.no_graph and not args.fused and not args.no_other_workloads:
         others = {}
         for name, wn, b in (("svd16", "svd16", 0), ("i2vgen16", "i2vgen16", 0), ("multi3", "multi3", 0), ("sdxl_b16", "sdxl", 16)):
             try:
