@@ -161,7 +161,7 @@ def quick_time(dev, wname, batch, steps, warmup, world):
     el = dp.timed_region(graph.replay, steps, device=dev)
     ms = el / steps * 1e3
     fl = step_flops(w, n)
-    res = {"value": round(dp.aggregate_throughput(1, steps, el, world), 3), "unit": "denoise-steps/s", "ms_per_step": round(ms, 3),
+    res = {"value": round(dp.aggregate_throughput(1, steps, el, world), 3), "ms_per_step": round(ms, 3),      # (unit: the headline's)
            "mfma_frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "baseline_config": w["config"], "batch_per_gpu": n, "steps": steps}
     del graph, keep, cns, ad, router, x
     torch.cuda.synchronize()
@@ -413,8 +413,7 @@ def main():
         (od, om), (oad, oam) = cpu_step()
         per_step = time.perf_counter() - c0
         cpu = {"value": round(1.0 / per_step, 5), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-               "note": "port = oracle/ (fp32 PyTorch restatement); live-checked bit-identical to the reference's own files on 64 random "
-                       "configurations (tests/golden/live_check.py) -- /root/reference does not exist on the GPU box",
+               "note": "oracle/ = fp32 restatement, live-checked bit-identical to the reference's files (tests/golden/live_check.py)",
                "sample": "one pass over the whole step of this workload (N=%d, the timed inputs), fp32 PyTorch oracle on %d "
                          "threads: %.2f s" % (n, cores, per_step)}
         ref_out = list(od) + [om] + list(oad) + ([oam] if oam is not None else [])

@@ -1529,10 +1529,6 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
             if (!strcmp(f, "4w128x256")) return launch_cfg2<128, 256, 32, 1, 4, 3, MODE, true>(a, s);
         }
     }
-    // Epilogue-heavy token GEMMs at large M (measured, tools/tile_experiment.py -> profiles/r02_tile_experiment.log): two
-    // resident workgroups per CU let one's epilogue -- the GEGLU math, or the HBM-bound fp32 residual read + fp32 master +
-    // fp16 mirror write of a stream update -- run under the other's k-loop.  GEGLU 512->4096 at M = 131072: 562 -> 677
-    // TFLOP/s (256x128); stream updates K = 320: 182 -> 217 (128x256), K = 2048: 551 -> 603 (256x128).
     // Epilogue-heavy token GEMMs at large M with a SHORT k-loop (measured, tools/tile_experiment.py -> profiles/r02_tile_experiment.log,
     // re-measured against the 8-phase kernel in round 4, profiles/r04_step_old_vs_8phase.txt): two resident workgroups per CU let
     // one's epilogue -- the GEGLU math, or the HBM-bound fp32 residual read + fp32 master + fp16 mirror write of a stream update --

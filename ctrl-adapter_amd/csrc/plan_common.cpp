@@ -303,8 +303,8 @@ int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, 
         TRY(run_layernorm(cx, w.norm1, X, xb, M, dim));
         xn = xb;
     }
-    // every LayerNorm of the block is handed to the GEMM that produces its input (run_linear: fused into that epilogue for
-    // 512-wide fp32 rows, the stand-alone kernel otherwise)
+    // every LayerNorm of the block is handed to the GEMM that produces its input (run_linear runs the stand-alone kernel right behind
+    // it; the fused-epilogue form of round 3 lost and was removed)
     half_t* xn2 = cx.h((size_t)M * dim);        // LayerNorm(norm2)(x1), then re-used for LayerNorm(norm3)(x2)
     TV x2 = stream_alloc(cx, (size_t)M * dim, false);
     if (e.Lk == 1) {
