@@ -41,7 +41,9 @@ static void say(const char* fmt, ...) {
 }
 
 // random fp16 bit patterns with magnitudes in [2^-6, 1): sign | exponent 9..14 | mantissa
+// (GEMM_BENCH_ZERO=1: all-zero operands instead -- the data dependence of the matrix rate, i.e. how far a kernel is power-limited)
 static void fill_half(std::vector<uint16_t>& v, uint64_t seed) {
+    if (const char* z = getenv("GEMM_BENCH_ZERO")) if (z[0] == '1') { std::fill(v.begin(), v.end(), (uint16_t)0); return; }
     uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
     for (size_t i = 0; i < v.size(); ++i) {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
