@@ -4,7 +4,7 @@
 #include "plan_common.h"
 
 // ------------------------------------------------------------------------------------------ builders
-int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w, bool dup) {
+int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w, bool dup, int dup_shortcut) {
     w->Cin = Cin; w->Cout = Cout;
     TRY(ps.norm(pre + ".norm1", Cin, &w->norm1));
     TRY(ps.conv(pre + ".conv1", Cout, Cin, 3, false, &w->conv1, dup));
@@ -12,7 +12,7 @@ int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool 
     TRY(ps.norm(pre + ".norm2", Cout, &w->norm2));
     TRY(ps.conv(pre + ".conv2", Cout, Cout, 3, false, &w->conv2, dup));
     w->has_shortcut = force_shortcut || (Cin != Cout);
-    if (w->has_shortcut) TRY(ps.conv(pre + ".conv_shortcut", Cout, Cin, 1, false, &w->shortcut, dup));
+    if (w->has_shortcut) TRY(ps.conv(pre + ".conv_shortcut", Cout, Cin, 1, false, &w->shortcut, dup_shortcut < 0 ? dup : dup_shortcut != 0));
     return 0;
 }
 

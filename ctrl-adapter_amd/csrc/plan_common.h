@@ -386,7 +386,8 @@ struct TemporalTBW {        // TemporalBasicTransformerBlock
     int dim = 0, cross = 0;
 };
 
-int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w, bool dup = false);
+// dup: split [hi | lo] operands for conv1 / conv2; dup_shortcut: the same for the 1x1 shortcut (-1 = as dup)
+int build_resnet(ParamSink& ps, const std::string& pre, int Cin, int Cout, bool force_shortcut, ResnetW* w, bool dup = false, int dup_shortcut = -1);
 int build_attn_self(ParamSink& ps, const std::string& pre, int dim, int heads, int D, AttnW* w);
 int build_attn_cross(ParamSink& ps, const std::string& pre, int dim, int cross, int heads, int D, AttnW* w);
 int build_basic_tb(ParamSink& ps, const std::string& pre, int dim, int heads, int D, int cross, BasicTBW* w);

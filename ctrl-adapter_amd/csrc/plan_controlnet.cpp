@@ -59,6 +59,18 @@ int cn_split_levels() {
     const int v = e ? atoi(e) : 3;
     return v < 0 ? 0 : (v > 5 ? 5 : v);
 }
+// The same depth for the ResNets' 3x3 convolutions alone (CTRL_CN_SPLIT_RESNET_LEVELS, default = CTRL_CN_SPLIT_LEVELS): the CPU emulation
+// per conv kind (tools/experiments/split_per_conv.py, round 4) says the 3x3 convolutions of the 640- and 1280-channel levels can take plain
+// operands at unchanged ControlNet / chain errors (6.2e-4 / 7.6e-4 against 6.8e-4 / 7.1e-4) while the 1x1 shortcuts, proj_in / proj_out,
+// down-samplers and zero-convs cannot; "1" would halve the matrix work of 12 of the most expensive split launches.  Opt-in until a full
+// GPU parity run has seen it (the SVD-16 chain has 0.8e-4 of headroom).
+int cn_split_resnet_levels() {
+    const char* e = getenv("CTRL_CN_SPLIT_RESNET_LEVELS");
+    const int lv = cn_split_levels();
+    if (!e) return lv;
+    const int v = atoi(e);
+    return v < 0 ? 0 : (v > lv ? lv : v);
+}
 // CTRL_CN_SPLIT=dup: the first form of the split (weights packed twice, [hi | lo] walked as one long K) for A/B runs
 bool cn_split_paired() {
     const char* e = getenv("CTRL_CN_SPLIT");
@@ -124,9 +136,9 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
 
     std::vector<std::string> temb_names;
     std::vector<int> temb_ns;
-    const int levels = cn_split_levels();
-    auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r, bool dup_r) -> int {
-        TRY(build_resnet(ps, pre, Cin, Cout, false, r, dup_r));
+    const int levels = cn_split_levels(), res_levels = cn_split_resnet_levels();
+    auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r, bool dup_r, int dup_sc = -1) -> int {
+        TRY(build_resnet(ps, pre, Cin, Cout, false, r, dup_r, dup_sc));
         r->temb_off = w->temb_total;
         w->temb_total += Cout;
         temb_names.push_back(pre + ".time_emb_proj");
@@ -146,7 +158,7 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
                           d.proj_out.resize(c.layers_per_block); d.tb.resize(c.layers_per_block); }
         const bool dup_i = dup && i < levels;
         for (int j = 0; j < c.layers_per_block; ++j) {
-            TRY(add_resnet(pre + ".resnets." + std::to_string(j), j == 0 ? d.Cin : d.Cout, d.Cout, &d.resnets[j], dup_i));
+            TRY(add_resnet(pre + ".resnets." + std::to_string(j), j == 0 ? d.Cin : d.Cout, d.Cout, &d.resnets[j], dup && i < res_levels, dup_i ? 1 : 0));
             if (d.has_attn)
                 TRY(build_transformer2d(ps, pre + ".attentions." + std::to_string(j), d.Cout, c.num_attention_heads,
                                         c.cross_attention_dim, &d.tnorm[j], &d.proj_in[j], &d.proj_out[j], &d.tb[j], dup_i));
