@@ -185,6 +185,22 @@ def pmc_traffic_for(kernel_row):
     return None, None
 
 
+def pmc_total_for(workload):
+    """whole-step HBM bytes (corrected FETCH_SIZE x 2 + WRITE_SIZE) from the newest committed PMC file of this workload (the sdxl
+    headline: profiles/rNN_pmc_hbm_traffic_vK.json; counters cannot be collected inside the bench)"""
+    if workload != "sdxl":
+        return None, None
+    for tfile in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_v*.json")))):
+        try:
+            with open(tfile) as fh:
+                tot = json.load(fh).get("total_hbm_bytes_per_step_corrected")
+        except Exception:
+            continue
+        if tot:
+            return round(tot / 1e9, 2), os.path.basename(tfile)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,10 +229,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CTRL_BENCH_MARKER_DIR"):      # tests/test_dist.py: proof that this rank was started (written before anything can fail)
+        with open(os.path.join(os.environ["CTRL_BENCH_MARKER_DIR"], "rank%d_of_%d" % (rank, world)), "w") as fh:
+            fh.write(os.environ.get("MASTER_ADDR", "") + "\n")
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
     if args.gpus != world:
@@ -313,6 +332,18 @@ def main():
     value = dp.aggregate_throughput(1, args.steps, elapsed, world)   # whole-job denoise-steps/s (each rank: its own batch / clip)
     if comm is not None:
         value = args.steps / elapsed                                 # ONE clip for the whole job: strong scaling
+    # the median over single steps ("median of >= 20"), taken AFTER the timed region with an event pair per step on
+    # the launch stream; reported beside the contract's mean-of-K `ms_per_step`, never instead of it
+    median_ms = None
+    if rank == 0 and comm is None:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 20))]
+        for e0, e1 in evs:
+            e0.record()
+            run()
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        median_ms = round(ts[len(ts) // 2], 3)
 
     # ---- the same step through the fused entry point (ControlNet on its own stream, adapter blocks start when their input
     #      exists): same arithmetic, bit-identical results; reported beside the headline, never as `value` ----
@@ -392,7 +423,8 @@ def main():
         hip_out = [("controlnet.down%d" % i, v.float().cpu()) for i, v in enumerate(hd)] + [("controlnet.mid", hm.float().cpu())] + \
                   [("adapter.down%d" % i, v.float().cpu()) for i, v in enumerate(ha)] + \
                   ([("adapter.mid", ham.float().cpu())] if ham is not None else [])
-        cores = min(os.cpu_count() or 1, 32)        # more threads than this slow the fp32 oracle down (NUMA / oversubscription)
+        box_cores = os.cpu_count() or 1
+        cores = min(box_cores, 32)                  # more threads than this slow the fp32 oracle down (NUMA / oversubscription)
         torch.set_num_threads(cores)
         ocs = [seeded_init(ControlNetOracle(cross_attention_dim=768).eval(), seed=11 + 100 * k) for k in range(w["n_cn"])]
         oa = seeded_init(ControlNetAdapterOracle(**w["adapter"]).eval(), seed=22)
@@ -412,10 +444,10 @@ def main():
         c0 = time.perf_counter()
         (od, om), (oad, oam) = cpu_step()
         per_step = time.perf_counter() - c0
-        cpu = {"value": round(1.0 / per_step, 5), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(1.0 / per_step, 5), "unit": "denoise-steps/s", "cores": cores, "box_cores": box_cores, "kind": "port",
                "note": "oracle/ = fp32 restatement, live-checked bit-identical to the reference's files (tests/golden/live_check.py)",
                "sample": "one pass over the whole step of this workload (N=%d, the timed inputs), fp32 PyTorch oracle on %d "
-                         "threads: %.2f s" % (n, cores, per_step)}
+                         "threads (the box has %d logical cores): %.2f s" % (n, cores, box_cores, per_step)}
         ref_out = list(od) + [om] + list(oad) + ([oam] if oam is not None else [])
         worst, worst_name, zeros_ok, ntens = 0.0, None, True, 0
         for (name, a), b in zip(hip_out, ref_out):
@@ -454,9 +486,11 @@ def main():
             except OSError as e:
                 print("bench: per-kernel table not written (%s)" % e, file=sys.stderr)
         top = [{"kernel": r["kernel"][:96], "ms_per_step": r["ms_per_step"], "frac": r["frac"]} for r in per_kernel[1:4]]
+        launches = int(round(sum(v["launches_per_step"] for v in kernels.values()))) if kernels else None
+        hbm_gb, hbm_src = pmc_total_for(args.workload) if args.batch == 8 and comm is None else (None, None)
         line = {
             "metric": w["metric"], "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": median_ms, "higher_is_better": True,
             "scaling": "strong" if comm is not None else "weak",
             "vs_baseline": None,
             "dtype": "f16",    # MFMA operands fp16; fp32 accumulate / statistics / softmax / residual streams
@@ -469,6 +503,8 @@ def main():
                        "launch": mode, "call_form": "controlnet(...) ; adapter(...)" if not args.fused else "controlled_step(...)"},
             "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
             "mfma_frac_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "launches_per_step": launches,        # kernel launches of one step (HIP-event leg: eager, lanes off)
+            "hbm_gb_per_step": hbm_gb, "hbm_gb_source": hbm_src,      # PMC counters of the committed profile run of this workload
             "fused_step": fused, "roofline": roof, "cpu_baseline": cpu, "parity_at_bench_config": parity, "other_workloads": others,
             "next_kernels": top, "per_kernel_file": os.path.basename(args.per_kernel_out) if (kernels or per_kernel) else None,
         }

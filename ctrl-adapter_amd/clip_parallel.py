@@ -165,9 +165,12 @@ class RcclTransport(ClipTransport):
     (None = the default group; any backend) -- used once, to broadcast the communicator ids from the group's rank 0.  With world == 1
     and no process group at all pass rank=0, world=1.
     lanes: communicators (each with its own exchange workspace) chained through ctrl_clip_comm::next_lane -- the adapter runs its four
-    pyramid levels on four HIP streams and lane l exchanges on communicator l; lanes=1 keeps the whole forward on the caller's stream."""
+    pyramid levels on four HIP streams and lane l exchanges on communicator l; lanes=1 (the default) keeps the whole forward on the
+    caller's stream.  Several lanes are an opt-in: collectives of different communicators issued from different streams are not
+    guaranteed to co-run, so a multi-GPU job should soak-test lanes > 1 before relying on it (only world 1 has run on hardware); under
+    hipGraph capture the forward uses one lane whatever the chain length (RCCL refuses a second communicator inside one capture)."""
 
-    def __init__(self, group=None, device=None, rank=None, world=None, lanes=4):
+    def __init__(self, group=None, device=None, rank=None, world=None, lanes=1):
         import torch.distributed as dist
         if rank is None:
             rank, world = dist.get_rank(group), dist.get_world_size(group)

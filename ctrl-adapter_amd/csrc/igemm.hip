@@ -1238,6 +1238,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmArgs a, const f
 #pragma unroll
             for (int j = 0; j < 8; ++j) ((u16*)sg.out)[o + j] = f32_to_bf16(x[j]);
         }
+        if (a.nonfinite && (a.out16 != nullptr || sg.dtype == DT_F16)) {      // range check (ctrl_igemm_desc::nonfinite), as the GEMM epilogues
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bad = bad || out_of_half(x[j]);
+            if (bad) *(volatile int32_t*)a.nonfinite = 1;
+        }
         if (a.out16) {
             h8 pk;
 #pragma unroll
@@ -1473,6 +1479,7 @@ size_t igemm_splitk_ws_bytes(const IGemmArgs& a, int sk) {
     const size_t rows = (size_t)sk * a.M * a.Nout * sizeof(float);
     const int bn = (a.Nout % 320 == 0) ? 320 : 256;
     const size_t tiles = (size_t)((a.M + 255) / 256) * ((a.Nout + bn - 1) / bn);
+    if (sk > 4) return rows;                     // the in-launch reduction serves 2..4 splits only
     const size_t frag = (tiles * sk * 256 * bn * sizeof(float) + 255) / 256 * 256 + tiles * sizeof(int);
     return rows > frag ? rows : frag;
 }
@@ -1482,16 +1489,19 @@ int igemm_splitk_factor(const IGemmArgs& a) {
     const int bn = (a.Nout % 320 == 0) ? 320 : 256;
     if (a.Nout % bn != 0) return 1;
     const long tiles = (long)((a.M + 255) / 256) * (a.Nout / bn);
-    const int nk = a.Ktot / 32;
-    if (tiles >= 160 || nk < 64) return 1;
+    const int nk32 = a.Ktot / 32;
+    if (tiles >= 160 || nk32 < 64) return 1;
     int sk = (int)((256 + tiles - 1) / tiles);
     if (sk > 16) sk = 16;
-    while (sk > 1 && nk / sk < 16) --sk;
-    // paired split-operand walk: a split covers an EVEN number of k-tiles (a (hi, lo) pair is never cut), so the per-split
-    // count is rounded up to even -- pick sk such that the last split still has work (with nk = 360, sk = 16 the
-    // rounded count 24 left split 15 empty: idle workgroups writing an all-zero slab the finish kernel still read)
-    if (a.a_split == 2)
-        while (sk > 1 && (long)(sk - 1) * ((((nk + sk - 1) / sk) + 1) & ~1) >= nk) --sk;
+    while (sk > 1 && nk32 / sk < 16) --sk;
+    // The kernels give split s the k-tiles [s * per, (s + 1) * per) with per = ceil(nk / sk) -- rounded up to even for the paired
+    // split-operand walk, which never cuts a (hi, lo) pair -- in THEIR k-tile depth: 64 for the 8-phase kernel, 32 for the ring kernel.
+    // Pick sk such that the last split still has work in the depth of the kernel that will run (640 -> 640 3x3 at 24
+    // tiles: nk64 = 90, sk = 11, per = 9 left split 10 empty -- an idle workgroup whose prologue DMA started at k = Ktot)
+    const int depth = can_use8(a) ? 64 : 32;
+    const int nk = a.Ktot / depth;
+    auto per_of = [&](int f) { int p = (nk + f - 1) / f; if (a.a_split == 2) p = (p + 1) & ~1; return p; };
+    while (sk > 1 && (long)(sk - 1) * per_of(sk) >= nk) --sk;
     return sk;
 }
 namespace {
@@ -1573,6 +1583,7 @@ int op_igemm(const IGemmArgs& a, hipStream_t s) {
     if (!a.nonfinite && range_check_on()) {          // debug aid: every fp16 value the epilogue writes is tested for inf / nan
         IGemmArgs b = a;
         b.nonfinite = range_flag();
+        CTRL_CHECK(b.nonfinite != nullptr, "igemm: the range check is on but its flag word could not be allocated");
         return op_igemm_checked(b, s);
     }
     return op_igemm_checked(a, s);
@@ -1597,6 +1608,16 @@ static int op_igemm_checked(const IGemmArgs& a, hipStream_t s) {
     for (int i = 0; i < a.nseg; ++i) {
         CTRL_CHECK(a.seg[i].col_begin % 16 == 0, "igemm: segment boundary must be a multiple of 16");
         CTRL_CHECK(a.seg[i].out != nullptr, "igemm: null segment output");
+    }
+    if (can_swap(a)) {
+        // the vector epilogue addresses every row-major operand with 32-bit unsigned ELEMENT offsets off a scalar base (igemm_epilogue:
+        // res_fetch8, the piece stores, the blend operand, the fp16 mirror): each of them must span < 2^32 elements
+        const double lim = 4294967296.0, M = (double)a.M;
+        for (int i = 0; i < a.nseg; ++i)
+            CTRL_CHECK(a.seg[i].fmt != SEG_ROW || M * (double)a.seg[i].ld < lim, "igemm: a row-major output spans 2^32 elements or more");
+        CTRL_CHECK(!a.res || M * (double)a.ldres < lim, "igemm: the residual operand spans 2^32 elements or more");
+        CTRL_CHECK(!a.out16 || M * (double)a.ld16 + (double)a.out16_lo_off < lim, "igemm: the fp16 mirror spans 2^32 elements or more");
+        CTRL_CHECK(!a.blend_mix || M * (double)a.ld_blend < lim, "igemm: the blend operand spans 2^32 elements or more");
     }
     if (a.mode == IG_CONV2D) {
         CTRL_CHECK(a.taps == 9 || a.taps == 1, "igemm conv2d: taps must be 1 or 9");

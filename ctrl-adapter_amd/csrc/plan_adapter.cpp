@@ -859,7 +859,11 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
         CTRL_CHECK(comm_lanes <= (int)ctrl_adapter::kLanes, "clip_sharded: transport chain longer than the lanes there are (or cyclic)");
     }
     const int want_lanes = std::min(std::max(env_lanes, 1), (int)ctrl_adapter::kLanes);
-    const int nlanes = g_prof_on ? 1 : (comm ? std::min(want_lanes, std::min(comm_lanes, (int)ctrl_adapter::kLevelLanes)) : want_lanes);
+    // Under stream capture a frame-sharded forward stays on ONE lane: RCCL refuses a second communicator on a forked stream inside
+    // one capture (hipErrorStreamCaptureUnsupported), and that error would arrive mid-capture, after the lanes are forked, leaving
+    // unjoined streams behind an invalidated capture.  Eager calls use the chain the caller passed.
+    const int comm_use = capturing ? 1 : std::min(comm_lanes, (int)ctrl_adapter::kLevelLanes);
+    const int nlanes = g_prof_on ? 1 : (comm ? std::min(want_lanes, comm_use) : want_lanes);
     size_t ws_peak = 0;
     AdapterCall k = {ins, in_dtype, N, H0, W0, num_frames, timesteps, t_count, encoder_hidden_states, ehs_dtype,
                      ehs_batch, Lk, outs, out_dtype, map_dev, frame_pos, N_out, h, nlanes, in_ev, comm, &ws_peak};

@@ -62,13 +62,12 @@ int cn_split_levels() {
 // The same depth for the ResNets' 3x3 convolutions alone (CTRL_CN_SPLIT_RESNET_LEVELS, default = CTRL_CN_SPLIT_LEVELS): the CPU emulation
 // per conv kind (tools/experiments/split_per_conv.py, round 4) says the 3x3 convolutions of the 640- and 1280-channel levels can take plain
 // operands at unchanged ControlNet / chain errors (6.2e-4 / 7.6e-4 against 6.8e-4 / 7.1e-4) while the 1x1 shortcuts, proj_in / proj_out,
-// down-samplers and zero-convs cannot; "1" would halve the matrix work of 12 of the most expensive split launches.  Opt-in until a full
-// GPU parity run has seen it (the SVD-16 chain has 0.8e-4 of headroom).
+// down-samplers and zero-convs cannot; "1" halves the matrix work of 12 of the most expensive split launches.  Default 1 since round 5
+// (the full GPU suite ran with it: profiles/r05_*; CTRL_CN_SPLIT_RESNET_LEVELS=3 restores the round-4 selection).
 int cn_split_resnet_levels() {
     const char* e = getenv("CTRL_CN_SPLIT_RESNET_LEVELS");
     const int lv = cn_split_levels();
-    if (!e) return lv;
-    const int v = atoi(e);
+    const int v = e ? atoi(e) : 1;
     return v < 0 ? 0 : (v > lv ? lv : v);
 }
 // CTRL_CN_SPLIT=dup: the first form of the split (weights packed twice, [hi | lo] walked as one long K) for A/B runs

@@ -44,6 +44,9 @@ int* range_flag() {
 }
 extern "C" int ctrl_range_check(int on) {
     if (on == 0 || on == 1) g_range_on = on;
+    // the flag word is allocated HERE, eagerly (its first use may otherwise fall inside a stream capture, where hipMalloc / hipMemset
+    // are illegal); -1: switched on but the flag could not be allocated -- op_igemm then fails loudly instead of checking nothing
+    if (range_check_on() && !range_flag()) return -1;
     return range_check_on() ? 1 : 0;
 }
 extern "C" int ctrl_range_status(int reset) {
@@ -51,6 +54,7 @@ extern "C" int ctrl_range_status(int reset) {
     int* f = range_flag();
     if (!f) return 2;
     int v = 0;
+    // (synchronises the device: not to be called while a stream capture is in progress -- include/ctrl_hip.h says so)
     if (hipDeviceSynchronize() != hipSuccess) return 2;
     if (hipMemcpy(&v, f, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 2;
     if (v && reset) (void)hipMemset(f, 0, sizeof(int));

@@ -14,7 +14,11 @@ import torch
 
 
 @torch.no_grad()
-def seeded_init(module, seed=1234, fp16_round=True):
+def seeded_init(module, seed=1234, fp16_round=True, gain=1.0, dist="normal", gamma_outliers=0.0, gamma_outlier_scale=8.0):
+    """gain / dist / gamma_outliers: the weight-distribution sweep of tests/test_gpu_e2e.py (a trained checkpoint has heavier tails and
+    outlier channels than unit-gain Gaussians): `gain` multiplies the standard deviation of every >= 2-D weight; dist="student4" draws
+    them from a Student-t with 4 degrees of freedom scaled to the same variance; `gamma_outliers` = fraction of the channels of every
+    normalisation scale (GroupNorm and LayerNorm weights alike) that is multiplied by gamma_outlier_scale."""
     for name, p in module.named_parameters():
         g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ seed) & 0x7FFFFFFF)
         leaf = name.rsplit(".", 1)[-1]
@@ -24,9 +28,19 @@ def seeded_init(module, seed=1234, fp16_round=True):
             v = torch.randn(p.shape, generator=g)
         elif p.dim() >= 2:
             fan_in = p[0].numel()
-            v = torch.randn(p.shape, generator=g) / fan_in ** 0.5
+            if dist == "student4":
+                # t_4 = z / sqrt(chi2_4 / 4), variance 4 / (4 - 2) = 2: divided by sqrt(2) to unit variance
+                z = torch.randn(p.shape, generator=g)
+                chi = torch.randn((4,) + tuple(p.shape), generator=g).pow(2).sum(0)
+                v = z / (chi / 4.0).sqrt() / 2.0 ** 0.5
+            else:
+                v = torch.randn(p.shape, generator=g)
+            v = v * (gain / fan_in ** 0.5)
         elif leaf == "weight":            # 1-D weight = GroupNorm / LayerNorm scale
             v = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
+            if gamma_outliers > 0.0:
+                pick = torch.rand(p.shape, generator=g) < gamma_outliers
+                v = torch.where(pick, v * gamma_outlier_scale, v)
         else:
             v = 0.1 * torch.randn(p.shape, generator=g)
         if fp16_round:

@@ -356,7 +356,8 @@ int ctrl_adapter_forward_clip_sharded(ctrl_adapter* h,
                                       ctrl_clip_comm* comm, void* stream);
 
 /* ---- The production transport, native: RCCL over xGMI, enqueued on the forward's stream from C++ (csrc/clip_rccl.cpp).  No host
- * callback into Python sits between launches, so ctrl_adapter_forward_clip_sharded is hipGraph-capturable with it.  RCCL is
+ * callback into Python sits between launches, so ctrl_adapter_forward_clip_sharded is hipGraph-capturable with it (under capture the
+ * forward uses the head of a next_lane chain only: RCCL refuses several communicators on forked streams inside one capture).  RCCL is
  * resolved at run time (dlopen; the copy already loaded into the process wins).  Rank 0 of the clip's group draws a unique id, the
  * caller ships its 128 bytes to the other ranks (any channel), every rank creates the communicator (collective), binds its
  * exchange workspace and passes the filled ctrl_clip_comm to the sharded forward. */

@@ -63,17 +63,23 @@ def test_shard_covers_everything():
             assert cover == list(range(total))
 
 
-def test_bench_launches_its_own_ranks():
+def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus N` without a launcher must start N ranks itself (it asserted on WORLD_SIZE).
-    There is no GPU here, so every rank stops at the loud no-GPU error -- which proves N ranks were launched with the
-    torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1) and that the parent relays their failure."""
+    There is no GPU here, so every rank stops at the loud no-GPU error.  That N ranks were launched with the torchrun
+    environment (RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1) is read from the marker file every rank writes first thing
+    (CTRL_BENCH_MARKER_DIR) -- not from the ranks' output: torchrun tears the sibling rank down as soon as the first one
+    fails, so how many of them get to print their error is a race."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CTRL_BENCH_MARKER_DIR"] = str(tmp_path)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
+    markers = sorted(f.name for f in tmp_path.iterdir())
+    assert markers == ["rank0_of_2", "rank1_of_2"], (markers, out[-2000:])
+    assert all((tmp_path / m).read_text().strip() == "127.0.0.1" for m in markers)
     import torch
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
         assert p.returncode == 0 and '"n_gpus": 2' in out, out[-2000:]
     else:
-        assert p.returncode != 0
-        assert out.count("bench.py needs a GPU") >= 2 or out.count("has no GPU") >= 1, out[-2000:]
+        assert p.returncode != 0                     # the parent relays the ranks' failure
+        assert out.count("bench.py needs a GPU") >= 1 or out.count("has no GPU") >= 1, out[-2000:]

@@ -936,3 +936,156 @@ def test_clip_sharded_adapter_over_native_rccl_two_gpus(P, gpu):
         assert not isinstance(worst, str), worst
         print("PARITY clip-sharded over native RCCL, 2 GPUs, rank %d vs unsharded rel_inf %.1e (%.1f MB sent)" % (rank, worst, sent / 1e6))
         assert worst <= 5e-4 and sent > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 5: the parts of the contract that were untested at shape (VERDICT r4 "missing" 3 / 4, "weak" 2)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _sdxl_cfg_pair_inputs(seed):
+    """what the SDXL pipeline hands the path for ONE image under classifier-free guidance (sdxl_controlnet_adapter_pipeline.py:1290-1343):
+    latents and condition image duplicated, prompt embeddings [negative, positive]"""
+    lat1 = seeded_tensor((1, 4, 128, 128), seed + 1)
+    cond1 = seeded_tensor((1, 3, 512, 512), seed + 3, kind="uniform")
+    return lat1.repeat(2, 1, 1, 1), seeded_tensor((2, 77, 768), seed + 2), cond1.repeat(2, 1, 1, 1), seeded_tensor((2, 77, 2048), seed + 4)
+
+
+def test_config1_cfg_pair_four_ddim_timesteps_at_shape_vs_oracle(P, controlnet, gpu):
+    """BASELINE.json config 1 at its real shape: 1 image 1024^2 under CFG (N = 2), the four DDIM timesteps of
+    inference_scripts/sdxl/sdxl_inference_depth.sh (999, 749, 499, 249) -- pool -> ControlNet -> adapter, every one of the
+    13 + 9 tensors of every step against the fp32 oracle -> oracle chain (the timestep only enters through the sinusoid
+    embeddings, fp32 on both sides: note N3)."""
+    from oracle.controlnet import ControlNetOracle
+    from oracle.adapter import ControlNetAdapterOracle
+    torch.set_grad_enabled(False)
+    lat, ehs_c, cond, ehs_a = _sdxl_cfg_pair_inputs(5100)
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+    oc = seeded_init(ControlNetOracle(**cases.CONTROLNET_KW).eval(), seed=11)
+    oa = seeded_init(ControlNetAdapterOracle(**cases.ADAPTER_SDXL).eval(), seed=22)
+    g = dict(lat=lat.half().to(gpu), ehs_c=ehs_c.half().to(gpu), cond=cond.half().to(gpu), ehs_a=ehs_a.half().to(gpu))
+    pooled = torch.nn.functional.adaptive_avg_pool2d(lat, (64, 64))
+    worst = {}
+    for tv in (999.0, 749.0, 499.0, 249.0):
+        t = torch.tensor(tv)
+        d, m = controlnet(P.pool_latents(g["lat"], (64, 64)), t, g["ehs_c"], g["cond"], return_dict=False)
+        o, om = ad(d, num_frames=1, timestep=t, encoder_hidden_states=g["ehs_a"])
+        assert om is None
+        rd, rm = oc(pooled, t, ehs_c, cond)
+        ro, _ = oa(rd, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+        e_cn = max(rel_inf(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm]))
+        e_chain = max(rel_inf(a, b) for a, b in zip(o[:9], ro[:9]))
+        worst[tv] = (e_cn, e_chain)
+        print("PARITY config-1 (N=2 CFG pair, 1024^2) t=%d controlnet %.2e chain %.2e" % (tv, e_cn, e_chain))
+        assert e_cn <= TOL and e_chain <= TOL_CHAIN, (tv, e_cn, e_chain)
+        for i in (9, 10, 11):
+            assert o[i].abs().max().item() == 0.0
+    # the four steps differ (the timestep reaches every ResNet): a constant output would pass the bounds above on one step only
+    assert len({round(v[1], 9) for v in worst.values()}) > 1
+
+
+def test_bf16_boundary_at_shape_vs_oracle(P, controlnet, gpu):
+    """The reference's run-time dtype at shape: the pipelines call the path under torch.autocast("cuda", bf16) with bf16 tensors in
+    and out (inference.py:207-232,499; sdxl_controlnet_adapter_pipeline.py:1339 casts the ControlNet features to adapter.dtype).
+    N = 2 CFG pair at the full SDXL shapes, every boundary tensor bf16 (values bf16-representable on both sides).
+    Bounds: a bf16 OUTPUT carries its own rounding, <= 2^-9 of its magnitude (8 significant bits, round to nearest), on top of the
+    path's 1e-3: 1e-3 + 2^-9 = 2.95e-3 asserted for the ControlNet outputs and for the adapter on IDENTICAL bf16 inputs; the path's own
+    error is shown separately by rounding the oracle's result to bf16 too (then only results that straddle a rounding boundary differ)."""
+    from oracle.controlnet import ControlNetOracle
+    from oracle.adapter import ControlNetAdapterOracle
+    torch.set_grad_enabled(False)
+    bf = torch.bfloat16
+    lat, ehs_c, cond, ehs_a = [x.to(bf).float() for x in _sdxl_cfg_pair_inputs(5200)]      # bf16-representable inputs
+    t = torch.tensor(749.0)
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+    s = P.pool_latents(lat.to(bf).to(gpu), (64, 64))
+    assert s.dtype == bf
+    d, m = controlnet(s, t, ehs_c.to(bf).to(gpu), cond.to(bf).to(gpu), return_dict=False)
+    assert all(x.dtype == bf for x in list(d) + [m])
+    oc = seeded_init(ControlNetOracle(**cases.CONTROLNET_KW).eval(), seed=11)
+    oa = seeded_init(ControlNetAdapterOracle(**cases.ADAPTER_SDXL).eval(), seed=22)
+    # the pipeline pools in the latents' dtype: the oracle starts from the same bf16 pooled latents
+    rd, rm = oc(s.float().cpu(), t, ehs_c, cond)
+    BOUND = 1e-3 + 2.0 ** -9
+    e_cn = [rel_inf(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm])]
+    print("PARITY bf16 boundary at shape controlnet rel_inf: " + " ".join("%.2e" % e for e in e_cn))
+    assert max(e_cn) <= BOUND
+    # adapter on the SAME bf16 features (the HIP ControlNet's own bf16 outputs, as the pipeline hands them over)
+    o, _ = ad(d, num_frames=1, timestep=t, encoder_hidden_states=ehs_a.to(bf).to(gpu))
+    assert all(x.dtype == bf for x in o)
+    ro, _ = oa([x.float().cpu() for x in d], num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+    e_ad = [rel_inf(a, b) for a, b in zip(o[:9], ro[:9])]
+    e_ad_r = [rel_inf(a, b.to(bf)) for a, b in zip(o[:9], ro[:9])]
+    print("PARITY bf16 boundary at shape adapter (same bf16 inputs) rel_inf: " + " ".join("%.2e" % e for e in e_ad))
+    print("PARITY bf16 boundary at shape adapter vs bf16-rounded oracle rel_inf: " + " ".join("%.2e" % e for e in e_ad_r))
+    assert max(e_ad) <= BOUND
+    # the chain against the all-fp32 oracle chain: the bf16 hand-over (2^-9 per feature element) is part of what the reference's
+    # own pipeline does; reported, bounded loosely
+    ro_chain, _ = oa(rd, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+    e_chain = [rel_inf(a, b) for a, b in zip(o[:9], ro_chain[:9])]
+    print("PARITY bf16 boundary at shape chain vs fp32 oracle chain rel_inf: " + " ".join("%.2e" % e for e in e_chain))
+    assert max(e_chain) <= 2 * BOUND
+    for i in (9, 10, 11):
+        assert o[i].abs().max().item() == 0.0 and o[i].dtype == bf
+
+
+WEIGHT_SWEEP = {
+    "gain0.5": dict(gain=0.5),
+    "gain2": dict(gain=2.0),
+    "student_t4": dict(dist="student4"),
+    "gamma_outliers": dict(gamma_outliers=0.01, gamma_outlier_scale=8.0),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(WEIGHT_SWEEP))
+def test_weight_distribution_sweep_sdxl_chain(P, gpu, tag):
+    """Robustness of the precision choices (which convolutions take split [hi | lo] operands, which streams are fp16) to the WEIGHT
+    distribution: every parity number elsewhere uses one family (unit-gain Gaussians); a trained checkpoint has other gains, heavier
+    tails and outlier channels.  SDXL b = 2 chain at the full shapes with: half / double the weight standard deviation, Student-t(4)
+    weights (same variance), 1 % of every normalisation scale multiplied by 8.  The DEFAULT selection must hold 1e-3; if it does not,
+    the conservative selection (fp32 adapter token stream, split operands on every ControlNet level) is measured too and named in the
+    failure message, so the report says which choice broke."""
+    import os
+    from oracle.controlnet import ControlNetOracle
+    from oracle.adapter import ControlNetAdapterOracle
+    torch.set_grad_enabled(False)
+    kw = WEIGHT_SWEEP[tag]
+    lat, ehs_c, cond, ehs_a = _sdxl_cfg_pair_inputs(5300)
+    lat[1] = seeded_tensor((4, 128, 128), 5399)                                   # two distinct images
+    cond[1] = seeded_tensor((3, 512, 512), 5398, kind="uniform")
+    t = torch.tensor(499.0)
+    oc = seeded_init(ControlNetOracle(**cases.CONTROLNET_KW).eval(), seed=11, **kw)
+    oa = seeded_init(ControlNetAdapterOracle(**cases.ADAPTER_SDXL).eval(), seed=22, **kw)
+    rd, rm = oc(torch.nn.functional.adaptive_avg_pool2d(lat, (64, 64)), t, ehs_c, cond)
+    ro, _ = oa(rd, num_frames=1, timestep=t, encoder_hidden_states=ehs_a)
+
+    def hip_chain():
+        cn = seeded_init(P.ControlNetModel(**cases.CONTROLNET_KW), seed=11, **kw).to(gpu)
+        ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22, **kw).to(gpu)
+        d, m = cn(P.pool_latents(lat.half().to(gpu), (64, 64)), t, ehs_c.half().to(gpu), cond.half().to(gpu), return_dict=False)
+        o, _ = ad(d, num_frames=1, timestep=t, encoder_hidden_states=ehs_a.half().to(gpu))
+        torch.cuda.synchronize()
+        e_cn = max(rel_inf(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm]))
+        e_ch = max(rel_inf(a, b) for a, b in zip(o[:9], ro[:9]))
+        return e_cn, e_ch
+
+    P._lib.range_check(True)                  # an activation beyond the fp16 range raises instead of passing silently as inf
+    try:
+        e_cn, e_ch = hip_chain()
+        print("PARITY weight sweep %-14s default selection: controlnet %.2e chain %.2e" % (tag, e_cn, e_ch))
+        if max(e_cn, e_ch) > 1e-3:
+            keep = {k: os.environ.get(k) for k in ("CTRL_ADAPTER_TOK_F16", "CTRL_CN_SPLIT_RESNET_LEVELS")}
+            os.environ["CTRL_ADAPTER_TOK_F16"] = "0"
+            os.environ["CTRL_CN_SPLIT_RESNET_LEVELS"] = "3"
+            try:
+                c_cn, c_ch = hip_chain()
+            finally:
+                for k, v in keep.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            print("PARITY weight sweep %-14s conservative selection: controlnet %.2e chain %.2e" % (tag, c_cn, c_ch))
+            raise AssertionError("weight distribution %r: default selection controlnet %.2e chain %.2e (bound 1e-3); conservative "
+                                 "selection (CTRL_ADAPTER_TOK_F16=0, CTRL_CN_SPLIT_RESNET_LEVELS=3) controlnet %.2e chain %.2e"
+                                 % (tag, e_cn, e_ch, c_cn, c_ch))
+    finally:
+        P._lib.range_check(False)
