@@ -29,7 +29,7 @@ class IGemmDesc(C.Structure):
                 ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
                 ("out16", C.c_void_p), ("ld16", C.c_int64),
                 ("blend_mix", C.c_void_p), ("blend_x", C.c_void_p), ("ld_blend", C.c_int64), ("blend_f32", C.c_int32), ("out16_lo_off", C.c_int32), ("scale2", C.c_float), ("scale2_from", C.c_int32),
-                ("res_up", C.c_int32), ("pad2_", C.c_int32),
+                ("res_up", C.c_int32), ("scale2_to", C.c_int32),
                 ("seg", IGemmSeg * 3), ("nonfinite", C.c_void_p)]
 
 
@@ -87,7 +87,7 @@ ABI_VERSION = 5       # CTRL_ABI_VERSION of include/ctrl_hip.h
 EXPORTS = [
     "ctrl_abi_version", "ctrl_last_error", "ctrl_prof_begin", "ctrl_prof_end", "ctrl_prof_count", "ctrl_prof_get",
     "ctrl_prof_launch_count", "ctrl_prof_launch_get",
-    "ctrl_op_igemm", "ctrl_range_check", "ctrl_range_status", "ctrl_igemm_set_order", "ctrl_igemm_set_wide", "ctrl_igemm_tile_of", "ctrl_op_flash_attn", "ctrl_attn_set_variant", "ctrl_op_temporal_attn", "ctrl_op_gn_stats_floats", "ctrl_op_gn_stats", "ctrl_op_gn_apply", "ctrl_op_gn_apply_split", "ctrl_op_pack_conv_w_dup",
+    "ctrl_op_igemm", "ctrl_range_check", "ctrl_range_status", "ctrl_igemm_set_order", "ctrl_igemm_set_wide", "ctrl_group_launches", "ctrl_igemm_tile_of", "ctrl_op_flash_attn", "ctrl_attn_set_variant", "ctrl_op_temporal_attn", "ctrl_op_gn_stats_floats", "ctrl_op_gn_stats", "ctrl_op_gn_apply", "ctrl_op_gn_apply_split", "ctrl_op_gn_fused_applies", "ctrl_op_gn_fused", "ctrl_op_pack_conv_w_dup",
     "ctrl_op_layernorm", "ctrl_op_nchw_to_nhwc", "ctrl_op_nhwc_to_nchw", "ctrl_avgpool_nchw",
     "ctrl_op_timestep_sincos", "ctrl_op_linear_small", "ctrl_op_blend", "ctrl_op_add_rowvec",
     "ctrl_op_conv3x3_direct", "ctrl_op_pack_conv_w", "ctrl_op_pack_conv_w_direct", "ctrl_op_pack_linear_w",

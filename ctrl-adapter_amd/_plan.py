@@ -155,8 +155,26 @@ class ParamTreeModule(PretrainedMixin, nn.Module):
         except Exception:
             pass
 
+    WEIGHT_GAIN_WARN = 1.5
+
+    def _warn_on_hot_weights(self, sd):
+        """The path rounds GEMM operands to fp16 (conv operands of the ControlNet to a [hi | lo] pair): its error against fp32 grows with
+        the GAIN of the weight matrices (std * sqrt(fan_in): every residual branch then outweighs its skip path) -- measured 0.75e-3 rel-inf
+        at gain 0.5 and 1.0, 2.0e-3 at gain 2.0 on the SDXL chain (tests/test_gpu_e2e.py::test_weight_distribution_sweep_sdxl_chain; no
+        selection of the path changes that, it is the fp16 operand format).  Says so once at plan creation instead of failing silently."""
+        gains = [v.detach().float().pow(2).mean().sqrt() * float(v[0].numel()) ** 0.5 for k, v in sd.items() if v.dim() >= 2 and v.numel() >= 4096]
+        if not gains:
+            return
+        med = torch.stack(gains).median().item()
+        self.weight_gain = med
+        if med > self.WEIGHT_GAIN_WARN:
+            import warnings
+            warnings.warn("%s: median weight gain %.2f (std * sqrt(fan_in)) is above %.1f -- the fp16-operand path is validated to 1e-3 "
+                          "rel-inf for gains <= 1; expect ~2e-3 at gain 2" % (type(self).__name__, med, self.WEIGHT_GAIN_WARN))
+
     def _tensor_refs(self):
         sd = {k: v for k, v in self.named_parameters()}
+        self._warn_on_hot_weights(sd)
         refs = (L.TensorRef * len(sd))()
         keep = []
         for i, (k, v) in enumerate(sd.items()):

@@ -36,7 +36,10 @@ __device__ __forceinline__ int tile_swz(int row) {
 }
 
 template <int D, int NW, bool BATCH, bool FOLD>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(AttnArgs a, const half_t* zeros) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(AttnGroup kargs, int per, const half_t* zeros) {
+    const int gp = __builtin_amdgcn_readfirstlane(blockIdx.x / per);
+    const int gbid = blockIdx.x - gp * per;
+    const AttnArgs a = ATTN_GROUP_ARGS(gp);
     constexpr int DP = (D + 31) / 32 * 32;      // padded head dim (zero filled): 64, 64, 96, 160
     constexpr int KS = (D + 15) / 16;           // k-steps of the 32x32x16 MFMA for QK^T (40 -> 3, 80 -> 5: no all-zero steps)
     constexpr int DB = DP / 32;                 // 32-row output blocks of O^T
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
     // pairs p = x, x+8, x+16, ... and walks their query tiles back to back, so the workgroups resident on one XCD at any
     // time stream the SAME K/V tiles through that XCD's private L2 (K+V of one pair at L = 16384 is 4 MiB = one L2).
     const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = gbid & 7, j = gbid >> 3;
     const int pair = (j / qtiles) * 8 + xcd;
     if (pair >= a.B * a.heads) return;
     const int b = pair / a.heads, h = pair - b * a.heads;
@@ -310,6 +313,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
 }
 
 const half_t* attn_zero_page() { return (const half_t*)device_zero_page(); }
+}  // namespace
+// descriptors of the grouped launch being dispatched (op_flash_attn_group); [0] is the problem the dispatcher sees
+thread_local const AttnArgs* t_attn_grp = nullptr;
+thread_local int t_attn_grp_n = 1;
+namespace {
 
 template <int D, int NW, bool BATCH, bool FOLD>
 int launch_attn2(const AttnArgs& a, hipStream_t s) {
@@ -324,11 +332,13 @@ int launch_attn2(const AttnArgs& a, hipStream_t s) {
     const half_t* zeros = attn_zero_page();
     CTRL_CHECK(zeros != nullptr, "flash_attn: could not allocate the zero page");
     const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32), pairs = a.B * a.heads;
-    dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
-    PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
-    prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
+    const int per = 8 * ((pairs + 7) / 8) * qtiles, G = attn_grp_count();
+    dim3 grid((unsigned)(per * G));
+    PROF_WORK(G * 4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, G * 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
+    if (G > 1) prof_detail("B%d h%d D%d Lq%d Lk%d x%d", a.B, a.heads, a.D, a.Lq, a.Lk, G);
+    else prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
     prof_symbol("flash_attn_kernel<%d, %d, %s, %s>", D, NW, BATCH ? "true" : "false", FOLD ? "true" : "false");
-    LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH, FOLD>), grid, dim3(NW * 64), smem, s, a, zeros);
+    LAUNCH("flash_attn", (flash_attn_kernel<D, NW, BATCH, FOLD>), grid, dim3(NW * 64), smem, s, attn_grp_make(a), per, zeros);
     return 0;
 }
 
@@ -455,7 +465,41 @@ bool flash_attn_d64_applies(const AttnArgs& a);
 int op_flash_attn_d64(const AttnArgs& a, hipStream_t s, int variant);
 int attn_variant();
 
+static int flash_attn_launch(const AttnArgs& a, hipStream_t s);
 int op_flash_attn(const AttnArgs& a, hipStream_t s) {
+    if (t_collect) {                                 // lock-step replay of sibling blocks: deposited, launched by the collector's flush()
+        int rc = 0;
+        const int i = t_collect->slot(OpCollector::ATTN, s, &rc);
+        if (i < 0) return rc;
+        t_collect->at[i] = a;
+        return 0;
+    }
+    return flash_attn_launch(a, s);
+}
+int op_flash_attn_group(const AttnArgs* a, int n, hipStream_t s) {
+    CTRL_CHECK(a && n >= 1 && n <= kMaxGroup, "flash_attn_group: 1..4 problems");
+    auto pk = [](const void* p) { return (int)((uintptr_t)p & 15); };
+    bool same = n > 1 && group_launches_enabled();
+    for (int i = 1; same && i < n; ++i)
+        same = a[i].ldq == a[0].ldq && a[i].ldk == a[0].ldk && a[i].Lkpad == a[0].Lkpad && a[i].kvB == a[0].kvB && a[i].ldo == a[0].ldo &&
+               a[i].B == a[0].B && a[i].heads == a[0].heads && a[i].D == a[0].D && a[i].Lq == a[0].Lq && a[i].Lk == a[0].Lk &&
+               a[i].scale == a[0].scale && a[i].k_prescaled == a[0].k_prescaled && pk(a[i].Q) == pk(a[0].Q) && pk(a[i].K) == pk(a[0].K) &&
+               pk(a[i].Vt) == pk(a[0].Vt) && pk(a[i].O) == pk(a[0].O);
+    if (!same) {
+        for (int i = 0; i < n; ++i) TRY(flash_attn_launch(a[i], s));
+        return 0;
+    }
+    t_attn_grp = a; t_attn_grp_n = n;        // the launch functions pick the siblings up from here
+    const int rc = flash_attn_launch(a[0], s);
+    t_attn_grp = nullptr; t_attn_grp_n = 1;
+    return rc;
+}
+static int flash_attn_launch(const AttnArgs& a, hipStream_t s) {
+    for (int i = 0; i < (t_attn_grp ? t_attn_grp_n : 1); ++i) {
+        const AttnArgs& q = t_attn_grp ? t_attn_grp[i] : a;
+        CTRL_CHECK((((uintptr_t)q.Q | (uintptr_t)q.K | (uintptr_t)q.Vt) & 15) == 0 && ((uintptr_t)q.O & 7) == 0,
+                   "flash_attn: pointers must be 16-byte aligned");
+    }
     CTRL_CHECK(a.B > 0 && a.heads > 0 && a.Lq > 0 && a.Lk > 0, "flash_attn: empty problem");
     CTRL_CHECK(a.kvB == 1 || a.kvB == a.B, "flash_attn: kvB must be 1 or B");
     CTRL_CHECK(a.Lkpad % 64 == 0 && a.Lkpad >= a.Lk, "flash_attn: Lkpad must be a multiple of 64 and >= Lk");

@@ -28,7 +28,10 @@ namespace {
 enum { AO_NEGM = 1, AO_SGB = 2, AO_PRIO = 4, AO_DEFER = 8, AO_MINI = 16, AO_DEFER8 = 32, AO_VPRIO = 64 };
 
 template <int QB, int NW, int OPT, int NSTAGE = 3>
-__global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_kernel(AttnArgs a, const half_t* zeros) {
+__global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_kernel(AttnGroup kargs, int per, const half_t* zeros) {
+    const int gp = __builtin_amdgcn_readfirstlane(blockIdx.x / per);      // grouped launch: attention.hip, AttnGroup
+    const int gbid = blockIdx.x - gp * per;
+    const AttnArgs a = ATTN_GROUP_ARGS(gp);
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth 2 .. 4");
     constexpr int TILEB = 64 * 64 * 2;                 // bytes of one K (or V^T) tile
     constexpr int VOFF = NSTAGE * TILEB;               // V^T ring behind the K ring
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
     const int hi = lane >> 5, lq = lane & 31;
     // XCD-aware work map, see flash_attn_kernel: every XCD owns whole (batch, head) pairs
     const int qtiles = (a.Lq + NW * QPW - 1) / (NW * QPW);
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = gbid & 7, j = gbid >> 3;
     const int pair = (j / qtiles) * 8 + xcd;
     if (pair >= a.B * a.heads) return;
     const int b = pair / a.heads, h = pair - b * a.heads;
@@ -299,7 +302,10 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
 // 4 waves x 64 queries per workgroup, two workgroups per CU (<= 256 registers); K and V^T rings of 3 tiles each: phase 2 of
 // tile t needs V(t) and K(t+1), which are waited for once per tile, before ONE barrier.
 template <int OPT>
-__global__ __launch_bounds__(256, 2) void flash_attn_d64p_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void flash_attn_d64p_kernel(AttnGroup kargs, int per) {
+    const int gp = __builtin_amdgcn_readfirstlane(blockIdx.x / per);
+    const int gbid = blockIdx.x - gp * per;
+    const AttnArgs a = ATTN_GROUP_ARGS(gp);
     constexpr int NW = 4, NSTAGE = 3;
     constexpr int TILEB = 64 * 64 * 2;
     constexpr int VOFF = NSTAGE * TILEB;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64p_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
     const int qtiles = (a.Lq + 255) / 256;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = gbid & 7, j = gbid >> 3;
     const int pair = (j / qtiles) * 8 + xcd;
     if (pair >= a.B * a.heads) return;
     const int b = pair / a.heads, h = pair - b * a.heads;
@@ -615,11 +621,13 @@ int launch_d64p(const AttnArgs& a, hipStream_t s) {
         attr_done[dev] = true;
     }
     const int qtiles = (a.Lq + 255) / 256, pairs = a.B * a.heads;
-    dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
-    PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
-    prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
+    const int per = 8 * ((pairs + 7) / 8) * qtiles, G = attn_grp_count();
+    dim3 grid((unsigned)(per * G));
+    PROF_WORK(G * 4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, G * 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
+    if (G > 1) prof_detail("B%d h%d D%d Lq%d Lk%d x%d", a.B, a.heads, a.D, a.Lq, a.Lk, G);
+    else prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
     prof_symbol("flash_attn_d64p_kernel<%d>", OPT);
-    LAUNCH("flash_attn", (flash_attn_d64p_kernel<OPT>), grid, dim3(256), smem, s, a);
+    LAUNCH("flash_attn", (flash_attn_d64p_kernel<OPT>), grid, dim3(256), smem, s, attn_grp_make(a), per);
     return 0;
 }
 
@@ -634,11 +642,13 @@ int launch_d64(const AttnArgs& a, hipStream_t s) {
     }
     const half_t* zeros = (const half_t*)device_zero_page();
     const int qtiles = (a.Lq + NW * 32 * QB - 1) / (NW * 32 * QB), pairs = a.B * a.heads;
-    dim3 grid((unsigned)(8 * ((pairs + 7) / 8) * qtiles));
-    PROF_WORK(4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
-    prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
+    const int per = 8 * ((pairs + 7) / 8) * qtiles, G = attn_grp_count();
+    dim3 grid((unsigned)(per * G));
+    PROF_WORK(G * 4.0 * a.B * a.heads * (double)a.Lq * a.Lk * a.D, G * 2.0 * a.heads * a.D * (2.0 * a.B * a.Lq + 2.0 * a.kvB * a.Lk));
+    if (G > 1) prof_detail("B%d h%d D%d Lq%d Lk%d x%d", a.B, a.heads, a.D, a.Lq, a.Lk, G);
+    else prof_detail("B%d h%d D%d Lq%d Lk%d", a.B, a.heads, a.D, a.Lq, a.Lk);
     prof_symbol("flash_attn_d64_kernel<%d, %d, %d, %d>", QB, NW, OPT, NSTAGE);
-    LAUNCH("flash_attn", (flash_attn_d64_kernel<QB, NW, OPT, NSTAGE>), grid, dim3(NW * 64), smem, s, a, zeros);
+    LAUNCH("flash_attn", (flash_attn_d64_kernel<QB, NW, OPT, NSTAGE>), grid, dim3(NW * 64), smem, s, attn_grp_make(a), per, zeros);
     return 0;
 }
 

@@ -1,0 +1,47 @@
+// Collector of the grouped launches (ops.h: OpCollector): deposits of one lock-step position, launched together by flush().
+#include "ops.h"
+#include "../../include/ctrl_hip.h"
+#include <cstdlib>
+
+thread_local OpCollector* t_collect = nullptr;
+
+static int g_group = -1;
+static int group_mode() {
+    if (g_group < 0) { const char* e = getenv("CTRL_GROUP"); g_group = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)); }
+    return g_group;
+}
+bool group_launches_enabled() { return group_mode() != 0; }
+bool group_tiles_as_alone() { return group_mode() == 2; }
+extern "C" int ctrl_group_launches(int on) {
+    if (on >= 0 && on <= 2) g_group = on;
+    return group_mode();
+}
+
+int OpCollector::slot(int type_, hipStream_t s_, int* rc) {
+    *rc = 0;
+    if (n > 0 && (type != type_ || s != s_ || n == kMaxGroup)) {
+        *rc = flush();
+        if (*rc) return -1;
+    }
+    type = type_; s = s_;
+    return n++;
+}
+
+int OpCollector::flush() {
+    if (n == 0) return 0;
+    OpCollector* const me = t_collect;
+    t_collect = nullptr;                 // the group ops below launch for real
+    int rc = 0;
+    switch (type) {
+        case IGEMM: rc = op_igemm_group(ig, n, s); break;
+        case GN_STATS: rc = op_gn_stats_group(gs, n, s); break;
+        case GN_APPLY: rc = op_gn_apply_group(ga, n, s); break;
+        case LAYERNORM: rc = op_layernorm_group(ln, n, s); break;
+        case ATTN: rc = op_flash_attn_group(at, n, s); break;
+        case GN_FUSED: rc = op_gn_fused_group(ga, n, s); break;
+        default: break;
+    }
+    t_collect = me;
+    n = 0; type = NONE;
+    return rc;
+}

@@ -29,6 +29,17 @@
 
 namespace {
 
+// Grouped launch (round 5): up to kMaxGroup problems of the SAME shape and epilogue form -- the sibling adapter blocks of one
+// pyramid level (model/ctrl_adapter.py:181-191 runs them one after the other; they are independent) -- share one launch: the
+// descriptors travel as an array in the kernel-argument segment, workgroup b works on problem b / per.  A 32^2 / 16^2 GEMM then
+// has 2-4 x the tiles (the wide tile instead of the 128 x 128 / 64 x 64 ring tiles) and the step has fewer launches.  A plain launch
+// is a group of one.  Every problem is computed exactly as it would be alone (same tiles, same k order): results are bit-identical.
+struct IGemmGroup { IGemmArgs a[kMaxIGemmGroup]; };
+// descriptor of this workgroup's problem, read from the kernel-argument segment (constant memory: scalar loads; the group is the first
+// kernel parameter, i.e. offset 0 of the segment).  Not `kargs.a[gp]`: a dynamic index into the by-value parameter would pin its
+// private copy -- 1.5 KB per lane -- in scratch.
+#define IGEMM_GROUP_ARGS(gp) (((const IGemmArgs*)__builtin_amdgcn_kernarg_segment_ptr())[gp])
+
 // Residual row of output row `row`.  res_up == 2: the residual is held at HALF the output resolution and read through a
 // nearest x2 up-sampling -- the 1x1 shortcut convolution of the adapter's ResnetBlock2D commutes with the nearest up-sampling
 // in front of it (model/resnet_block_2d.py:174-184 up-samples input_tensor, :216 applies conv_shortcut: every output pixel of
@@ -83,6 +94,35 @@ __device__ __forceinline__ void res_fetch8(const ResSrc& r, int row, int col, f4
     }
 }
 
+// scale of output column `col`: scale2 inside [scale2_from, scale2_to) (scale2_to == 0: to the end), scale elsewhere
+__device__ __forceinline__ float col_scale(const IGemmArgs& e, int col) {
+    return (e.scale2_from > 0 && col >= e.scale2_from && (e.scale2_to == 0 || col < e.scale2_to)) ? e.scale2 : e.scale;
+}
+
+// Segment `si` of the descriptor with every field selected VALUE by value from scalars that are opaque to the optimiser: left to
+// itself the compiler turns "select between loaded kernel-argument fields" into "load from a selected address", which moves the whole
+// descriptor to scratch for the entire kernel (every argument read then waits on vmcnt)
+__device__ __forceinline__ IGemmSeg seg_select(const IGemmArgs& e, int si) {
+    void* q_out[3] = {e.seg[0].out, e.seg[1].out, e.seg[2].out};
+    int64_t q_ld[3] = {e.seg[0].ld, e.seg[1].ld, e.seg[2].ld};
+    int q_cb[3] = {e.seg[0].col_begin, e.seg[1].col_begin, e.seg[2].col_begin}, q_nc[3] = {e.seg[0].ncols, e.seg[1].ncols, e.seg[2].ncols};
+    int q_fmt[3] = {e.seg[0].fmt, e.seg[1].fmt, e.seg[2].fmt}, q_dt[3] = {e.seg[0].dtype, e.seg[1].dtype, e.seg[2].dtype}, q_L[3] = {e.seg[0].L, e.seg[1].L, e.seg[2].L};
+    const int32_t* q_map[3] = {e.seg[0].img_map, e.seg[1].img_map, e.seg[2].img_map};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(q_out[k]), "+s"(q_ld[k]), "+s"(q_cb[k]), "+s"(q_nc[k]), "+s"(q_fmt[k]), "+s"(q_dt[k]), "+s"(q_L[k]), "+s"(q_map[k]));
+    IGemmSeg sg;
+    sg.out = si == 0 ? q_out[0] : (si == 1 ? q_out[1] : q_out[2]);
+    sg.ld = si == 0 ? q_ld[0] : (si == 1 ? q_ld[1] : q_ld[2]);
+    sg.col_begin = si == 0 ? q_cb[0] : (si == 1 ? q_cb[1] : q_cb[2]);
+    sg.ncols = si == 0 ? q_nc[0] : (si == 1 ? q_nc[1] : q_nc[2]);
+    sg.fmt = si == 0 ? q_fmt[0] : (si == 1 ? q_fmt[1] : q_fmt[2]);
+    sg.dtype = si == 0 ? q_dt[0] : (si == 1 ? q_dt[1] : q_dt[2]);
+    sg.L = si == 0 ? q_L[0] : (si == 1 ? q_L[1] : q_L[2]);
+    sg.img_map = si == 0 ? q_map[0] : (si == 1 ? q_map[1] : q_map[2]);
+    sg.pad_ = 0;
+    return sg;
+}
+
 // ---------------- epilogue of an accumulated tile (m0, n0), shared by every main loop of this file ----------------
 // acc[mi][ni]: the 16x16 fragments of the wave tile (WM x WN at wave position (wm, wn)); epi_smem: the workgroup's LDS, dead
 // as a k-loop ring when this runs (the caller has NOT synchronised: the first thing the staged forms do is a barrier).
@@ -100,7 +140,12 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
         // leaves as whole 16-byte pieces of full output rows: residual reads and result writes are coalesced 128-byte+
         // row segments instead of 8-byte fragments scattered over 16 rows.
         __syncthreads();           // every wave is done with the ring
-        if (e.seg[0].fmt == SEG_TRANSPOSED) {
+        // Mixed layouts (row-major segments + ONE transposed last segment: Q | K | V^T of a self-attention projection in one launch):
+        // the dispatcher only picks tiles whose width divides the transposed segment's first column, so a tile lies in one segment
+        // and the choice below is workgroup-uniform
+        const bool t_last = e.nseg > 1 && n0 >= (e.nseg == 2 ? e.seg[1].col_begin : e.seg[2].col_begin);
+        const int t_fmt_last = e.nseg == 1 ? e.seg[0].fmt : (e.nseg == 2 ? e.seg[1].fmt : e.seg[2].fmt);
+        if ((e.nseg == 1 || t_last) && t_fmt_last == SEG_TRANSPOSED) {
             // One transposed segment (NCHW result / V^T operand): out[(img*ncols + c)*ld + tok].  Everything that is
             // indexed by (row, column) -- bias, time vector, SiLU, residual, scale -- is applied in the fragment layout;
             // a 16-channel slab of the wave tile (16 x WM tokens) is then transposed through the wave's LDS area and
@@ -108,7 +153,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
             // natural orientation's isolated 8-byte stores.
             constexpr int SLT = WM + 4;                    // 4*SLT = 16 (mod 64 banks): the 4 channel groups of a write hit distinct banks
             float* stg = (float*)epi_smem + wave * (16 * SLT);
-            const IGemmSeg sg = e.seg[0];
+            const IGemmSeg sg = seg_select(e, e.nseg - 1);
             const int erow = lane & 15, ecol = (lane >> 4) * 4;
             const int wrow0 = m0 + wm * WM;
 #pragma unroll
@@ -118,6 +163,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                     const int pcol = pcb + ecol;
                     f4 b4 = f4{0.f, 0.f, 0.f, 0.f};
                     if (e.bias) b4 = *(const f4*)(e.bias + pcol);
+                    const float sc_t = col_scale(e, pcb);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
                         const int row_w = wrow0 + mi * 16 + erow;
@@ -139,7 +185,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                             }
                         }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) stg[(ecol + i) * SLT + mi * 16 + erow] = x[i] * e.scale;
+                        for (int i = 0; i < 4; ++i) stg[(ecol + i) * SLT + mi * 16 + erow] = x[i] * sc_t;
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     constexpr int CH8 = WM / 8;
@@ -237,7 +283,8 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                 // fp16 rows with nothing to add after the transposition (projections, GEGLU, convolutions without a residual): the slab is
                 // staged as PACKED fp16 -- scale and rounding happen in the fragment layout, the same fp32 operations in the same order --
                 // so a piece is one 16-byte LDS read and one store: half the LDS traffic and a third of the per-piece instructions
-                if (!has_res && !e.blend_mix && !e.out16 && e.nseg == 1 && e.seg[0].dtype == DT_F16) {
+                const bool one_row_seg = e.nseg == 1 || (e.nseg == 2 && e.seg[1].fmt == SEG_TRANSPOSED);      // (this tile then lies in segment 0)
+                if (!has_res && !e.blend_mix && !e.out16 && one_row_seg && e.seg[0].dtype == DT_F16) {
                     constexpr int RS = OWMAX * 2 + 16;                 // bytes per staged row
                     char* const stg16 = (char*)stg;
                     half_t* const outp = (half_t*)e.seg[0].out;
@@ -268,7 +315,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                                 for (int i = 0; i < 4; ++i) x[i] = silu_f(x[i]);
                             }
                             const int lcol = (gg ? (ni >> 1) * 16 : ni * 16) + ecol;
-                            const float sc = (e.scale2_from > 0 && wcol0 + lcol >= e.scale2_from) ? e.scale2 : e.scale;
+                            const float sc = col_scale(e, wcol0 + lcol);
                             const h4 pk = {(half_t)(x[0] * sc), (half_t)(x[1] * sc), (half_t)(x[2] * sc), (half_t)(x[3] * sc)};
                             if (e.nonfinite) flag_nonfinite(e.nonfinite, row_w < e.M && (out_of_half(x[0] * sc) || out_of_half(x[1] * sc) || out_of_half(x[2] * sc) || out_of_half(x[3] * sc)));
                             *(h4*)(stg16 + erow * RS + lcol * 2) = pk;
@@ -339,7 +386,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                         }
                         {
                             // an 8-column chunk never straddles scale2_from (a multiple of 8, checked by op_igemm)
-                            const float sc = (e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale;
+                            const float sc = col_scale(e, ocol);
 #pragma unroll
                             for (int i = 0; i < 8; ++i) x[i] *= sc;
                         }
@@ -428,24 +475,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
 #pragma unroll
             for (int k = 1; k < 3; ++k)
                 if (k < e.nseg && ocb >= e.seg[k].col_begin) si = k;
-            // (field by field, from opaque scalars: "select between loaded kernel-argument fields" otherwise becomes "load from a selected
-            // address" and pins the whole descriptor in scratch for the entire kernel)
-            void* q_out[3] = {e.seg[0].out, e.seg[1].out, e.seg[2].out};
-            int64_t q_ld[3] = {e.seg[0].ld, e.seg[1].ld, e.seg[2].ld};
-            int q_cb[3] = {e.seg[0].col_begin, e.seg[1].col_begin, e.seg[2].col_begin}, q_nc[3] = {e.seg[0].ncols, e.seg[1].ncols, e.seg[2].ncols};
-            int q_fmt[3] = {e.seg[0].fmt, e.seg[1].fmt, e.seg[2].fmt}, q_dt[3] = {e.seg[0].dtype, e.seg[1].dtype, e.seg[2].dtype}, q_L[3] = {e.seg[0].L, e.seg[1].L, e.seg[2].L};
-            const int32_t* q_map[3] = {e.seg[0].img_map, e.seg[1].img_map, e.seg[2].img_map};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(q_out[k]), "+s"(q_ld[k]), "+s"(q_cb[k]), "+s"(q_nc[k]), "+s"(q_fmt[k]), "+s"(q_dt[k]), "+s"(q_L[k]), "+s"(q_map[k]));
-            IGemmSeg sg;
-            sg.out = si == 0 ? q_out[0] : (si == 1 ? q_out[1] : q_out[2]);
-            sg.ld = si == 0 ? q_ld[0] : (si == 1 ? q_ld[1] : q_ld[2]);
-            sg.col_begin = si == 0 ? q_cb[0] : (si == 1 ? q_cb[1] : q_cb[2]);
-            sg.ncols = si == 0 ? q_nc[0] : (si == 1 ? q_nc[1] : q_nc[2]);
-            sg.fmt = si == 0 ? q_fmt[0] : (si == 1 ? q_fmt[1] : q_fmt[2]);
-            sg.dtype = si == 0 ? q_dt[0] : (si == 1 ? q_dt[1] : q_dt[2]);
-            sg.L = si == 0 ? q_L[0] : (si == 1 ? q_L[1] : q_L[2]);
-            sg.img_map = si == 0 ? q_map[0] : (si == 1 ? q_map[1] : q_map[2]);
+            const IGemmSeg sg = seg_select(e, si);
             const int scol = ocol - sg.col_begin;
             const float bh = e.bias ? e.bias[pcol] : 0.f;
             const float bg = (e.geglu && e.bias) ? e.bias[pcol + 16] : 0.f;
@@ -466,7 +496,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
                     if (e.act == 1) x = silu_f(x);
                     if (Rptr && row < e.M)
                         x += e.res_f32 ? ((const float*)e.res)[res_row_of(e, row) * e.ldres + ocol] : (float)Rptr[res_row_of(e, row) * e.ldres + ocol];
-                    v[i] = x * ((e.scale2_from > 0 && ocol >= e.scale2_from) ? e.scale2 : e.scale);
+                    v[i] = x * col_scale(e, ocol);
                 }
                 if (sg.fmt == SEG_ROW) {
 #pragma unroll
@@ -511,8 +541,14 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& e, f4 (&acc)[BM 
 // in round 2 and measured again at the start of round 3 after the epilogue fetch hoisting: 0.72-1.03x the one-tile form on
 // every shape of the path, profiles/r03_gemm_persistent_form.txt.  It is gone from the product.)
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmArgs a, int ntm, int ntn, const half_t* zeros, int splitk, int order) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M * WAVES_N>::v)) void igemm_kernel(IGemmGroup kargs, int per, int ntm, int ntn, const half_t* zeros, int splitk, int order) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // grouped launch: workgroups [gp * per, (gp + 1) * per) belong to problem gp (per = the problem's workgroup count, rounded up to
+    // a multiple of 8 in a group so that the XCD of a workgroup is still its local index % 8; the padding workgroups leave here)
+    const int gp = __builtin_amdgcn_readfirstlane(blockIdx.x / per);      // (the division runs on the vector ALU: back to a scalar, so that
+    const int gbid = blockIdx.x - gp * per;                                //  the descriptor below is read with scalar loads)
+    if (gbid >= ntm * ntn * splitk) return;
+    const IGemmArgs& a = IGEMM_GROUP_ARGS(gp);
     constexpr int NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // per-wave tile
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -534,8 +570,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (MinWaves<BM, BN, WAVES_M *
     // split-K: blockIdx.x = split * nblk + tile; every split accumulates a contiguous range of k-tiles and writes its
     // fp32 partial tile to slab `split` of the scratch buffer (reduced + finished by splitk_finish_kernel)
     const int nblk = ntm * ntn;
-    const int split = blockIdx.x / nblk;
-    const int first_bid = blockIdx.x - split * nblk;
+    const int split = gbid / nblk;
+    const int first_bid = gbid - split * nblk;
     int m0, n0;                          // origin of the output tile being ACCUMULATED (the epilogue's tile)
     {
         int tile_m, tile_n;
@@ -842,8 +878,15 @@ struct KPos { int tap, ac, wk, hl; };
     __builtin_amdgcn_sched_barrier(0);
 
 template <int NI, int MODE>
-__global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmArgs a, int ntm, int ntn, int splitk, int order, float* red_ws, int* red_cnt) {
+__global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmGroup kargs, int per, int ntm, int ntn, int splitk, int order, long red_off) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int gp = __builtin_amdgcn_readfirstlane(blockIdx.x / per);      // grouped launch: see igemm_kernel
+    const int gbid = blockIdx.x - gp * per;
+    if (gbid >= ntm * ntn * splitk) return;
+    const IGemmArgs& a = IGEMM_GROUP_ARGS(gp);
+    // in-launch split-K reduction (red_off >= 0): fragment slabs at the start of the problem's split-K scratch, ticket words at red_off
+    float* const red_ws = (float*)a.splitk_ws;
+    int* const red_cnt = red_off >= 0 ? (int*)((char*)a.splitk_ws + red_off) : nullptr;
     typedef g8::Lds<NI> L;
     constexpr int BM = 256, BN = 64 * NI, BK = 64, WN = 16 * NI, NL = L::NL;
     typedef void __attribute__((address_space(3)))* lptr_t;
@@ -853,8 +896,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmArgs a, int ntm, in
     const int wm = wave >> 2, wn = wave & 3;
 
     const int nblk = ntm * ntn;
-    const int split = blockIdx.x / nblk;
-    const int first_bid = blockIdx.x - split * nblk;
+    const int split = gbid / nblk;
+    const int first_bid = gbid - split * nblk;
     int m0, n0;
     {
         int tile_m, tile_n;
@@ -986,7 +1029,12 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmArgs a, int ntm, in
                 const int vy = (int)((st >> 12) & 0xfff) - 1 + ky, vx = (int)(st & 0xfff) - 1 + kx;
                 const bool ok = (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW;
                 const int pix = (int)(st >> 24) * hwin + (vy >> ushift) * a.Win + (vx >> ushift);
-                a_cur[sb][i] = ok ? (unsigned)(pix * lda2 + c8u) : g8::OOB;
+                // (multiply and add kept apart: fused into v_mad_u64_u32 they need a register PAIR, and the 256-register 320-wide tile
+                // then spills one register around it -- a scratch reload inside the k-loop, which the in-order vmcnt turns into a drain
+                // of the DMA queue; tests/test_kernel_resources.py)
+                unsigned poff = (unsigned)pix * (unsigned)lda2;
+                asm volatile("" : "+v"(poff));
+                a_cur[sb][i] = ok ? poff + (unsigned)c8u : g8::OOB;
             }
         }
 #pragma unroll
@@ -1299,6 +1347,44 @@ int plan_order(const IGemmArgs& a, int BM, int BN, int ntm, int ntn) {
     return G < ntn ? tileorder::make_order(tileorder::ORDER_XCD_M, G) : 0;
 }
 
+// descriptors of the grouped launch being dispatched (op_igemm_group): [0] is the problem the dispatcher sees
+thread_local const IGemmArgs* t_grp = nullptr;
+thread_local int t_grp_n = 1;
+inline int grp_count() { return t_grp ? t_grp_n : 1; }
+inline const IGemmArgs& grp_at(const IGemmArgs& a, int i) { return t_grp ? t_grp[i] : a; }
+// workgroups per problem of a launch: a group pads them to a multiple of 8 (XCD of a workgroup = its local index % 8, tile_order.h)
+inline int grp_per(int nblk) { return grp_count() > 1 ? ((nblk + 7) & ~7) : nblk; }
+// split-K in the finish-kernel form: the GEMM writes fp32 row slabs, every epilogue term is applied once by the finish kernel
+inline IGemmArgs splitk_slab_desc(const IGemmArgs& a) {
+    IGemmArgs p = a;
+    p.bias = nullptr; p.rowvec = nullptr; p.res = nullptr; p.res_f32 = 0; p.act = 0; p.scale = 1.f; p.out16 = nullptr;
+    p.blend_mix = nullptr; p.blend_x = nullptr;
+    p.nseg = 1;
+    p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
+    return p;
+}
+int launch_splitk_finish(const IGemmArgs& a, int splitk, hipStream_t s) {
+    for (int i = 0; i < grp_count(); ++i) {
+        const IGemmArgs& ai = grp_at(a, i);
+        const size_t total = (size_t)ai.M * (ai.Nout / 8);
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        PROF_WORK(0, 4.0 * splitk * ai.M * ai.Nout);
+        prof_detail("M%d N%d splitk%d", ai.M, ai.Nout, splitk);
+        LAUNCH("splitk_finish", splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ai, (const float*)ai.splitk_ws, splitk);
+    }
+    return 0;
+}
+void prof_igemm(const IGemmArgs& a, const char* extra) {
+    const int G = grp_count();
+    // algorithmic work = the reference op's: a split operand doubles the K the kernel walks, not the FLOPs that count
+    const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
+    PROF_WORK(G * 2.0 * a.M * a.Nout * kalg, G * 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
+    char grp[16] = "";
+    if (G > 1) snprintf(grp, sizeof(grp), " x%d", G);
+    prof_detail("M%d N%d K%d taps%d%s%s%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "", extra, grp);
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, bool SWAP>
 int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     constexpr int PASSROWS = WAVES_M * WAVES_N * (64 / (BK / 8));
@@ -1318,34 +1404,26 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     CTRL_CHECK(zeros != nullptr, "igemm: could not allocate the zero page");
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nout + BN - 1) / BN;
     const int order = plan_order(a, BM, BN, ntm, ntn);
-    // algorithmic work = the reference op's: a split operand doubles the K the kernel walks, not the FLOPs that count
-    const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
-    PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
-    prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
+    const int G = grp_count();
+    const int per = grp_per(ntm * ntn * splitk);
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
     const auto sym = [&]() { prof_symbol("igemm_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP ? "true" : "false"); };
+    IGemmGroup grp;
     if (splitk > 1) {
         // partial sums go to fp32 slabs [splitk][M][Nout]; every epilogue term is applied once, by the finish kernel
-        IGemmArgs p = a;
-        p.bias = nullptr; p.rowvec = nullptr; p.res = nullptr; p.res_f32 = 0; p.act = 0; p.scale = 1.f; p.out16 = nullptr;
-        p.blend_mix = nullptr; p.blend_x = nullptr;
-        p.nseg = 1;
-        p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
-        prof_detail("M%d N%d K%d taps%d%s splitk%d", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
+        for (int i = 0; i < G; ++i) grp.a[i] = splitk_slab_desc(grp_at(a, i));
+        char ex[32]; snprintf(ex, sizeof(ex), " splitk%d", splitk);
+        prof_igemm(a, ex);
         sym();
-        LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn * splitk),
-               dim3(WAVES_M * WAVES_N * 64), smem, s, p, ntm, ntn, zeros, splitk, order);
-        const size_t total = (size_t)a.M * (a.Nout / 8);
-        size_t blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        PROF_WORK(0, 4.0 * splitk * a.M * a.Nout);
-        prof_detail("M%d N%d splitk%d", a.M, a.Nout, splitk);
-        LAUNCH("splitk_finish", splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)a.splitk_ws, splitk);
-        return 0;
+        LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(per * G),
+               dim3(WAVES_M * WAVES_N * 64), smem, s, grp, per, ntm, ntn, zeros, splitk, order);
+        return launch_splitk_finish(a, splitk, s);
     }
+    for (int i = 0; i < G; ++i) grp.a[i] = grp_at(a, i);
+    prof_igemm(a, "");
     sym();
-    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(ntm * ntn), dim3(WAVES_M * WAVES_N * 64), smem, s,
-           a, ntm, ntn, zeros, 1, order);
+    LAUNCH(tag, (igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, SWAP>), dim3(per * G), dim3(WAVES_M * WAVES_N * 64), smem, s,
+           grp, per, ntm, ntn, zeros, 1, order);
     return 0;
 }
 
@@ -1353,16 +1431,17 @@ int launch_cfg2(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
 // vector epilogue); mixed or unaligned segment lists keep the natural orientation and its scalar epilogue.
 bool can_swap(const IGemmArgs& a) {
     bool swap = (a.Nout % 16 == 0);
-    if (a.nseg == 1 && a.seg[0].fmt == SEG_TRANSPOSED) {
-        // single transposed output: LDS-transposed epilogue, 8-token pieces (an image's tokens start 16-byte aligned)
-        const IGemmSeg& g = a.seg[0];
-        swap = swap && !a.geglu && !a.out16 && g.L > 0 && (g.L % 8 == 0) && (g.ld % 8 == 0) && (a.M % 8 == 0) &&
-               (((uintptr_t)g.out & 15) == 0);
-    } else {
-        for (int i = 0; i < a.nseg; ++i)
-            swap = swap && a.seg[i].fmt == SEG_ROW && (a.seg[i].ld % 8 == 0) && (((uintptr_t)a.seg[i].out & 15) == 0) &&
-                   (a.seg[i].col_begin % 8 == 0);
+    // a transposed segment must be the last one (LDS-transposed epilogue, 8-token pieces: an image's tokens start 16-byte aligned); in
+    // front of it only row-major segments, and then it starts at a multiple of 64 columns (mixed_boundary)
+    const int nrow = (a.seg[a.nseg - 1].fmt == SEG_TRANSPOSED) ? a.nseg - 1 : a.nseg;
+    if (nrow < a.nseg) {
+        const IGemmSeg& g = a.seg[a.nseg - 1];
+        swap = swap && !a.geglu && !a.out16 && !a.blend_mix && g.L > 0 && (g.L % 8 == 0) && (g.ld % 8 == 0) && (a.M % 8 == 0) &&
+               (((uintptr_t)g.out & 15) == 0) && (nrow == 0 || (g.col_begin % 64 == 0 && !a.res && !a.rowvec));
     }
+    for (int i = 0; i < nrow; ++i)
+        swap = swap && a.seg[i].fmt == SEG_ROW && (a.seg[i].ld % 8 == 0) && (((uintptr_t)a.seg[i].out & 15) == 0) &&
+               (a.seg[i].col_begin % 8 == 0);
     if (a.res) swap = swap && (a.ldres % 8 == 0) && (((uintptr_t)a.res & 15) == 0);
     if (a.out16) swap = swap && (a.ld16 % 8 == 0) && (((uintptr_t)a.out16 & 15) == 0) && (a.out16_lo_off % 8 == 0);
     if (a.blend_mix) swap = swap && a.blend_x && (a.ld_blend % 8 == 0) && (((uintptr_t)a.blend_x & 15) == 0);
@@ -1411,11 +1490,11 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
     // rate that traffic is the limiter: M131072 N2048 K2048 1.52 ms grouped vs 1.07 ms legacy (profiles/r04_gemm_tile_order_8phase.txt)
     (void)plan_order(a, BM, BN, ntm, ntn);          // (parses CTRL_IGEMM_ORDER on first use)
     const int order = g_order_spec.kind == 2 ? tileorder::make_order(g_order_spec.mode, g_order_spec.group) : 0;
-    const double kalg = a.a_split ? 0.5 * a.Ktot : (double)a.Ktot;
-    PROF_WORK(2.0 * a.M * a.Nout * kalg, 2.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Ktot + (double)a.M * a.Nout));
-    prof_detail("M%d N%d K%d taps%d%s%s", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", a.geglu ? " geglu" : "");
+    const int G = grp_count();
+    const int per = grp_per(ntm * ntn * splitk);
     const char* tag = MODE == IG_ROWS ? "igemm_rows" : (MODE == IG_CONV2D ? "igemm_conv" : "igemm_temporal");
     const auto sym = [&]() { prof_symbol("igemm8_kernel<%d, %d>", NI, MODE); };
+    IGemmGroup grp;
     if (splitk > 1) {
         // 2..4 splits: reduced inside the launch by the last-arriving workgroup of every tile (see the kernel); the workspace then
         // holds tile-shaped fragment slabs [tile][split][fragment][thread] + one ticket word per tile (zeroed by a memset node)
@@ -1423,32 +1502,31 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         const size_t need = (slabs + 255) / 256 * 256 + (size_t)ntm * ntn * sizeof(int);
         static int inlaunch = -1;
         if (inlaunch < 0) { const char* e = getenv("CTRL_SPLITK_INLAUNCH"); inlaunch = (e && e[0] == '0') ? 0 : 1; }
-        if (inlaunch && splitk <= 4 && (size_t)a.splitk_ws_bytes >= need) {
-            int* cnt = (int*)((char*)a.splitk_ws + (slabs + 255) / 256 * 256);
-            HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)ntm * ntn * sizeof(int), s));
-            prof_detail("M%d N%d K%d taps%d%s splitk%d in-launch", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
+        bool fits = true;
+        for (int i = 0; i < G; ++i) fits = fits && (size_t)grp_at(a, i).splitk_ws_bytes >= need;
+        if (inlaunch && splitk <= 4 && fits) {
+            const long red_off = (long)((slabs + 255) / 256 * 256);
+            for (int i = 0; i < G; ++i) {
+                grp.a[i] = grp_at(a, i);
+                HIP_TRY(hipMemsetAsync((char*)grp.a[i].splitk_ws + red_off, 0, (size_t)ntm * ntn * sizeof(int), s));
+            }
+            char ex[40]; snprintf(ex, sizeof(ex), " splitk%d in-launch", splitk);
+            prof_igemm(a, ex);
             sym();
-            LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn * splitk), dim3(512), smem, s, a, ntm, ntn, splitk, order, (float*)a.splitk_ws, cnt);
+            LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(per * G), dim3(512), smem, s, grp, per, ntm, ntn, splitk, order, red_off);
             return 0;
         }
-        IGemmArgs p = a;
-        p.bias = nullptr; p.rowvec = nullptr; p.res = nullptr; p.res_f32 = 0; p.act = 0; p.scale = 1.f; p.out16 = nullptr;
-        p.blend_mix = nullptr; p.blend_x = nullptr;
-        p.nseg = 1;
-        p.seg[0] = IGemmSeg{a.splitk_ws, a.Nout, 0, a.Nout, SEG_ROW, DT_F32, 1, 0};
-        prof_detail("M%d N%d K%d taps%d%s splitk%d", a.M, a.Nout, a.Ktot, a.taps, a.a_split ? " split-A" : "", splitk);
+        for (int i = 0; i < G; ++i) grp.a[i] = splitk_slab_desc(grp_at(a, i));
+        char ex[32]; snprintf(ex, sizeof(ex), " splitk%d", splitk);
+        prof_igemm(a, ex);
         sym();
-        LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn * splitk), dim3(512), smem, s, p, ntm, ntn, splitk, order, (float*)nullptr, (int*)nullptr);
-        const size_t total = (size_t)a.M * (a.Nout / 8);
-        size_t blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        PROF_WORK(0, 4.0 * splitk * a.M * a.Nout);
-        prof_detail("M%d N%d splitk%d", a.M, a.Nout, splitk);
-        LAUNCH("splitk_finish", splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)a.splitk_ws, splitk);
-        return 0;
+        LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(per * G), dim3(512), smem, s, grp, per, ntm, ntn, splitk, order, (long)-1);
+        return launch_splitk_finish(a, splitk, s);
     }
+    for (int i = 0; i < G; ++i) grp.a[i] = grp_at(a, i);
+    prof_igemm(a, "");
     sym();
-    LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn, 1, order, (float*)nullptr, (int*)nullptr);
+    LAUNCH(tag, (igemm8_kernel<NI, MODE>), dim3(per * G), dim3(512), smem, s, grp, per, ntm, ntn, 1, order, (long)-1);
     return 0;
 }
 
@@ -1512,12 +1590,24 @@ int launch_cfg(const IGemmArgs& a, hipStream_t s) {
     return launch_cfg2<BM, BN, BK, WAVES_M, WAVES_N, NSTAGE, MODE, false>(a, s);
 }
 
+// first column of the transposed last segment of a MIXED segment list on the vector epilogue (0 = not such a problem): every tile must
+// lie in one segment, so only tile widths that divide it may be chosen
+int mixed_boundary(const IGemmArgs& a) {
+    if (a.nseg < 2 || a.seg[a.nseg - 1].fmt != SEG_TRANSPOSED || !can_swap(a)) return 0;
+    return a.seg[a.nseg - 1].col_begin;
+}
+
 template <int MODE>
 int dispatch(const IGemmArgs& a, hipStream_t s) {
     const bool bk64 = (a.Cin % 64) == 0;
+    const int mb = mixed_boundary(a);
+    auto al = [&](int bn) { return mb == 0 || mb % bn == 0; };
     // Tile choice: 256x128 (8 waves) when the grid still over-fills the 256 CUs, 128x128 otherwise, 64x64 for small
     // problems.  N extents that are not multiples of 128 pay padded columns, so the waste is weighed against tile size.
-    auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.Nout + bn - 1) / bn); };
+    // (a grouped launch fills the chip with all its problems: the tile is sized for the group, unless the caller wants every problem
+    // computed with the tile it would get alone -- ctrl_group_launches(2), bit-identical to one-by-one launches)
+    const long gmul = group_tiles_as_alone() ? 1 : grp_count();
+    auto tiles = [&](int bm, int bn) { return gmul * (long)((a.M + bm - 1) / bm) * ((a.Nout + bn - 1) / bn); };
     auto eff = [&](int bn) { return (double)a.Nout / (double)(((a.Nout + bn - 1) / bn) * bn); };
     // 256x256 (8 waves, 128x64 per wave): fewest LDS bytes per FLOP -- the limiter of the smaller tiles on this chip
     // split-K: small-M / long-K problems (the ControlNet's low-resolution 3x3 convs) leave most CUs idle with 256-row
@@ -1532,6 +1622,17 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
         }
     }
     if (const char* f = getenv("CTRL_IGEMM_FORCE")) {      // tile experiments (tools/tile_experiment.py), row outputs only
+        if (can_swap(a) && MODE == IG_ROWS && a.nseg == 1 && !a.geglu) {
+            // round 5, short launches of the small-M chain (tools/gemm_order_bench small): 4-wave tiles at three workgroups per CU
+            if (!strcmp(f, "128x128x32")) return launch_cfg2<128, 128, 32, 2, 2, 3, MODE, true>(a, s);
+            if (!strcmp(f, "128x64x64") && bk64) return launch_cfg2<128, 64, 64, 2, 2, 3, MODE, true>(a, s);
+            if (!strcmp(f, "64x64x64") && bk64) return launch_cfg2<64, 64, 64, 2, 2, 3, MODE, true>(a, s);
+            if (!strcmp(f, "128x128x64") && bk64) return launch_cfg2<128, 128, 64, 2, 4, 4, MODE, true>(a, s);
+            if (!strcmp(f, "wide") && can_use8(a)) {
+                if (a.Nout % 320 == 0) return launch8<5, MODE>(a, s);
+                if (a.Nout % 256 == 0) return launch8<4, MODE>(a, s);
+            }
+        }
         if (can_swap(a) && MODE == IG_ROWS) {
             if (!strcmp(f, "128x256")) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
             if (!strcmp(f, "256x128")) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
@@ -1545,7 +1646,7 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     // run under the other's k-loop, which the one-workgroup-per-CU wide tile cannot.  GEGLU 512 -> 4096 at M = 131072: 653 (256x128
     // pair) vs 635 TFLOP/s (8-phase); stream update K = 320: 273 vs 221.  From K = 2048 on the 8-phase loop wins (815 vs 740).
     const bool force8 = igemm8_mode() == 2;
-    if (!force8 && MODE == IG_ROWS && a.M >= 65536 && can_swap(a) && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && a.Nout % 256 == 0) {
+    if (!force8 && MODE == IG_ROWS && a.M >= 65536 && can_swap(a) && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && a.Nout % 256 == 0 && al(256)) {
         const bool f32_stream = a.seg[0].dtype == DT_F32 || (a.res && a.res_f32);      // fp32 rows written and / or read per element
         if (a.geglu) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
         if (f32_stream && a.Ktot <= 1024) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
@@ -1558,37 +1659,94 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     // the 8-phase wide tiles wherever the grid fills the chip with them (1.3-1.5x the BK = 32 ring kernel on plain epilogues and
     // long k-loops: convolutions 543 -> 671 TFLOP/s as a class)
     if (can_use8(a) && (getenv("CTRL_IGEMM_FORCE") == nullptr)) {
-        if (a.Nout % 320 == 0 && (tiles(256, 320) >= 160 || force8) && !a.geglu) return launch8<5, MODE>(a, s);
-        if (a.Nout % 256 == 0 && (tiles(256, 256) >= 200 || force8)) return launch8<4, MODE>(a, s);
+        if (a.Nout % 320 == 0 && (tiles(256, 320) >= 160 || force8) && !a.geglu && al(320)) return launch8<5, MODE>(a, s);
+        if (a.Nout % 256 == 0 && (tiles(256, 256) >= 200 || force8) && al(256)) return launch8<4, MODE>(a, s);
     }
     // (vector-epilogue variant only: the scalar-epilogue one does not fit the register file at this tile size)
-    if (tiles(256, 256) >= 200 && eff(256) > 0.9 && can_swap(a)) return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s);
+    if (tiles(256, 256) >= 200 && eff(256) > 0.9 && can_swap(a) && al(256)) return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s);
     // N = 320 / 640 / 960 / 1280 / 1920 / 3840 (every conv and QKV width of the path): 256x320 tile, 128x80 per wave
-    if (a.Nout % 320 == 0 && tiles(256, 320) >= 160 && can_swap(a) && !a.geglu) return launch_cfg2<256, 320, 32, 2, 4, 4, MODE, true>(a, s);
+    if (a.Nout % 320 == 0 && tiles(256, 320) >= 160 && can_swap(a) && !a.geglu && al(320)) return launch_cfg2<256, 320, 32, 2, 4, 4, MODE, true>(a, s);
     if (!bk64) {
-        if (tiles(128, 128) >= 192) return launch_cfg<128, 128, 32, 2, 2, 3, MODE>(a, s);
+        if (tiles(128, 128) >= 192 && al(128)) return launch_cfg<128, 128, 32, 2, 2, 3, MODE>(a, s);
         return launch_cfg<64, 64, 32, 2, 2, 3, MODE>(a, s);
     }
     // (a 256x128x64 tile at two workgroups per CU stood here: every instantiation spilled inside its MFMA loop -- 128 registers do
     // not hold a 64-deep fragment set -- and the shapes it served now run on the 8-phase tiles; removed in round 4)
-    if (tiles(128, 128) >= 192 && eff(128) > 0.8) return launch_cfg<128, 128, 64, 2, 4, 4, MODE>(a, s);
+    if (tiles(128, 128) >= 192 && eff(128) > 0.8 && al(128)) return launch_cfg<128, 128, 64, 2, 4, 4, MODE>(a, s);
     if (tiles(128, 64) >= 192) return launch_cfg<128, 64, 64, 2, 2, 3, MODE>(a, s);
     return launch_cfg<64, 64, 64, 2, 2, 3, MODE>(a, s);
 }
 
 }  // namespace
 
-static int op_igemm_checked(const IGemmArgs& a, hipStream_t s);
+static int igemm_validate(const IGemmArgs& a);
+static int igemm_dispatch(const IGemmArgs& a, hipStream_t s) {
+    if (a.mode == IG_CONV2D) return dispatch<IG_CONV2D>(a, s);
+    if (a.mode == IG_TEMPORAL) return dispatch<IG_TEMPORAL>(a, s);
+    return dispatch<IG_ROWS>(a, s);
+}
 int op_igemm(const IGemmArgs& a, hipStream_t s) {
-    if (!a.nonfinite && range_check_on()) {          // debug aid: every fp16 value the epilogue writes is tested for inf / nan
-        IGemmArgs b = a;
+    if (t_collect) {                                 // lock-step replay of sibling blocks: deposited, launched by the collector's flush()
+        int rc = 0;
+        const int i = t_collect->slot(OpCollector::IGEMM, s, &rc);
+        if (i < 0) return rc;
+        t_collect->ig[i] = a;
+        return 0;
+    }
+    IGemmArgs b = a;
+    if (!b.nonfinite && range_check_on()) {          // debug aid: every fp16 value the epilogue writes is tested for inf / nan
         b.nonfinite = range_flag();
         CTRL_CHECK(b.nonfinite != nullptr, "igemm: the range check is on but its flag word could not be allocated");
-        return op_igemm_checked(b, s);
     }
-    return op_igemm_checked(a, s);
+    TRY(igemm_validate(b));
+    return igemm_dispatch(b, s);
 }
-static int op_igemm_checked(const IGemmArgs& a, hipStream_t s) {
+
+// what has to agree for two problems to share a launch: every field the dispatcher, the launch geometry and the kernels' uniform
+// branches depend on -- i.e. everything but the addresses, of which only presence and 16-byte alignment matter
+static bool igemm_same_form(const IGemmArgs& x, const IGemmArgs& y) {
+    auto pk = [](const void* p) { return p ? 1 + (int)((uintptr_t)p & 15) : 0; };
+#define SAME(f) (x.f == y.f)
+#define SAMEP(f) (pk((const void*)x.f) == pk((const void*)y.f))
+    bool ok = SAME(lda) && SAME(mode) && SAME(Cin) && SAME(taps) && SAME(Hin) && SAME(Win) && SAME(Hout) && SAME(Wout) && SAME(stride) &&
+              SAME(up) && SAME(F) && SAME(HW) && SAME(t_pad) && SAME(M) && SAME(Nout) && SAME(Ktot) && SAME(rowvec_ld) && SAME(rows_per_img) &&
+              SAME(ldres) && SAME(scale) && SAME(geglu) && SAME(nseg) && SAME(act) && SAME(res_f32) && SAME(a_split) &&
+              SAME(splitk_ws_bytes) && SAME(ld16) && SAME(ld_blend) && SAME(blend_f32) && SAME(out16_lo_off) && SAME(scale2) &&
+              SAME(scale2_from) && SAME(scale2_to) && SAME(res_up) &&
+              SAMEP(A) && SAMEP(W) && SAMEP(bias) && SAMEP(rowvec) && SAMEP(res) && SAMEP(splitk_ws) && SAMEP(out16) && SAMEP(blend_mix) &&
+              SAMEP(blend_x) && SAMEP(nonfinite);
+    for (int i = 0; ok && i < x.nseg; ++i)
+        ok = SAME(seg[i].ld) && SAME(seg[i].col_begin) && SAME(seg[i].ncols) && SAME(seg[i].fmt) && SAME(seg[i].dtype) && SAME(seg[i].L) &&
+             SAMEP(seg[i].out) && SAMEP(seg[i].img_map);
+#undef SAME
+#undef SAMEP
+    return ok;
+}
+
+int op_igemm_group(const IGemmArgs* a, int n, hipStream_t s) {
+    CTRL_CHECK(a && n >= 1 && n <= kMaxIGemmGroup, "igemm_group: 1..4 problems");
+    bool same = n > 1 && group_launches_enabled();
+    for (int i = 1; same && i < n; ++i) same = igemm_same_form(a[0], a[i]);
+    if (!same) {
+        for (int i = 0; i < n; ++i) TRY(op_igemm(a[i], s));
+        return 0;
+    }
+    IGemmArgs b[kMaxIGemmGroup];
+    for (int i = 0; i < n; ++i) {
+        b[i] = a[i];
+        if (!b[i].nonfinite && range_check_on()) {
+            b[i].nonfinite = range_flag();
+            CTRL_CHECK(b[i].nonfinite != nullptr, "igemm: the range check is on but its flag word could not be allocated");
+        }
+        TRY(igemm_validate(b[i]));
+    }
+    t_grp = b; t_grp_n = n;            // the launch functions pick the siblings up from here
+    const int rc = igemm_dispatch(b[0], s);
+    t_grp = nullptr; t_grp_n = 1;
+    return rc;
+}
+
+static int igemm_validate(const IGemmArgs& a) {
     CTRL_CHECK(a.M > 0 && a.Nout > 0 && a.Ktot > 0, "igemm: empty problem");
     CTRL_CHECK(a.Cin % 32 == 0, "igemm: Cin must be a multiple of 32 (got " + std::to_string(a.Cin) + ")");
     CTRL_CHECK(a.Ktot == a.taps * a.Cin, "igemm: Ktot != taps*Cin");
@@ -1597,8 +1755,11 @@ static int op_igemm_checked(const IGemmArgs& a, hipStream_t s) {
     CTRL_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "igemm: A/W must be 16-byte aligned");
     CTRL_CHECK(a.nseg >= 1 && a.nseg <= 3, "igemm: nseg must be 1..3");
     CTRL_CHECK(!a.geglu || (a.Nout % 32) == 0, "igemm: GEGLU needs Nout % 32 == 0");
-    CTRL_CHECK(a.scale2_from == 0 || (a.scale2_from % 16 == 0 && !a.geglu && !a.splitk_ws && a.seg[0].fmt == SEG_ROW),
-               "igemm: scale2_from must be a multiple of 16 on a plain row-major output");
+    CTRL_CHECK(a.scale2_from == 0 || (a.scale2_from % 16 == 0 && a.scale2_to % 16 == 0 && (a.scale2_to == 0 || a.scale2_to > a.scale2_from) &&
+                                      !a.geglu && !a.splitk_ws),
+               "igemm: the scale2 column range must be bounded by multiples of 16 (no GEGLU, no split-K)");
+    for (int i = 0; i + 1 < a.nseg; ++i)
+        CTRL_CHECK(a.seg[i].col_begin < a.seg[i + 1].col_begin, "igemm: segments must be listed in ascending column order");
     CTRL_CHECK(!a.out16 || (a.nseg == 1 && a.seg[0].fmt == SEG_ROW && can_swap(a)), "igemm: the fp16 mirror needs a single aligned row-major output");
     CTRL_CHECK(!a.blend_mix || (a.blend_x && a.nseg == 1 && a.seg[0].fmt == SEG_ROW && !a.geglu && can_swap(a)),
                "igemm: the blend fold needs a single aligned row-major output and an aligned blend operand");
@@ -1622,13 +1783,12 @@ static int op_igemm_checked(const IGemmArgs& a, hipStream_t s) {
     if (a.mode == IG_CONV2D) {
         CTRL_CHECK(a.taps == 9 || a.taps == 1, "igemm conv2d: taps must be 1 or 9");
         CTRL_CHECK((a.up == 1 || a.up == 2) && (a.stride == 1 || a.stride == 2), "igemm conv2d: up/stride must be 1|2");
-        return dispatch<IG_CONV2D>(a, s);
     } else if (a.mode == IG_TEMPORAL) {
         CTRL_CHECK(a.taps == 3 && a.F > 0 && a.HW > 0, "igemm temporal: taps must be 3");
-        return dispatch<IG_TEMPORAL>(a, s);
+    } else {
+        CTRL_CHECK(a.taps == 1, "igemm rows: taps must be 1");
     }
-    CTRL_CHECK(a.taps == 1, "igemm rows: taps must be 1");
-    return dispatch<IG_ROWS>(a, s);
+    return 0;
 }
 
 int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, half_t* out, long ldo,

@@ -10,6 +10,7 @@
 // (normalise + affine + optional SiLU) because one group of an SDXL-sized map (10 ch x 128x128) does not fit one
 // workgroup.
 #include "ops.h"
+#include <cstdlib>
 
 namespace {
 
@@ -31,11 +32,21 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
 // (no LDS atomics), each (image, chunk) workgroup stores its 2*G partial sums, and the last workgroup of an image to
 // arrive (ticket counter) adds the chunks in index order.  stats layout: [imgs][G][2] results | [imgs] tickets (zero on
 // entry, reset to zero on exit) | [imgs][chunks][G][2] partials.
+// Grouped launches (ops.h: OpCollector): up to four problems of one shape share a launch, problem = blockIdx.z; their pointers
+// travel as plain kernel arguments and are selected value by value (scalar selects).
+template <typename P> struct Ptr4 { P p[4]; };
+template <typename P> __device__ __forceinline__ P pick4(const Ptr4<P>& q, int z) {
+    P a = q.p[0], b = q.p[1], c = q.p[2], d = q.p[3];
+    return z == 0 ? a : (z == 1 ? b : (z == 2 ? c : d));
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_stats_kernel(Ptr4<const T*> xs, Ptr4<float*> statss,
                                                        int rows, int C, int G, int rows_per_block) {
     extern __shared__ float sh[];   // [rpi][2*C]: per (row lane, channel) sum | sumsq
     __shared__ int is_last;
+    const T* __restrict__ x = pick4(xs, blockIdx.z);
+    float* __restrict__ stats = pick4(statss, blockIdx.z);
     const int tid = threadIdx.x;
     const int lpr = C >> 3;                 // lanes per row
     const int rpi = 256 / lpr;              // rows per iteration
@@ -107,20 +118,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         is_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(chunks - 1));
     __syncthreads();
     if (!is_last) return;
-    if (tid < 2 * G) {
-        const float* pv = part_all + tid;
+    // The last workgroup adds the chunks of its image.  Round 5: by all four waves -- wave q owns the q-th quarter of the chunk list
+    // (index order inside, 8 loads in flight), the four quarter sums are added in quarter order: still one fixed order whoever
+    // arrives last.  (One wave walking 96 chunks of a 128^2 map was 12 dependent round trips to the coherence point, ~20 us of the
+    // 76 us launch: the statistics pass ran at 2.2 TB/s of its read while the apply pass streams at 4.2.)
+    {
+        const int v = tid & 63, q = tid >> 6;
+        const int cq = (chunks + 3) >> 2;
+        const int k0 = q * cq, k1 = min(chunks, k0 + cq);
         float acc = 0.f;
-        int k = 0;
-        for (; k + 8 <= chunks; k += 8) {   // 8 loads in flight, added in index order
-            float v[8];
+        if (v < 2 * G) {
+            const float* pv = part_all + v;
+            int k = k0;
+            for (; k + 8 <= k1; k += 8) {
+                float u8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                v[u] = __hip_atomic_load(pv + (size_t)(k + u) * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int u = 0; u < 8; ++u)
+                    u8[u] = __hip_atomic_load(pv + (size_t)(k + u) * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
+                for (int u = 0; u < 8; ++u) acc += u8[u];
+            }
+            for (; k < k1; ++k) acc += __hip_atomic_load(pv + (size_t)k * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        for (; k < chunks; ++k) acc += __hip_atomic_load(pv + (size_t)k * G * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        res[tid] = acc;
+        sh[q * 64 + v] = acc;            // (the per-row partial area of `sh` is dead: every thread passed the barriers above)
+        __syncthreads();
+        if (tid < 2 * G) res[tid] = ((sh[tid] + sh[64 + tid]) + sh[128 + tid]) + sh[192 + tid];
     }
     if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this buffer
 }
@@ -128,11 +150,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 // same decomposition as the statistics pass: a thread folds mean / rstd / gamma / beta of its 8 channels into one
 // (scale, shift) pair each, once, then streams its rows: y = x*scale + shift (optional SiLU)
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       half_t* __restrict__ y, int rows, int C, int G, float eps,
+__global__ __launch_bounds__(256) void gn_apply_kernel(Ptr4<const T*> xs, Ptr4<const float*> statss,
+                                                       Ptr4<const float*> gammas, Ptr4<const float*> betas,
+                                                       Ptr4<half_t*> ys, int rows, int C, int G, float eps,
                                                        int silu, int rows_per_block, long ldy, int lo_off,
                                                        float stat_rows, long y_img_rows, long y_row0) {
+    const T* __restrict__ x = pick4(xs, blockIdx.z);
+    const float* __restrict__ stats = pick4(statss, blockIdx.z);
+    const float* __restrict__ gamma = pick4(gammas, blockIdx.z);
+    const float* __restrict__ beta = pick4(betas, blockIdx.z);
+    half_t* __restrict__ y = pick4(ys, blockIdx.z);
     const int tid = threadIdx.x;
     const int lpr = C >> 3;
     const int rpi = 256 / lpr;
@@ -185,16 +212,123 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// GroupNorm of a SMALL map in one launch (round 5): a workgroup owns 80 channels (8 / 4 / 2 whole groups at C = 320 / 640 / 1280) of one
+// image -- statistics over its rows (per-thread partials through LDS slots, a fixed order: bit-reproducible), then the apply pass over the
+// same rows, which still sit in L2.  The two-kernel form above costs the low-resolution levels of the ControlNet chain two launches of
+// ~10 us for a few hundred KB; it remains the form for every map whose 80-channel slice exceeds kGnFusedBytes.
+constexpr int kGnFusedCh = 80;
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fused_kernel(Ptr4<const T*> xs, Ptr4<const float*> gammas, Ptr4<const float*> betas, Ptr4<half_t*> ys,
+                                                       int rows, int C, int cg, float eps, int silu, long ldy, int lo_off) {
+    __shared__ float sh[25][2 * kGnFusedCh];      // per (row lane, channel): sum | sum of squares
+    __shared__ float gst[8][2];                   // per group of the block: mean, rstd
+    const T* __restrict__ x = pick4(xs, blockIdx.z);
+    const float* __restrict__ gamma = pick4(gammas, blockIdx.z);
+    const float* __restrict__ beta = pick4(betas, blockIdx.z);
+    half_t* __restrict__ y = pick4(ys, blockIdx.z);
+    const int tid = threadIdx.x;
+    const int tr = tid / 10, tc = tid - tr * 10;      // 10 lanes of 8 channels per row, 25 rows per iteration
+    const int img = blockIdx.y, c0 = blockIdx.x * kGnFusedCh;
+    const T* xp = x + ((size_t)img * rows) * C + c0 + tc * 8;
+    if (tr < 25) {
+        float s[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+        int r = tr;
+        for (; r + 75 < rows; r += 100) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8<T>(xp + (size_t)(r + u * 25) * C, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = v[u][j]; s[j] += f; ss[j] += f * f; }
+        }
+        for (; r < rows; r += 25) {
+            float v[8];
+            load8<T>(xp + (size_t)r * C, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = v[j]; s[j] += f; ss[j] += f * f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sh[tr][tc * 8 + j] = s[j]; sh[tr][kGnFusedCh + tc * 8 + j] = ss[j]; }
+    }
+    __syncthreads();
+    {
+        // group g of the block = 8 lanes, fixed element -> lane assignment, fixed xor tree
+        const int g = tid >> 3, part = tid & 7, ngrp = kGnFusedCh / cg;
+        float a = 0.f, b = 0.f;
+        if (g < ngrp) {
+            const int n = cg * 25;
+            for (int e = part; e < n; e += 8) {
+                const int t = e / cg, c = g * cg + (e - t * cg);
+                a += sh[t][c];
+                b += sh[t][kGnFusedCh + c];
+            }
+        }
+#pragma unroll
+        for (int o = 4; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (g < ngrp && part == 0) {
+            const float inv_cnt = 1.0f / ((float)rows * (float)cg);
+            const float mean = a * inv_cnt;
+            const float var = fmaxf(b * inv_cnt - mean * mean, 0.f);
+            gst[g][0] = mean;
+            gst[g][1] = rsqrtf(var + eps);
+        }
+    }
+    __syncthreads();
+    if (tr >= 25) return;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cl = tc * 8 + j, g = cl / cg;
+        sc[j] = gst[g][1] * gamma[c0 + cl];
+        sf[j] = beta[c0 + cl] - gst[g][0] * sc[j];
+    }
+    half_t* yp = y + ((size_t)img * rows) * ldy + c0 + tc * 8;
+    auto emit = [&](const float (&v)[8], half_t* dst) {
+        h8 o, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = v[j] * sc[j] + sf[j];
+            if (silu) f = silu_f(f);
+            o[j] = (half_t)f;
+            l[j] = (half_t)(f - (float)o[j]);
+        }
+        *(h8*)dst = o;
+        if (lo_off) *(h8*)(dst + lo_off) = l;
+    };
+    int r = tr;
+    for (; r + 75 < rows; r += 100) {
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8<T>(xp + (size_t)(r + u * 25) * C, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) emit(v[u], yp + (size_t)(r + u * 25) * ldy);
+    }
+    for (; r < rows; r += 25) {
+        float v[8];
+        load8<T>(xp + (size_t)r * C, v);
+        emit(v, yp + (size_t)r * ldy);
+    }
+}
+
 // one wavefront per row; C <= 64*8*NCH
 // addv (optional): a per-image fp32 vector added to the row BEFORE the norm, addv[((row / rows_per_img) % vmod) * ldv + c] (the
 // frame-index embedding in front of the temporal transformer, model/adapter_spatial_temporal.py:279); the sum is also
 // written out (xsum, in x's dtype) because it is the block's residual stream -- one pass instead of add_rowvec + layernorm
 template <int NCH, typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long ldx,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        half_t* __restrict__ y, long ldy, int M, int C, float eps,
-                                                        const float* __restrict__ addv, long ldv, int rows_per_img, int vmod,
-                                                        T* __restrict__ xsum) {
+__global__ __launch_bounds__(256) void layernorm_kernel(Ptr4<const T*> xs, long ldx,
+                                                        Ptr4<const float*> gammas, Ptr4<const float*> betas,
+                                                        Ptr4<half_t*> ys, long ldy, int M, int C, float eps,
+                                                        Ptr4<const float*> addvs, long ldv, int rows_per_img, int vmod,
+                                                        Ptr4<T*> xsums) {
+    const T* __restrict__ x = pick4(xs, blockIdx.z);
+    const float* __restrict__ gamma = pick4(gammas, blockIdx.z);
+    const float* __restrict__ beta = pick4(betas, blockIdx.z);
+    half_t* __restrict__ y = pick4(ys, blockIdx.z);
+    const float* __restrict__ addv = pick4(addvs, blockIdx.z);
+    T* __restrict__ xsum = pick4(xsums, blockIdx.z);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
@@ -272,27 +406,82 @@ size_t op_gn_stats_floats(int imgs, int rows_per_img, int C, int G) {
     return (size_t)imgs * G * 2 + imgs + (chunks > 1 ? (size_t)imgs * chunks * G * 2 : 0);
 }
 
+template <typename P, typename A, typename F> static Ptr4<P> ptrs_of(const A* a, int n, F f) {
+    Ptr4<P> q;
+    for (int i = 0; i < 4; ++i) q.p[i] = (P)f(a[i < n ? i : 0]);
+    return q;
+}
+static int pk16(const void* p) { return p ? 1 + (int)((uintptr_t)p & 15) : 0; }
+
 int op_gn_stats(const void* x, int x_dtype, float* stats, int imgs, int rows_per_img, int C, int G, hipStream_t s) {
+    const GnStatsArgs a = {x, x_dtype, stats, imgs, rows_per_img, C, G};
+    if (t_collect) {
+        int rc = 0;
+        const int i = t_collect->slot(OpCollector::GN_STATS, s, &rc);
+        if (i < 0) return rc;
+        t_collect->gs[i] = a;
+        return 0;
+    }
+    return op_gn_stats_group(&a, 1, s);
+}
+
+int op_gn_stats_group(const GnStatsArgs* a, int n, hipStream_t s) {
+    CTRL_CHECK(a && n >= 1 && n <= kMaxGroup, "gn_stats_group: 1..4 problems");
+    bool same = group_launches_enabled();
+    for (int i = 1; i < n; ++i)
+        same = same && a[i].x_dtype == a[0].x_dtype && a[i].imgs == a[0].imgs && a[i].rows_per_img == a[0].rows_per_img && a[i].C == a[0].C && a[i].G == a[0].G;
+    if (n > 1 && !same) {
+        for (int i = 0; i < n; ++i) TRY(op_gn_stats_group(a + i, 1, s));
+        return 0;
+    }
+    const int x_dtype = a[0].x_dtype, imgs = a[0].imgs, rows_per_img = a[0].rows_per_img, C = a[0].C, G = a[0].G;
     CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_stats: input must be fp16 or fp32");
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_stats: C must be a multiple of 8 and of G, <= 2048");
     CTRL_CHECK(G <= 32, "gn_stats: at most 32 groups");
     // fewer, fatter workgroups than the apply pass: the last workgroup of an image adds all its chunks serially
     const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 768);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
-    PROF_WORK(0, (x_dtype == DT_F32 ? 4.0 : 2.0) * imgs * rows_per_img * C);
+    PROF_WORK(0, n * (x_dtype == DT_F32 ? 4.0 : 2.0) * imgs * rows_per_img * C);
+    if (n > 1) prof_detail("x%d", n);
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
+    const auto st = ptrs_of<float*>(a, n, [](const GnStatsArgs& q) { return q.stats; });
     if (x_dtype == DT_F32)
-        LAUNCH("gn_stats", gn_stats_kernel<float>, dim3(chunks, imgs), dim3(256), lds, s,
-               (const float*)x, stats, rows_per_img, C, G, rows_per_block);
+        LAUNCH("gn_stats", gn_stats_kernel<float>, dim3(chunks, imgs, n), dim3(256), lds, s,
+               ptrs_of<const float*>(a, n, [](const GnStatsArgs& q) { return q.x; }), st, rows_per_img, C, G, rows_per_block);
     else
-        LAUNCH("gn_stats", gn_stats_kernel<half_t>, dim3(chunks, imgs), dim3(256), lds, s,
-               (const half_t*)x, stats, rows_per_img, C, G, rows_per_block);
+        LAUNCH("gn_stats", gn_stats_kernel<half_t>, dim3(chunks, imgs, n), dim3(256), lds, s,
+               ptrs_of<const half_t*>(a, n, [](const GnStatsArgs& q) { return q.x; }), st, rows_per_img, C, G, rows_per_block);
     return 0;
 }
 
 int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, half_t* y,
                 int imgs, int rows_per_img, int C, int G, float eps, int silu, hipStream_t s, long ldy, int lo_off,
                 long stat_rows, long y_img_rows, long y_row0) {
+    const GnApplyArgs a = {x, x_dtype, stats, gamma, beta, y, imgs, rows_per_img, C, G, eps, silu, ldy, lo_off, stat_rows, y_img_rows, y_row0};
+    if (t_collect) {
+        int rc = 0;
+        const int i = t_collect->slot(OpCollector::GN_APPLY, s, &rc);
+        if (i < 0) return rc;
+        t_collect->ga[i] = a;
+        return 0;
+    }
+    return op_gn_apply_group(&a, 1, s);
+}
+
+int op_gn_apply_group(const GnApplyArgs* a, int n, hipStream_t s) {
+    CTRL_CHECK(a && n >= 1 && n <= kMaxGroup, "gn_apply_group: 1..4 problems");
+    bool same = group_launches_enabled();
+    for (int i = 1; i < n; ++i)
+        same = same && a[i].x_dtype == a[0].x_dtype && a[i].imgs == a[0].imgs && a[i].rows_per_img == a[0].rows_per_img && a[i].C == a[0].C &&
+               a[i].G == a[0].G && a[i].eps == a[0].eps && a[i].silu == a[0].silu && a[i].ldy == a[0].ldy && a[i].lo_off == a[0].lo_off &&
+               a[i].stat_rows == a[0].stat_rows && a[i].y_img_rows == a[0].y_img_rows && a[i].y_row0 == a[0].y_row0;
+    if (n > 1 && !same) {
+        for (int i = 0; i < n; ++i) TRY(op_gn_apply_group(a + i, 1, s));
+        return 0;
+    }
+    const int x_dtype = a[0].x_dtype, imgs = a[0].imgs, rows_per_img = a[0].rows_per_img, C = a[0].C, G = a[0].G, lo_off = a[0].lo_off;
+    long ldy = a[0].ldy, stat_rows = a[0].stat_rows, y_img_rows = a[0].y_img_rows;
+    const long y_row0 = a[0].y_row0;
     CTRL_CHECK(C % 8 == 0 && C % G == 0 && C / 8 <= 256, "gn_apply: C must be a multiple of 8 and of G, <= 2048");
     if (ldy == 0) ldy = C;
     if (stat_rows <= 0) stat_rows = rows_per_img;
@@ -302,15 +491,20 @@ int op_gn_apply(const void* x, int x_dtype, const float* stats, const float* gam
     const int rows_per_block = gn_rows_per_block(imgs, rows_per_img, C, 2048);
     const int chunks = (rows_per_img + rows_per_block - 1) / rows_per_block;
     CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_apply: input must be fp16 or fp32");
-    PROF_WORK(0, ((x_dtype == DT_F32 ? 6.0 : 4.0) + (lo_off ? 2.0 : 0.0)) * imgs * rows_per_img * C);
+    PROF_WORK(0, n * ((x_dtype == DT_F32 ? 6.0 : 4.0) + (lo_off ? 2.0 : 0.0)) * imgs * rows_per_img * C);
+    if (n > 1) prof_detail("x%d", n);
+    const auto st = ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.stats; });
+    const auto ga = ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.gamma; });
+    const auto be = ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.beta; });
+    const auto ys = ptrs_of<half_t*>(a, n, [](const GnApplyArgs& q) { return q.y; });
     if (x_dtype == DT_F32)
-        LAUNCH("gn_apply", gn_apply_kernel<float>, dim3(chunks, imgs), dim3(256), 0, s,
-               (const float*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block, ldy, lo_off,
-               (float)stat_rows, y_img_rows, y_row0);
+        LAUNCH("gn_apply", gn_apply_kernel<float>, dim3(chunks, imgs, n), dim3(256), 0, s,
+               ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.x; }), st, ga, be, ys, rows_per_img, C, G, a[0].eps, a[0].silu,
+               rows_per_block, ldy, lo_off, (float)stat_rows, y_img_rows, y_row0);
     else
-        LAUNCH("gn_apply", gn_apply_kernel<half_t>, dim3(chunks, imgs), dim3(256), 0, s,
-               (const half_t*)x, stats, gamma, beta, y, rows_per_img, C, G, eps, silu, rows_per_block, ldy, lo_off,
-               (float)stat_rows, y_img_rows, y_row0);
+        LAUNCH("gn_apply", gn_apply_kernel<half_t>, dim3(chunks, imgs, n), dim3(256), 0, s,
+               ptrs_of<const half_t*>(a, n, [](const GnApplyArgs& q) { return q.x; }), st, ga, be, ys, rows_per_img, C, G, a[0].eps, a[0].silu,
+               rows_per_block, ldy, lo_off, (float)stat_rows, y_img_rows, y_row0);
     return 0;
 }
 
@@ -321,27 +515,115 @@ int op_layernorm(const void* x, int x_dtype, long ldx, const float* gamma, const
 
 int op_layernorm_add(const void* x, int x_dtype, long ldx, const float* addv, long ldv, int rows_per_img, int vmod, void* xsum,
                      const float* gamma, const float* beta, half_t* y, long ldy, int M, int C, float eps, hipStream_t s) {
-    CTRL_CHECK(!addv || (xsum && rows_per_img > 0 && vmod > 0 && ldv % 4 == 0 && (((uintptr_t)addv | (uintptr_t)xsum) & 15) == 0),
-               "layernorm: the added vector needs an output for the sum, 16-byte aligned");
+    const LnArgs a = {x, x_dtype, ldx, addv, ldv, rows_per_img, vmod, xsum, gamma, beta, y, ldy, M, C, eps};
+    if (t_collect) {
+        int rc = 0;
+        const int i = t_collect->slot(OpCollector::LAYERNORM, s, &rc);
+        if (i < 0) return rc;
+        t_collect->ln[i] = a;
+        return 0;
+    }
+    return op_layernorm_group(&a, 1, s);
+}
+
+int op_layernorm_group(const LnArgs* a, int n, hipStream_t s) {
+    CTRL_CHECK(a && n >= 1 && n <= kMaxGroup, "layernorm_group: 1..4 problems");
+    bool same = group_launches_enabled();
+    for (int i = 1; i < n; ++i)
+        same = same && a[i].x_dtype == a[0].x_dtype && a[i].ldx == a[0].ldx && a[i].ldv == a[0].ldv && a[i].rows_per_img == a[0].rows_per_img &&
+               a[i].vmod == a[0].vmod && a[i].ldy == a[0].ldy && a[i].M == a[0].M && a[i].C == a[0].C && a[i].eps == a[0].eps &&
+               pk16(a[i].addv) == pk16(a[0].addv) && pk16(a[i].xsum) == pk16(a[0].xsum);
+    if (n > 1 && !same) {
+        for (int i = 0; i < n; ++i) TRY(op_layernorm_group(a + i, 1, s));
+        return 0;
+    }
+    const void* addv = a[0].addv; const void* xsum = a[0].xsum;
+    const int x_dtype = a[0].x_dtype, M = a[0].M, C = a[0].C;
+    const long ldx = a[0].ldx, ldy = a[0].ldy, ldv = a[0].ldv;
+    int rows_per_img = a[0].rows_per_img, vmod = a[0].vmod;
+    const float eps = a[0].eps;
+    for (int i = 0; i < n; ++i)
+        CTRL_CHECK(!a[i].addv || (a[i].xsum && rows_per_img > 0 && vmod > 0 && ldv % 4 == 0 && (((uintptr_t)a[i].addv | (uintptr_t)a[i].xsum) & 15) == 0),
+                   "layernorm: the added vector needs an output for the sum, 16-byte aligned");
+    (void)addv; (void)xsum;
     CTRL_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C must be a multiple of 8 and <= 2048");
     CTRL_CHECK(ldx % 8 == 0 && ldy % 8 == 0, "layernorm: leading dims must be multiples of 8");
     CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "layernorm: input must be fp16 or fp32");
-    const dim3 grid((M + 3) / 4), block(256);
-    PROF_WORK(0, ((x_dtype == DT_F32 ? 6.0 : 4.0) + (addv ? (x_dtype == DT_F32 ? 4.0 : 2.0) : 0.0)) * M * C);
+    const dim3 grid((M + 3) / 4, 1, n), block(256);
+    PROF_WORK(0, n * ((x_dtype == DT_F32 ? 6.0 : 4.0) + (a[0].addv ? (x_dtype == DT_F32 ? 4.0 : 2.0) : 0.0)) * M * C);
+    if (n > 1) prof_detail("x%d", n);
     if (!rows_per_img) rows_per_img = 1;
     if (!vmod) vmod = 1;
+    const auto ga = ptrs_of<const float*>(a, n, [](const LnArgs& q) { return q.gamma; });
+    const auto be = ptrs_of<const float*>(a, n, [](const LnArgs& q) { return q.beta; });
+    const auto ys = ptrs_of<half_t*>(a, n, [](const LnArgs& q) { return q.y; });
+    const auto av = ptrs_of<const float*>(a, n, [](const LnArgs& q) { return q.addv; });
 #define LN_LAUNCH(NCH)                                                                                              \
     do {                                                                                                            \
         if (x_dtype == DT_F32)                                                                                      \
-            LAUNCH("layernorm", (layernorm_kernel<NCH, float>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, y, ldy, M, C, eps, \
-                   addv, ldv, rows_per_img, vmod, (float*)xsum);                                                    \
+            LAUNCH("layernorm", (layernorm_kernel<NCH, float>), grid, block, 0, s,                                   \
+                   ptrs_of<const float*>(a, n, [](const LnArgs& q) { return q.x; }), ldx, ga, be, ys, ldy, M, C, eps, \
+                   av, ldv, rows_per_img, vmod, ptrs_of<float*>(a, n, [](const LnArgs& q) { return q.xsum; }));     \
         else                                                                                                        \
-            LAUNCH("layernorm", (layernorm_kernel<NCH, half_t>), grid, block, 0, s, (const half_t*)x, ldx, gamma, beta, y, ldy, M, C, eps, \
-                   addv, ldv, rows_per_img, vmod, (half_t*)xsum);                                                   \
+            LAUNCH("layernorm", (layernorm_kernel<NCH, half_t>), grid, block, 0, s,                                  \
+                   ptrs_of<const half_t*>(a, n, [](const LnArgs& q) { return q.x; }), ldx, ga, be, ys, ldy, M, C, eps, \
+                   av, ldv, rows_per_img, vmod, ptrs_of<half_t*>(a, n, [](const LnArgs& q) { return q.xsum; }));    \
     } while (0)
     if (C <= 512) LN_LAUNCH(1);
     else if (C <= 1024) LN_LAUNCH(2);
     else LN_LAUNCH(4);
 #undef LN_LAUNCH
+    return 0;
+}
+
+
+// ---- GroupNorm of a small map in one launch (gn_fused_kernel) ----
+constexpr size_t kGnFusedBytes = 512 * 1024;     // largest 80-channel slice of one image a workgroup takes (read twice: HBM, then L2)
+bool op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G) {
+    static const bool on = !(getenv("CTRL_GN_FUSED") && getenv("CTRL_GN_FUSED")[0] == '0');
+    if (!on || G != 32 || C % kGnFusedCh != 0 || (C / G) <= 0 || kGnFusedCh % (C / G) != 0 || kGnFusedCh / (C / G) > 8) return false;
+    return (size_t)rows_per_img * kGnFusedCh * (x_dtype == DT_F32 ? 4 : 2) <= kGnFusedBytes;
+}
+
+int op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* beta, half_t* y, int imgs, int rows_per_img, int C, int G,
+                float eps, int silu, hipStream_t s, long ldy, int lo_off) {
+    const GnApplyArgs a = {x, x_dtype, nullptr, gamma, beta, y, imgs, rows_per_img, C, G, eps, silu, ldy, lo_off, 0, 0, 0};
+    if (t_collect) {
+        int rc = 0;
+        const int i = t_collect->slot(OpCollector::GN_FUSED, s, &rc);
+        if (i < 0) return rc;
+        t_collect->ga[i] = a;
+        return 0;
+    }
+    return op_gn_fused_group(&a, 1, s);
+}
+
+int op_gn_fused_group(const GnApplyArgs* a, int n, hipStream_t s) {
+    CTRL_CHECK(a && n >= 1 && n <= kMaxGroup, "gn_fused_group: 1..4 problems");
+    bool same = group_launches_enabled();
+    for (int i = 1; i < n; ++i)
+        same = same && a[i].x_dtype == a[0].x_dtype && a[i].imgs == a[0].imgs && a[i].rows_per_img == a[0].rows_per_img && a[i].C == a[0].C &&
+               a[i].G == a[0].G && a[i].eps == a[0].eps && a[i].silu == a[0].silu && a[i].ldy == a[0].ldy && a[i].lo_off == a[0].lo_off;
+    if (n > 1 && !same) {
+        for (int i = 0; i < n; ++i) TRY(op_gn_fused_group(a + i, 1, s));
+        return 0;
+    }
+    const int x_dtype = a[0].x_dtype, imgs = a[0].imgs, rows = a[0].rows_per_img, C = a[0].C, G = a[0].G, lo_off = a[0].lo_off;
+    const long ldy = a[0].ldy ? a[0].ldy : C;
+    CTRL_CHECK(op_gn_fused_applies(x_dtype, rows, C, G), "gn_fused: not a small GroupNorm(32) map");
+    CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_fused: input must be fp16 or fp32");
+    CTRL_CHECK(ldy % 8 == 0 && lo_off % 8 == 0 && (lo_off == 0 || (lo_off >= C && lo_off + C <= ldy)), "gn_fused: bad split layout");
+    PROF_WORK(0, n * ((x_dtype == DT_F32 ? 6.0 : 4.0) + (lo_off ? 2.0 : 0.0)) * imgs * rows * C);     // (the second read comes from L2)
+    if (n > 1) prof_detail("x%d", n);
+    const dim3 grid(C / kGnFusedCh, imgs, n);
+    const auto ga = ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.gamma; });
+    const auto be = ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.beta; });
+    const auto ys = ptrs_of<half_t*>(a, n, [](const GnApplyArgs& q) { return q.y; });
+    if (x_dtype == DT_F32)
+        LAUNCH("gn_fused", gn_fused_kernel<float>, grid, dim3(256), 0, s, ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.x; }),
+               ga, be, ys, rows, C, C / G, a[0].eps, a[0].silu, ldy, lo_off);
+    else
+        LAUNCH("gn_fused", gn_fused_kernel<half_t>, grid, dim3(256), 0, s, ptrs_of<const half_t*>(a, n, [](const GnApplyArgs& q) { return q.x; }),
+               ga, be, ys, rows, C, C / G, a[0].eps, a[0].silu, ldy, lo_off);
     return 0;
 }

@@ -25,6 +25,12 @@ int igemm_set_order(const char* spec);
 // eligible problem (the parity tests run their small shapes through it this way), -1 back to CTRL_IGEMM8 / the default; 0 = accepted
 int igemm_set_wide(int mode);
 void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
+// Grouped launch (round 5): n <= kMaxIGemmGroup problems of the same shape and epilogue form (sibling adapter blocks of one
+// pyramid level) in ONE launch -- every problem computed exactly as it would be alone; problems that do not agree are launched one
+// by one.  See igemm.hip: IGemmGroup.
+constexpr int kMaxIGemmGroup = 4;
+constexpr int kMaxGroup = kMaxIGemmGroup;
+int op_igemm_group(const IGemmArgs* a, int n, hipStream_t s);
 // convenience: plain linear out[M][N] (fp16 row-major) = A[M][K] * W[N][K]^T + bias
 int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, half_t* out, long ldo,
               int M, int N, int K, const half_t* res, long ldres, hipStream_t s);
@@ -36,6 +42,22 @@ int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, hal
 // ------------------------------------------------------------------------------------------
 typedef ctrl_attn_desc AttnArgs;
 int op_flash_attn(const AttnArgs& a, hipStream_t s);
+int op_flash_attn_group(const AttnArgs* a, int n, hipStream_t s);      // same-shape problems in one launch (see op_igemm_group)
+// Grouped launch of the attention kernels (attention.hip, attention_d64.hip): up to kMaxGroup problems of one shape -- the attentions
+// of sibling adapter blocks -- share a launch; the descriptors travel as an array at offset 0 of the kernel-argument segment,
+// workgroup b works on problem b / per (per = the workgroups of one problem, a multiple of 8: the XCD of a workgroup stays its local
+// index & 7).  A plain launch is a group of one.
+struct AttnGroup { AttnArgs a[kMaxGroup]; };
+#define ATTN_GROUP_ARGS(gp) (((const AttnArgs*)__builtin_amdgcn_kernarg_segment_ptr())[gp])
+// descriptors of the grouped launch being dispatched (op_flash_attn_group); [0] is the problem the dispatcher sees
+extern thread_local const AttnArgs* t_attn_grp;
+extern thread_local int t_attn_grp_n;
+inline int attn_grp_count() { return t_attn_grp ? t_attn_grp_n : 1; }
+inline AttnGroup attn_grp_make(const AttnArgs& a) {
+    AttnGroup g;
+    for (int i = 0; i < attn_grp_count(); ++i) g.a[i] = t_attn_grp ? t_attn_grp[i] : a;
+    return g;
+}
 // instruction-selection variant of the head_dim-64 long-sequence kernel (attention_d64.hip); performance only
 int attn_set_variant(int v);
 
@@ -135,3 +157,45 @@ int op_pack_vec(const void* v, int dtype, float* out, int N, int geglu, hipStrea
 int op_prepare_images(const unsigned char* src, int F, int Hin, int Win, const int* hbounds, const int* hk, int hks,
                       const int* vbounds, const int* vk, int vks, unsigned char* tmp, void* out, int out_dtype,
                       int W, int H, int rep, int cfg, hipStream_t s);
+
+
+// ------------------------------------------------------------------------------------------
+// Grouped launches over sibling problems (round 5).  The adapter blocks of one pyramid level are independent and have identical
+// shapes (model/ctrl_adapter.py:181-191 simply runs them one after the other): the plan records the op sequence of every sibling and
+// replays the sequences in lock-step; while a collector is installed, the ops below deposit their arguments instead of launching,
+// and flush() launches what was deposited for one step -- as ONE grouped launch when the problems agree in shape and form,
+// one by one otherwise.  Every problem is computed exactly as it would be alone: results are bit-identical to the ungrouped forward.
+// ------------------------------------------------------------------------------------------
+struct GnStatsArgs { const void* x; int x_dtype; float* stats; int imgs, rows_per_img, C, G; };
+struct GnApplyArgs { const void* x; int x_dtype; const float* stats; const float* gamma; const float* beta; half_t* y;
+                     int imgs, rows_per_img, C, G; float eps; int silu; long ldy; int lo_off; long stat_rows, y_img_rows, y_row0; };
+struct LnArgs { const void* x; int x_dtype; long ldx; const float* addv; long ldv; int rows_per_img, vmod; void* xsum;
+                const float* gamma; const float* beta; half_t* y; long ldy; int M, C; float eps; };
+int op_gn_stats_group(const GnStatsArgs* a, int n, hipStream_t s);
+int op_gn_apply_group(const GnApplyArgs* a, int n, hipStream_t s);
+int op_layernorm_group(const LnArgs* a, int n, hipStream_t s);
+// GroupNorm(32) of a SMALL map (the 80-channel slice of one image <= 512 KB) in ONE launch: statistics + apply by the same workgroup
+// (norm.hip: gn_fused_kernel); op_gn_fused_applies says whether a problem qualifies (CTRL_GN_FUSED=0: never)
+bool op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G);
+int op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* beta, half_t* y, int imgs, int rows_per_img, int C, int G,
+                float eps, int silu, hipStream_t s, long ldy = 0, int lo_off = 0);
+int op_gn_fused_group(const GnApplyArgs* a, int n, hipStream_t s);
+
+struct OpCollector {
+    enum { NONE = 0, IGEMM, GN_STATS, GN_APPLY, LAYERNORM, ATTN, GN_FUSED };
+    int type = NONE, n = 0;
+    hipStream_t s = nullptr;
+    IGemmArgs ig[kMaxGroup];
+    GnStatsArgs gs[kMaxGroup];
+    GnApplyArgs ga[kMaxGroup];
+    LnArgs ln[kMaxGroup];
+    AttnArgs at[kMaxGroup];
+    // make room for one more problem of `type` on stream `s` (flushes what is pending when it cannot join); returns its index or -1
+    int slot(int type_, hipStream_t s_, int* rc);
+    int flush();
+};
+extern thread_local OpCollector* t_collect;
+// CTRL_GROUP=0 turns grouped launches off (every problem in its own launch, as in rounds 1-4); 2 keeps them but lets the GEMM
+// dispatcher choose the tile as if every problem ran alone (then results are bit-identical to the ungrouped forward: the tests)
+bool group_launches_enabled();
+bool group_tiles_as_alone();

@@ -35,6 +35,7 @@ struct AdapterLayerW {
 
 struct AdapterBlockW {
     int C = 0, up = 1, heads = 0;
+    bool tok_f32 = false;     // outlier channels in this block's normalisation scales: its token stream stays fp32 (ParamSink::norm_scale_spread)
     Lin rte1, rte2;           // resnet_time_embedding
     Norm norm;
     Lin proj_in, proj_out;
@@ -54,6 +55,7 @@ const int INNER = 512;   // num_attention_heads(8) * attention_head_dim(64): ada
 
 int build_block(ParamSink& ps, const std::string& pre, int C, const ctrl_adapter_config& c, int up, AdapterBlockW* b) {
     b->C = C; b->up = up; b->heads = C / 64;      // :42 -- head count = C / attention_head_dim
+    b->tok_f32 = ps.norm_scale_spread(pre + ".") > kNormSpreadGate;
     const bool sr = c.add_spatial_resnet, tr = c.add_temporal_resnet, st = c.add_spatial_transformer, tt = c.add_temporal_transformer;
     if (sr || tr) {
         TRY(ps.linear(pre + ".resnet_time_embedding.linear_1", C, C, true, false, &b->rte1));
@@ -462,7 +464,7 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             TRY(run_groupnorm(cx, b.norm, x, n, N, Lt, 1e-6f, false));
             // the spatial transformer's token stream: three residual updates on a stream that proj_in starts afresh, so it can be
             // kept in fp16 where the error budget allows (adapter_tok_f16(): measured per workload)
-            const bool tok16 = st && adapter_tok_f16() && cx.f32stream;
+            const bool tok16 = st && adapter_tok_f16() && cx.f32stream && !b.tok_f32;
             if (tok16) cx.f32stream = false;
             TV tok = stream_alloc(cx, (size_t)M * INNER, false);
             // the first LayerNorm of the spatial transformer rides on proj_in's epilogue
@@ -558,6 +560,7 @@ struct ctrl_adapter : PlanBase {
     hipStream_t side[kLanes - 1] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kLanes - 1] = {};
     size_t lane_need[kLanes] = {};
+    size_t slot_need[13] = {};                   // workspace of the block of slot i (dry pass): siblings of a group lie side by side
     int init_lanes() {
         for (int i = 0; i < kLanes - 1; ++i) {
             HIP_TRY(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
@@ -686,27 +689,20 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
         ctrl_clip_comm* cc = k.comm;
         for (int l = 0; l < ctrl_adapter::kLanes; ++l) { lane_comm[l] = cc ? cc : k.comm; if (cc) cc = cc->next_lane; }
     }
-    auto run_in_lane = [&](int lane, int slot, const AdapterBlockW& bw, const BlockPre& bp, const void* in, void* out, int h, int wd, size_t frame_elems) -> int {
-        cx.s = lane == 0 ? main_s : P->side[lane - 1];
-        a.comm = lane_comm[lane];
-        if (!cx.dry && k.in_ev) HIP_TRY(hipStreamWaitEvent(cx.s, k.in_ev[slot], 0));     // fused step: producer still running
-        cx.ar->off = lane_base[lane];
-        if (cx.dry) cx.ar->peak = lane_base[lane];
-        TRY(run_block(cx, bw, c, a, bp, in, out, h, wd));
-        TRY(fill_holes(out, frame_elems));
-        if (cx.dry) {
-            const size_t need = (cx.ar->peak - lane_base[lane] + 255) & ~(size_t)255;
-            if (need > P->lane_need[lane]) P->lane_need[lane] = need;
-        }
-        cx.s = main_s;
-        return 0;
-    };
+    // ---- jobs: one per slot that has a block, in slot order; consecutive jobs of one lane with the same (C, h, w) are SIBLINGS --
+    //      the adapters of one location (ctrl_adapter.py:119-139: three per location, equal shapes for the last two or all three;
+    //      the mid block joins the 8^2 ones).  Siblings are recorded and replayed in lock-step, so every GEMM / norm / attention of
+    //      theirs leaves as ONE grouped launch (ops.h: OpCollector): 2-4 x the tiles per launch at the 64^2 .. 8^2 levels, where
+    //      a single block fills less than the chip, and 40 % fewer launches per step.  Each sibling owns a disjoint workspace
+    //      region (sized by the dry pass: slot_need).  Bit-identical to running them one by one (CTRL_GROUP=0).
+    struct Job { int slot, lane, h, wd, C; const AdapterBlockW* bw; const BlockPre* bp; const void* in; void* out; size_t frame_elems; };
+    std::vector<Job> jobs;
     size_t bi = 0;
     for (int i = 0; i < 12; ++i) {
         const int h = std::max(k.H0 / slot_f[i], 1), wd = std::max(k.W0 / slot_f[i], 1);
         const bool has = bi < w.slot_ids.size() && w.slot_ids[bi] == i;
         if (has) {
-            TRY(run_in_lane(lane_of(slot_f[i]), i, w.blocks[bi], pre[bi], k.ins[i], k.outs[i], h, wd, (size_t)slot_c[i] * h * up * wd * up));
+            jobs.push_back({i, lane_of(slot_f[i]), h, wd, slot_c[i], &w.blocks[bi], &pre[bi], k.ins[i], k.outs[i], (size_t)slot_c[i] * h * up * wd * up});
             ++bi;
         } else {
             // torch.zeros_like(down_block_res_samples[i])  (ctrl_adapter.py:193): input-sized, not up-sampled
@@ -715,8 +711,42 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     }
     if (run_mid) {
         const int h = std::max(k.H0 / 8, 1), wd = std::max(k.W0 / 8, 1);
-        TRY(run_in_lane(lane_of(8), 12, w.mid, pre.back(), k.ins[12], k.outs[12], h, wd, (size_t)1280 * h * up * wd * up));
+        jobs.push_back({12, lane_of(8), h, wd, 1280, &w.mid, &pre.back(), k.ins[12], k.outs[12], (size_t)1280 * h * up * wd * up});
     }
+    const bool grouping = group_launches_enabled() && !k.comm;
+    size_t lane_off[ctrl_adapter::kLanes];      // dry pass: how far the chains of a lane have got inside its region (they run one after the other: max)
+    for (int l = 0; l < ctrl_adapter::kLanes; ++l) lane_off[l] = 0;
+    for (size_t j0 = 0; j0 < jobs.size();) {
+        size_t j1 = j0 + 1;
+        while (grouping && j1 < jobs.size() && j1 - j0 < (size_t)kMaxGroup && jobs[j1].lane == jobs[j0].lane && jobs[j1].C == jobs[j0].C &&
+               jobs[j1].h == jobs[j0].h && jobs[j1].wd == jobs[j0].wd) ++j1;
+        const int ng = (int)(j1 - j0), lane = jobs[j0].lane;
+        cx.s = lane == 0 ? main_s : P->side[lane - 1];
+        a.comm = lane_comm[lane];
+        OpList lists[kMaxGroup];
+        size_t off = lane_base[lane];
+        for (int g = 0; g < ng; ++g) {
+            const Job& jb = jobs[j0 + g];
+            if (!cx.dry && k.in_ev) HIP_TRY(hipStreamWaitEvent(cx.s, k.in_ev[jb.slot], 0));     // fused step: producer still running
+            cx.ar->off = off;
+            if (cx.dry) cx.ar->peak = off;
+            cx.rec = (ng > 1 && !cx.dry) ? &lists[g] : nullptr;
+            int rc = run_block(cx, *jb.bw, c, a, *jb.bp, jb.in, jb.out, jb.h, jb.wd);
+            if (!rc) rc = fill_holes(jb.out, jb.frame_elems);
+            cx.rec = nullptr;
+            if (rc) { cx.s = main_s; return rc; }
+            if (cx.dry) P->slot_need[jb.slot] = (cx.ar->peak - off + 255) & ~(size_t)255;
+            off += P->slot_need[jb.slot];
+        }
+        if (cx.dry && off - lane_base[lane] > P->lane_need[lane]) P->lane_need[lane] = off - lane_base[lane];
+        if (ng > 1 && !cx.dry) {
+            const int rc = replay_lockstep(lists, ng);
+            if (rc) { cx.s = main_s; return rc; }
+        }
+        cx.s = main_s;
+        j0 = j1;
+    }
+    (void)lane_off;
     if (!cx.dry && nl > 1) {
         for (int l = 1; l < nl; ++l) {
             HIP_TRY(hipEventRecord(P->join_ev[l - 1], P->side[l - 1]));

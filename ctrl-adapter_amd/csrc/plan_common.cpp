@@ -63,6 +63,10 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
 
 // ------------------------------------------------------------------------------------------ runners
 int run_groupnorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int imgs, int rows, float eps, bool silu, bool split) {
+    if (op_gn_fused_applies(x.dt, rows, n.C, 32)) {      // small map: statistics + apply in one launch
+        RUN(cx, op_gn_fused(x.p, x.dt, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s, split ? 2 * n.C : n.C, split ? n.C : 0));
+        return 0;
+    }
     float* st = cx.stats(op_gn_stats_floats(imgs, rows, n.C, 32));
     RUN(cx, op_gn_stats(x.p, x.dt, st, imgs, rows, n.C, 32, cx.s));
     RUN(cx, op_gn_apply(x.p, x.dt, st, n.g, n.b, y, imgs, rows, n.C, 32, eps, silu ? 1 : 0, cx.s, split ? 2 * n.C : n.C, split ? n.C : 0));
@@ -172,21 +176,30 @@ static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, con
     half_t* qk = cx.h((size_t)M * 2 * Ci);
     half_t* vt = cx.h((size_t)B * Ci * Lpad);
     if (L % 8) RUN(cx, op_fill_zero(vt, (size_t)B * Ci * Lpad * sizeof(half_t), cx.s));   // attention contract: finite pad columns
-    // Q|K leave row-major through the coalesced vector epilogue; V is written transposed ([batch][C][tokens], the
-    // attention kernel's A operand) by a second launch over the V rows of the packed weight -- one launch with mixed
-    // layouts would force the scalar epilogue on all three thirds
+    // Q | K | V in ONE launch (round 5): Q|K leave row-major through the coalesced vector epilogue, V transposed ([batch][C][tokens],
+    // the attention kernel's A operand) through the LDS-transposed one -- a tile lies in one segment because the dispatcher only
+    // picks tile widths that divide 2 * Ci (ctrl_igemm_desc::seg), so the activation panel is read once instead of twice and the
+    // grid has 1.5 x the tiles of the Q|K launch.  CTRL_QKV_ONE=0: the two launches of rounds 1-4 (bit-identical results).
+    static const bool qkv_one = !(getenv("CTRL_QKV_ONE") && getenv("CTRL_QKV_ONE")[0] == '0');
     IGemmArgs g = {};
     g.A = xn; g.lda = dim; g.mode = IG_ROWS; g.Cin = dim; g.taps = 1;
     g.W = w.qkv.w; g.M = M; g.Nout = 2 * Ci; g.Ktot = dim; g.scale = 1.f;
-    g.scale2_from = Ci; g.scale2 = attn_k_scale(w.D);          // the K half leaves pre-scaled for the attention kernel
+    g.scale2_from = Ci; g.scale2_to = 2 * Ci; g.scale2 = attn_k_scale(w.D);      // the K third leaves pre-scaled for the attention kernel
     g.nseg = 1;
     g.seg[0] = IGemmSeg{qk, 2 * Ci, 0, 2 * Ci, SEG_ROW, DT_F16, 1, 0};
-    RUN(cx, op_igemm(g, cx.s));
-    IGemmArgs gv = g;
-    gv.scale2_from = 0; gv.scale2 = 0.f;
-    gv.W = w.qkv.w + (size_t)2 * Ci * dim; gv.Nout = Ci;
-    gv.seg[0] = IGemmSeg{vt, Lpad, 0, Ci, SEG_TRANSPOSED, DT_F16, L, 0};
-    RUN(cx, op_igemm(gv, cx.s));
+    if (qkv_one && (2 * Ci) % 64 == 0 && L % 8 == 0 && Lpad % 8 == 0 && M % 8 == 0) {
+        g.Nout = 3 * Ci;
+        g.nseg = 2;
+        g.seg[1] = IGemmSeg{vt, Lpad, 2 * Ci, Ci, SEG_TRANSPOSED, DT_F16, L, 0};
+        RUN(cx, op_igemm(g, cx.s));
+    } else {
+        RUN(cx, op_igemm(g, cx.s));
+        IGemmArgs gv = g;
+        gv.scale2_from = 0; gv.scale2_to = 0; gv.scale2 = 0.f;
+        gv.W = w.qkv.w + (size_t)2 * Ci * dim; gv.Nout = Ci;
+        gv.seg[0] = IGemmSeg{vt, Lpad, 0, Ci, SEG_TRANSPOSED, DT_F16, L, 0};
+        RUN(cx, op_igemm(gv, cx.s));
+    }
     half_t* o = cx.h((size_t)M * Ci);
     TRY(run_attention(cx, qk, 2 * Ci, qk + Ci, 2 * Ci, vt, Lpad, o, Ci, B, B, w.heads, w.D, L, L));
     TRY(run_linear(cx, w.out, o, Ci, out, dim, M, resid, dim, addvec, dim, addvec_rows, nullptr, TV(), ln_next, ln_out));
@@ -223,17 +236,28 @@ int project_text_kv(Ctx& cx, const AttnW& w, const EhsCtx& e, PreKV* out) {
     }
     if (!(cached && cx.kvc->mode == KvCache::REUSE)) {
         if (e.Lk % 8) RUN(cx, op_fill_zero(vt, (size_t)e.batch * Ci * Lkpad * sizeof(half_t), cx.s));   // finite pad columns
+        // K | V^T of the text states in ONE launch (round 5; 77 tokens per prompt are not a multiple of 8, so the mixed segment list
+        // takes the scalar epilogue -- as the V launch always did; these GEMMs have 616 rows): K pre-scaled, V plain
+        static const bool kv_one = !(getenv("CTRL_QKV_ONE") && getenv("CTRL_QKV_ONE")[0] == '0');
         IGemmArgs g = {};
         g.A = e.h16; g.lda = e.cross; g.mode = IG_ROWS; g.Cin = e.cross; g.taps = 1;
         g.W = w.kv.w; g.M = Mk; g.Nout = Ci; g.Ktot = e.cross; g.scale = attn_k_scale(w.D);     // pre-scaled K
         g.nseg = 1;
         g.seg[0] = IGemmSeg{k, Ci, 0, Ci, SEG_ROW, DT_F16, 1, 0};
-        RUN(cx, op_igemm(g, cx.s));
-        IGemmArgs gv = g;
-        gv.scale = 1.f;
-        gv.W = w.kv.w + (size_t)Ci * e.cross;
-        gv.seg[0] = IGemmSeg{vt, Lkpad, 0, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
-        RUN(cx, op_igemm(gv, cx.s));
+        if (kv_one && Ci % 64 == 0) {
+            g.Nout = 2 * Ci;
+            g.scale2_from = Ci; g.scale2_to = 0; g.scale2 = 1.f;
+            g.nseg = 2;
+            g.seg[1] = IGemmSeg{vt, Lkpad, Ci, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
+            RUN(cx, op_igemm(g, cx.s));
+        } else {
+            RUN(cx, op_igemm(g, cx.s));
+            IGemmArgs gv = g;
+            gv.scale = 1.f;
+            gv.W = w.kv.w + (size_t)Ci * e.cross;
+            gv.seg[0] = IGemmSeg{vt, Lkpad, 0, Ci, SEG_TRANSPOSED, DT_F16, e.Lk, 0};
+            RUN(cx, op_igemm(gv, cx.s));
+        }
     }
     out->k = k; out->vt = vt;
     return 0;

@@ -6,6 +6,7 @@
 //   * block runners (GroupNorm+SiLU, ResnetBlock2D, BasicTransformerBlock, ...) that enqueue the HIP kernels
 #pragma once
 #include "ops.h"
+#include <algorithm>
 #include <cstdlib>
 #include <functional>
 #include <string>
@@ -37,7 +38,14 @@ struct ParamSink {
     virtual int scalar(const std::string& name, float** out) = 0;
     // raw fp32 copy of a small tensor (router weights ...)
     virtual int raw_f32(const std::string& name, const std::vector<int64_t>& shape, float** out) = 0;
+    // spread of the normalisation scales under `prefix`: max over its GroupNorm / LayerNorm weights of max|gamma| / median|gamma|
+    // (0 = unknown: the parameter inventory pass).  Outlier channels in a trained checkpoint's norm scales are what the precision
+    // selections of the path (fp16 adapter token stream, plain operands for the ControlNet's low-resolution 3x3 convolutions) are
+    // least robust to (tests/test_gpu_e2e.py::test_weight_distribution_sweep_sdxl_chain): the plans fall back to the conservative
+    // selection where the spread exceeds kNormSpreadGate.
+    virtual float norm_scale_spread(const std::string& prefix) { (void)prefix; return 0.f; }
 };
+constexpr float kNormSpreadGate = 4.0f;
 
 struct SpecCollector : ParamSink {
     std::vector<SpecEntry> entries;
@@ -193,6 +201,45 @@ struct Packer : ParamSink {
         TRY(dalloc(sizeof(float), (void**)out));
         return vec(name, 1, false, *out);
     }
+    // load-time scan of every 1-D "...norm....weight" tensor (converted on the device, read back once: plan creation only)
+    std::unordered_map<std::string, float> spread_by_name;
+    bool spread_scanned = false;
+    void scan_norm_scales() {
+        spread_scanned = true;
+        size_t maxc = 0;
+        std::vector<const ctrl_tensor_ref*> ts;
+        for (const auto& kv : map) {
+            const std::string& n = kv.first;
+            const ctrl_tensor_ref* t = kv.second;
+            if (t->ndim != 1 || !t->data || n.size() < 7 || n.compare(n.size() - 7, 7, ".weight") != 0 || n.find("norm") == std::string::npos) continue;
+            ts.push_back(t);
+            if ((size_t)t->shape[0] > maxc) maxc = (size_t)t->shape[0];
+        }
+        if (ts.empty()) return;
+        float* tmp = nullptr;
+        if (hipMalloc((void**)&tmp, maxc * sizeof(float)) != hipSuccess) return;
+        std::vector<float> h(maxc);
+        for (const ctrl_tensor_ref* t : ts) {
+            const int C = (int)t->shape[0];
+            if (op_pack_vec(t->data, t->dtype, tmp, C, 0, s) != 0) continue;
+            if (hipMemcpyAsync(h.data(), tmp, (size_t)C * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) continue;
+            if (hipStreamSynchronize(s) != hipSuccess) continue;
+            std::vector<float> a(h.begin(), h.begin() + C);
+            float mx = 0.f;
+            for (float& v : a) { v = v < 0 ? -v : v; if (v > mx) mx = v; }
+            std::nth_element(a.begin(), a.begin() + C / 2, a.end());
+            const float med = a[C / 2];
+            spread_by_name[t->name] = med > 0.f ? mx / med : (mx > 0.f ? 1e9f : 1.f);
+        }
+        (void)hipFree(tmp);
+    }
+    float norm_scale_spread(const std::string& prefix) override {
+        if (!spread_scanned) scan_norm_scales();
+        float worst = 0.f;
+        for (const auto& kv : spread_by_name)
+            if (kv.first.compare(0, prefix.size(), prefix) == 0 && kv.second > worst) worst = kv.second;
+        return worst;
+    }
     int raw_f32(const std::string& name, const std::vector<int64_t>& shape, float** out) override {
         const ctrl_tensor_ref* t;
         TRY(get(name, shape, &t));
@@ -321,11 +368,16 @@ struct KvCache {
     }
 };
 
+// Recorded op sequence of one sibling block (grouped launches, ops.h: OpCollector): while Ctx::rec is set, RUN() appends the op as a
+// closure instead of enqueueing it; replay_lockstep() then runs the sequences of the siblings position by position.
+struct OpList { std::vector<std::function<int()>> ops; };
+
 // Execution context: `dry` = sizing pass (allocations only advance the offset, nothing is launched).
 struct Ctx {
     Arena* ar;
     hipStream_t s;
     bool dry;
+    OpList* rec = nullptr;     // record instead of launching (see OpList)
     bool f32stream = true;     // residual streams kept in fp32 (set from CTRL_STREAM_F32, default on)
     bool split = false;        // GEMM-operand mirrors of the streams are split [hi | lo] rows (ControlNet, CTRL_CN_SPLIT)
     bool h1_f16 = false;       // a ResNet's conv1 output (read by GroupNorm only) in fp16 instead of the stream dtype (adapter, adapter_h1_f16())
@@ -352,7 +404,37 @@ struct Ctx {
         return p;
     }
 };
-#define RUN(cx, expr) do { if (!(cx).dry) TRY(expr); } while (0)
+// (the closure copies what the expression names -- the context with its stream, descriptors, pointers: everything an op call takes
+// is a value or a pointer into plan-owned memory that outlives the forward)
+#define RUN(cx, expr)                                                                      \
+    do {                                                                                   \
+        if (!(cx).dry) {                                                                   \
+            if ((cx).rec) (cx).rec->ops.push_back([=]() -> int { return (expr); });        \
+            else TRY(expr);                                                                \
+        }                                                                                  \
+    } while (0)
+// Replays n recorded sequences in lock-step: position k of every sibling is issued with a collector installed, so that the ops of the
+// grouped kinds (implicit GEMM, GroupNorm, LayerNorm, attention) deposit their arguments and leave as ONE launch per position when
+// the siblings agree; every other op is enqueued as it comes.  Sequences of different lengths are replayed one after the other.
+inline int replay_lockstep(OpList* lists, int n) {
+    bool same = true;
+    for (int i = 1; i < n; ++i) same = same && lists[i].ops.size() == lists[0].ops.size();
+    if (!same || n == 1) {
+        for (int i = 0; i < n; ++i)
+            for (auto& f : lists[i].ops) TRY(f());
+        return 0;
+    }
+    OpCollector col;
+    for (size_t k = 0; k < lists[0].ops.size(); ++k) {
+        t_collect = &col;
+        int rc = 0;
+        for (int i = 0; i < n && !rc; ++i) rc = lists[i].ops[k]();
+        if (!rc) rc = col.flush();
+        t_collect = nullptr;
+        if (rc) return rc;
+    }
+    return 0;
+}
 // first call of every forward body: carve (real pass) the pooled GroupNorm statistics and zero them once
 inline int begin_forward(Ctx& cx) {
     if (!cx.dry) {

@@ -135,7 +135,11 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
 
     std::vector<std::string> temb_names;
     std::vector<int> temb_ns;
-    const int levels = cn_split_levels(), res_levels = cn_split_resnet_levels();
+    // per-conv selection of the split operands; a checkpoint whose normalisation scales have outlier channels keeps them on every level
+    // the 1x1 convolutions take them on (ParamSink::norm_scale_spread)
+    const int levels = cn_split_levels();
+    const bool outliers = ps.norm_scale_spread("") > kNormSpreadGate && !getenv("CTRL_CN_SPLIT_RESNET_LEVELS");
+    const int res_levels = outliers ? levels : cn_split_resnet_levels();
     auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r, bool dup_r, int dup_sc = -1) -> int {
         TRY(build_resnet(ps, pre, Cin, Cout, false, r, dup_r, dup_sc));
         r->temb_off = w->temb_total;

@@ -58,7 +58,7 @@ def pack_vec(v, geglu=False):
 def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, rowvec=None, rows_per_img=1,
           res=None, ldres=0, scale=1.0, geglu=False, segs=None, F=0, HW=0, out16=None, ld16=0, splitk_ws=None,
           blend_mix=None, blend_x=None, ld_blend=0, a_split=False, out16_lo_off=0, t_pad=False, scale2=0.0, scale2_from=0,
-          res_up=0):
+          res_up=0, scale2_to=0):
     """segs: list of (out_tensor, ld, col_begin, ncols, fmt, L); res_up=2: `res` is [N][Hout/2][Wout/2][ldres], read through a
     nearest x2 up-sampling (conv2d)"""
     d = L.IGemmDesc()
@@ -85,7 +85,7 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     d.ld_blend = ld_blend
     d.blend_f32 = int(blend_x is not None and blend_x.dtype == torch.float32)
     d.scale = scale; d.geglu = int(geglu)
-    d.scale2 = scale2; d.scale2_from = scale2_from
+    d.scale2 = scale2; d.scale2_from = scale2_from; d.scale2_to = scale2_to
     d.a_split = int(a_split); d.out16_lo_off = out16_lo_off      # a_split: 0 | 1 (weights packed twice) | 2 (paired walk)
     d.nseg = len(segs)
     for i, (out, ld, cb, nc, fmt, Ltok) in enumerate(segs):
@@ -105,6 +105,13 @@ def set_igemm_wide(mode):
     """which GEMM / convolution problems run on the 8-phase wide-tile kernel: 0 none, 1 where the grid fills the chip (default), 2 every
     eligible problem (tests), -1 back to the default (csrc/igemm.hip)"""
     L.check(L.lib().ctrl_igemm_set_wide(int(mode)))
+
+
+def set_group_launches(mode):
+    """grouped launches over the sibling adapter blocks of a pyramid level (csrc/ops.h: OpCollector): 1 / True on (default), 2 on with
+    the tile selection every problem would get alone (bit-identical to the one-by-one forward), 0 / False off, None queries; returns
+    the mode."""
+    return int(L.lib().ctrl_group_launches(-1 if mode is None else int(mode)))
 
 
 def set_attn_variant(v):
@@ -179,6 +186,18 @@ def groupnorm(x, gamma, beta, imgs, rows_per_img, G=32, eps=1e-5, silu=False):
     L.check(lib.ctrl_op_gn_stats(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), imgs, rows_per_img, Cc, G, L.cur_stream()))
     L.check(lib.ctrl_op_gn_apply(L.ptr(x), L.dtype_code(x.dtype), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(y), imgs, rows_per_img, Cc, G,
                                  C.c_float(eps), int(silu), L.cur_stream()))
+    return y
+
+
+def groupnorm_fused(x, gamma, beta, imgs, rows_per_img, G=32, eps=1e-5, silu=False, split=False):
+    """GroupNorm(32) of a small map in one launch (csrc/norm.hip: gn_fused_kernel); None when the problem does not qualify"""
+    Cc = x.shape[-1]
+    lib = L.lib()
+    if not lib.ctrl_op_gn_fused_applies(L.dtype_code(x.dtype), rows_per_img, Cc, G):
+        return None
+    y = torch.empty(tuple(x.shape[:-1]) + ((2 * Cc) if split else Cc,), dtype=torch.float16, device=x.device)
+    L.check(lib.ctrl_op_gn_fused(L.ptr(x), L.dtype_code(x.dtype), L.ptr(gamma), L.ptr(beta), L.ptr(y), C.c_int64(2 * Cc if split else Cc),
+                                 Cc if split else 0, imgs, rows_per_img, Cc, G, C.c_float(eps), int(silu), L.cur_stream()))
     return y
 
 

@@ -92,12 +92,16 @@ typedef struct ctrl_igemm_desc {
      * only: out = (1-a) * y + a * blend_x[m*ld_blend + n], a = sigmoid(*blend_mix), y = the epilogue result above */
     const float* blend_mix; const void* blend_x; int64_t ld_blend; int32_t blend_f32;
     int32_t out16_lo_off;   /* > 0: the fp16 mirror is a split operand, out16[m*ld16 + n] = hi, out16[m*ld16 + out16_lo_off + n] = lo */
-    float scale2; int32_t scale2_from;   /* scale2_from > 0: output columns >= scale2_from are multiplied by scale2 instead of scale
-                                            (row-major outputs): the K half of a Q|K projection leaves pre-multiplied by
+    float scale2; int32_t scale2_from;   /* scale2_from > 0: output columns scale2_from <= n < scale2_to are multiplied by scale2 instead
+                                            of scale: the K third of a Q|K|V projection leaves pre-multiplied by
                                             softmax_scale * log2(e) for ctrl_attn_desc::k_prescaled */
     int32_t res_up;     /* 2: conv2d only -- `res` holds [img][Hout/2][Wout/2][ldres] and is read through a nearest x2 up-sampling
                            (res[img][oy/2][ox/2]); 0 | 1: res[m*ldres + n] */
-    int32_t pad2_;
+    int32_t scale2_to;  /* end of the scale2 column range (0 = Nout) */
+    /* Output segments (1..3, ascending col_begin).  Mixed layouts -- row-major segments followed by ONE transposed last segment,
+       the Q | K | V^T outputs of a self-attention projection in one launch -- run on the vector epilogue when the transposed
+       segment starts at a multiple of 64 columns (the dispatcher then only picks tiles whose width divides that boundary, so
+       every tile lies in one segment); anything else takes the scalar epilogue. */
     ctrl_igemm_seg seg[3];
     int32_t* nonfinite;  /* optional (device): set to 1 when an fp16 value this launch writes is inf / nan, i.e. an activation left the
                             fp16 range (|x| > 65504).  NULL = no check; op_igemm fills it in itself while the range check is on
@@ -124,6 +128,13 @@ int ctrl_igemm_set_order(const char* spec);
    kernel families share one epilogue and the same accumulation order inside a k-tile; results may differ in the last fp32 bit
    between families (different k-tile depth).  0 = accepted. */
 int ctrl_igemm_set_wide(int mode);
+/* Grouped launches (csrc/ops.h: OpCollector): the sibling adapter blocks of one pyramid level -- equal shapes, independent
+   (model/ctrl_adapter.py:181-191) -- are replayed in lock-step and every GEMM / GroupNorm / LayerNorm / attention of theirs leaves as
+   ONE launch over 2-4 problems.  1 (default; also CTRL_GROUP) on: the GEMM dispatcher sizes its tile for the whole group (a 32^2 level
+   reaches the wide tile), so results equal the one-by-one forward within the tile families' last-bit differences, like another batch
+   size; 2 on with the tile every problem would get alone: bit-identical to the one-by-one forward; 0 off; -1 queries.  Returns the
+   mode.  Every mode is bit-reproducible run to run. */
+int ctrl_group_launches(int on);
 int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
 
 typedef struct ctrl_attn_desc {
@@ -169,6 +180,12 @@ int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float
 /* split-operand variant: y rows are [hi | lo] (row stride ldy, lo at column offset lo_off), hi + lo = the fp32 result to ~2^-22 */
 int ctrl_op_gn_apply_split(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                            int64_t ldy, int lo_off, int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
+/* GroupNorm(32) of a small map in ONE launch (statistics + apply by the same workgroup; what the plans use whenever the 80-channel
+ * slice of one image is at most 512 KB): ldy = row stride of y (0 = C), lo_off > 0 = split [hi | lo] result as above.  Fails
+ * when the problem does not qualify (ctrl_op_gn_fused_applies == 0). */
+int ctrl_op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G);
+int ctrl_op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int64_t ldy, int lo_off,
+                     int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
 int ctrl_op_layernorm(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                       int M, int C, float eps, void* stream);
 int ctrl_op_nchw_to_nhwc(const void* x, int dtype, void* y, int N, int C, int HW, void* stream);

@@ -668,3 +668,57 @@ def test_range_check_flags_an_activation_beyond_fp16(ops, gpu):
     finally:
         ops.set_igemm_wide(-1)
         lib.ctrl_range_check(0)
+
+
+@pytest.mark.parametrize("B,Ltok,K,Cc,wide", [(4, 1024, 512, 320, 2), (4, 1024, 512, 320, 1), (2, 256, 512, 1280, 1), (8, 64, 1280, 1280, 1),
+                                              (2, 4096, 320, 320, 2), (3, 136, 512, 640, 1)])
+def test_qkv_one_launch_is_bit_identical_to_two(ops, gpu, B, Ltok, K, Cc, wide):
+    """Round 5: Q | K | V^T of a self-attention projection in ONE launch on the vector epilogue (row-major Q|K segment + transposed V
+    segment: ctrl_igemm_desc::seg) -- the same values bit for bit as the Q|K launch + the V launch of rounds 1-4, K pre-scaled through
+    the bounded scale2 range (scale2_from / scale2_to).  wide = 2 forces the 8-phase tile, 1 leaves the dispatcher alone (ring tiles
+    for the small grids: 128- and 64-wide tiles divide 2 * Cc)."""
+    M = B * Ltok
+    x = rnd(M, K, seed=1).half().to(gpu)
+    w = rnd(3 * Cc, K, seed=2, scale=0.05)
+    wp = ops.pack_linear_w(w.to(gpu))
+    Lpad = (Ltok + 63) // 64 * 64
+    ks = 1.4426950408889634 / math.sqrt(64.0)
+    ops.set_igemm_wide(wide)
+    try:
+        qk1 = torch.zeros(M, 2 * Cc, dtype=torch.float16, device=gpu)
+        vt1 = torch.zeros(B, Cc, Lpad, dtype=torch.float16, device=gpu)
+        ops.igemm(x, K, wp, M, 3 * Cc, K, scale2=ks, scale2_from=Cc, scale2_to=2 * Cc,
+                  segs=[(qk1, 2 * Cc, 0, 2 * Cc, ops.SEG_ROW, 1), (vt1, Lpad, 2 * Cc, Cc, ops.SEG_TRANSPOSED, Ltok)])
+        qk2 = torch.zeros_like(qk1)
+        vt2 = torch.zeros_like(vt1)
+        ops.igemm(x, K, wp, M, 2 * Cc, K, scale2=ks, scale2_from=Cc, segs=[(qk2, 2 * Cc, 0, 2 * Cc, ops.SEG_ROW, 1)])
+        ops.igemm(x, K, wp[2 * Cc:], M, Cc, K, segs=[(vt2, Lpad, 0, Cc, ops.SEG_TRANSPOSED, Ltok)])
+    finally:
+        ops.set_igemm_wide(-1)
+    ref = x.float().cpu() @ w.t()
+    ref[:, Cc:2 * Cc] *= ks
+    report("qkv one launch q|k (B%d L%d C%d)" % (B, Ltok, Cc), rel_inf(qk1, ref[:, :2 * Cc]))
+    report("qkv one launch v^T", rel_inf(vt1[:, :, :Ltok], ref[:, 2 * Cc:].reshape(B, Ltok, Cc).permute(0, 2, 1)))
+    assert torch.equal(qk1, qk2) and torch.equal(vt1, vt2)
+    assert vt1[:, :, Ltok:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("Cc,hw,silu,n", [(320, 32 * 32, True, 3), (640, 16 * 16, False, 2), (1280, 64, True, 8), (1280, 7 * 9, False, 2),
+                                          (640, 32 * 32, True, 2), (320, 100, False, 1)])
+def test_groupnorm_fused_small_maps(ops, gpu, Cc, hw, silu, n):
+    """Round 5: statistics + apply of a small GroupNorm(32) map in ONE launch (gn_fused_kernel: a workgroup owns 80 channels = 8 / 4 / 2
+    whole groups of one image).  Against torch's group_norm, fp16 and fp32 inputs, plain and split [hi | lo] results; the large map
+    of test_groupnorm does not qualify and stays on the two-kernel form."""
+    x = rnd(n, hw, Cc, seed=1) * 1.7 + 0.5
+    g, b = rnd(Cc, seed=2) + 1.0, rnd(Cc, seed=3)
+    ref = F.group_norm(x.permute(0, 2, 1), 32, g, b, eps=1e-6).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    for xin in (x.half().to(gpu), x.to(gpu)):
+        out = ops.groupnorm_fused(xin, g.to(gpu), b.to(gpu), n, hw, eps=1e-6, silu=silu)
+        assert out is not None
+        report("groupnorm fused C%d hw%d (%s in)" % (Cc, hw, str(xin.dtype)[6:]), rel_inf(out, ref))
+        sp = ops.groupnorm_fused(xin, g.to(gpu), b.to(gpu), n, hw, eps=1e-6, silu=silu, split=True)
+        assert torch.equal(sp[..., :Cc], out)
+        report("groupnorm fused split hi+lo", rel_inf(sp[..., :Cc].float() + sp[..., Cc:].float(), ref), 2e-5 if xin.dtype == torch.float32 else 2e-5)
+    assert ops.groupnorm_fused(torch.zeros(1, 128 * 128, 320, dtype=torch.float32, device=gpu), g[:320].to(gpu), b[:320].to(gpu), 1, 128 * 128) is None

@@ -299,7 +299,7 @@ static int check() {
 // The path's heaviest GEMM / convolution shapes with their real epilogue kinds (profiles/r0N_per_kernel_*.json), random
 // operands, median of 9 launches each -- the table the round-4 review's "done" criteria read (M131072 N512 K2048, M32768 N640
 // K5760 taps9, M131072 N4096 K512 geglu, ...).  `CTRL_IGEMM8=0 gemm_order_bench out.txt shapes` times the round-3 kernels.
-static int shapes_mode() {
+static int shapes_mode(bool small = false) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -326,8 +326,33 @@ static int shapes_mode() {
         {"ControlNet ff1 geglu 640->5120 @32^2", 8192, 5120, 640, 1, 0, 0},
         {"plain 2048-deep operand out", 131072, 512, 2048, 3, 0, 0},
     };
-    say("\npath shapes (median of 9, random fp16 operands; TFLOP/s = algorithmic 2 M N K / t)\n");
-    for (const S& sh : ss) {
+    // `small`: the short launches of the ControlNet chain at b = 8 and of the 64^2 / 32^2 adapter levels (M = 32768 .. 512), where a
+    // launch is a few waves of tiles: the tile experiments of round 5 (CTRL_IGEMM_FORCE=<tile> gemm_order_bench out.txt small)
+    const S sm[] = {
+        {"q proj 512->320 @128^2", 131072, 320, 512, 0, 0, 0},
+        {"CN proj 320->320 @64^2", 32768, 320, 320, 0, 0, 0},
+        {"CN q|k|v 320->960 @64^2", 32768, 960, 320, 0, 0, 0},
+        {"CN attn out 320->320 stream @64^2", 32768, 320, 320, 2, 0, 0},
+        {"CN ff2 1280->320 stream @64^2", 32768, 320, 1280, 2, 0, 0},
+        {"adapter q|k|v 512->1920 @64^2", 32768, 1920, 512, 0, 0, 0},
+        {"adapter attn out 640->512 @64^2", 32768, 512, 640, 3, 0, 0},
+        {"CN proj 640->640 @32^2", 8192, 640, 640, 0, 0, 0},
+        {"CN q|k|v 640->1920 @32^2", 8192, 1920, 640, 0, 0, 0},
+        {"CN attn out 640->640 stream @32^2", 8192, 640, 640, 2, 0, 0},
+        {"CN ff2 2560->640 stream @32^2", 8192, 640, 2560, 2, 0, 0},
+        {"adapter q|k|v 512->3840 @32^2", 8192, 3840, 512, 0, 0, 0},
+        {"CN q|k|v 1280->3840 @16^2", 2048, 3840, 1280, 0, 0, 0},
+        {"CN attn out 1280->1280 stream @16^2", 2048, 1280, 1280, 2, 0, 0},
+        {"CN ff2 5120->1280 stream @16^2", 2048, 1280, 5120, 2, 0, 0},
+        {"CN attn out 1280->1280 stream @8^2", 512, 1280, 1280, 2, 0, 0},
+        {"CN ff1 geglu 1280->10240 @8^2", 512, 10240, 1280, 1, 0, 0},
+    };
+    say("\npath shapes (median of 9, random fp16 operands; TFLOP/s = algorithmic 2 M N K / t)%s%s\n", getenv("CTRL_IGEMM_FORCE") ? "  CTRL_IGEMM_FORCE=" : "",
+        getenv("CTRL_IGEMM_FORCE") ? getenv("CTRL_IGEMM_FORCE") : "");
+    const S* list = small ? sm : ss;
+    const int nlist = small ? (int)(sizeof(sm) / sizeof(sm[0])) : (int)(sizeof(ss) / sizeof(ss[0]));
+    for (int li = 0; li < nlist; ++li) {
+        const S& sh = list[li];
         const int on = sh.kind == 1 ? sh.N / 2 : sh.N;
         const bool conv = sh.kind == 5;
         const int cin = conv ? sh.K / 9 : sh.K;
@@ -397,6 +422,7 @@ int main(int argc, char** argv) {
     if (argc > 2 && !strcmp(argv[2], "stores")) return stores();
     if (argc > 2 && !strcmp(argv[2], "check")) return check();
     if (argc > 2 && !strcmp(argv[2], "shapes")) return shapes_mode();
+    if (argc > 2 && !strcmp(argv[2], "small")) return shapes_mode(true);
     std::vector<Shape> shapes = {
         {"geglu 512->4096 @128^2 x8", 131072, 4096, 512, true, false, {"legacy", "auto", "m,8", "m,16", "m,4", "n,0"}},
         {"geglu 512->4096 @64^2 x8", 32768, 4096, 512, true, false, {"legacy", "auto", "m,8", "m,16", "n,0"}},
