@@ -79,6 +79,10 @@ int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const floa
                            int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, void* stream) {
     return op_conv3x3_direct(in, in_dtype, in_nchw, w, bias, H(out), N, Cin, Cout, Hin, Win, stride, silu, S(stream));
 }
+int ctrl_op_conv3x3_small_mfma(const void* x, const void* w, const float* bias, void* out, int N, int Cin, int Cout, int Hin, int Win,
+                               int stride, int silu, void* stream) {
+    return op_conv3x3_small_mfma((const half_t*)x, (const half_t*)w, bias, H(out), N, Cin, Cout, Hin, Win, stride, silu, S(stream));
+}
 int ctrl_op_pack_conv_w(const void* w, int dtype, void* out, int Cout, int Cin, int taps, void* stream) {
     return op_pack_conv_w(w, dtype, H(out), Cout, Cin, taps, S(stream));
 }

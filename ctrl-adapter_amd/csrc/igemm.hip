@@ -1672,6 +1672,16 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     }
     // (a 256x128x64 tile at two workgroups per CU stood here: every instantiation spilled inside its MFMA loop -- 128 registers do
     // not hold a 64-deep fragment set -- and the shapes it served now run on the 8-phase tiles; removed in round 4)
+    // Short launches of the small-M chains (the ControlNet at b = 8, the 64^2 .. 8^2 adapter levels: a few waves of tiles, k-loops of
+    // 5 .. 40 k-tiles): what counts is how many workgroups a CU can interleave, not the tile's LDS traffic per FLOP.  Measured on the
+    // path's shapes (tools/gemm_order_bench small -> profiles/r05_gemm_small_tiles.txt): the 4-wave 128 x 128 x 32 tile at three
+    // workgroups per CU beats the 8-wave 128 x 128 x 64 tile (one per CU) by 10-18 % from ~500 tiles on, the 64 x 64 x 64 tile
+    // (three per CU) by 10-20 % below that for N <= 1280.  CTRL_SMALL_TILES=0: the round-4 choice.
+    static const bool small_tiles = !(getenv("CTRL_SMALL_TILES") && getenv("CTRL_SMALL_TILES")[0] == '0');
+    if (small_tiles && MODE == IG_ROWS && can_swap(a) && !a.geglu) {
+        if (tiles(128, 128) >= 512 && eff(128) > 0.8 && al(128)) return launch_cfg2<128, 128, 32, 2, 2, 3, MODE, true>(a, s);
+        if (tiles(128, 128) < 512 && a.Nout <= 1280 && al(64)) return launch_cfg2<64, 64, 64, 2, 2, 3, MODE, true>(a, s);
+    }
     if (tiles(128, 128) >= 192 && eff(128) > 0.8 && al(128)) return launch_cfg<128, 128, 64, 2, 4, 4, MODE>(a, s);
     if (tiles(128, 64) >= 192) return launch_cfg<128, 64, 64, 2, 2, 3, MODE>(a, s);
     return launch_cfg<64, 64, 64, 2, 2, 3, MODE>(a, s);

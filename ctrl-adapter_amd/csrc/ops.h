@@ -136,6 +136,12 @@ int op_router_softmax(const float* wg, const int* mask, float* out, int R, int E
 int op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w, const float* bias, half_t* out,
                       int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, hipStream_t s);
 
+// The same convolution on the matrix cores for the channels-last layers with Cin, Cout in {16, 32} (the conditioning embedder's
+// 16 -> 16, 16 -> 32 s2, 32 -> 32): x NHWC fp16, w fp16 [Cout][9][Cin] (op_pack_conv_w), out NHWC fp16 (+ bias, optional SiLU)
+bool op_conv3x3_small_mfma_applies(int Cin, int Cout);
+int op_conv3x3_small_mfma(const half_t* x, const half_t* w, const float* bias, half_t* out, int N, int Cin, int Cout, int Hin, int Win,
+                          int stride, int silu, hipStream_t s);
+
 // weight packing (load time)
 // conv weight [Cout][Cin][kh][kw] (any dtype) -> fp16 [Cout][kh*kw][Cin]   (taps-major K)
 int op_pack_conv_w(const void* w, int dtype, half_t* out, int Cout, int Cin, int taps, hipStream_t s, int* ovf = nullptr);

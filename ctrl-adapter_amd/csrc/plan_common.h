@@ -19,7 +19,8 @@ struct Lin { half_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; bool geg
 // operand rows against the weights repeated twice), see ctrl_igemm_desc::a_split
 // paired: the split operand is walked in (hi, lo) pairs against the PLAIN weight pack (ctrl_igemm_desc::a_split == 2)
 struct ConvW { half_t* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0, taps = 0; bool dup = false, paired = false; };
-struct ConvD { float* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0; };
+// w16: fp16 [Cout][9][Cin] copy for the MFMA form of the small convolutions (op_conv3x3_small_mfma), when the layer qualifies
+struct ConvD { float* w = nullptr; float* b = nullptr; int Cout = 0, Cin = 0; half_t* w16 = nullptr; };
 struct Norm { float* g = nullptr; float* b = nullptr; int C = 0; };
 
 struct SpecEntry { std::string name; std::vector<int64_t> shape; };
@@ -184,6 +185,11 @@ struct Packer : ParamSink {
         TRY(get(name + ".weight", {Cout, Cin, 3, 3}, &t));
         TRY(dalloc((size_t)9 * Cin * Cout * sizeof(float), (void**)&out->w));
         TRY(op_pack_conv_w_direct(t->data, t->dtype, out->w, Cout, Cin, s));
+        out->w16 = nullptr;
+        if (op_conv3x3_small_mfma_applies(Cin, Cout)) {
+            TRY(dalloc((size_t)9 * Cin * Cout * sizeof(half_t), (void**)&out->w16));
+            TRY(op_pack_conv_w(t->data, t->dtype, out->w16, Cout, Cin, 9, s, ovf_flag()));
+        }
         TRY(dalloc((size_t)Cout * sizeof(float), (void**)&out->b));
         TRY(vec(name + ".bias", Cout, false, out->b));
         out->Cout = Cout; out->Cin = Cin;

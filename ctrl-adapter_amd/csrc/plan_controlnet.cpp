@@ -346,7 +346,12 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
                 if ((int)i >= w.n_direct) ++gi;
             } else if ((int)i < w.n_direct) {
                 CTRL_CHECK(!last, "controlnet: the conditioning embedder must end with an implicit-GEMM layer");
-                RUN(cx, op_conv3x3_direct(cur, cur_dt, nchw, w.ce_direct[i].w, w.ce_direct[i].b, y16, N, ch, co, hh, ww, st, 1, cx.s));
+                // channels-last 16 / 32-channel layers: on the matrix cores (round 5; CTRL_SMALLCONV_MFMA=0: the direct VALU kernel)
+                static const bool small_mfma = !(getenv("CTRL_SMALLCONV_MFMA") && getenv("CTRL_SMALLCONV_MFMA")[0] == '0');
+                if (small_mfma && !nchw && cur_dt == DT_F16 && w.ce_direct[i].w16)
+                    RUN(cx, op_conv3x3_small_mfma((const half_t*)cur, w.ce_direct[i].w16, w.ce_direct[i].b, y16, N, ch, co, hh, ww, st, 1, cx.s));
+                else
+                    RUN(cx, op_conv3x3_direct(cur, cur_dt, nchw, w.ce_direct[i].w, w.ce_direct[i].b, y16, N, ch, co, hh, ww, st, 1, cx.s));
             } else {
                 ConvOpts o; o.stride = st; o.act = last ? 0 : 1;
                 if (last && stem) o.res = tv16(stem);

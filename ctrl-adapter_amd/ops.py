@@ -285,6 +285,16 @@ def conv3x3_direct(x, w_direct, bias, Cout, stride=1, silu=False, nchw=False):
     return out
 
 
+def conv3x3_small_mfma(x, w_packed, bias, Cout, stride=1, silu=False):
+    """x NHWC fp16 [N][H][W][Cin] (Cin, Cout in {16, 32}), w_packed = pack_conv_w(w): the MFMA form of the small convolutions"""
+    N, H, W, Cin = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = _f16(N, Ho, Wo, Cout)
+    L.check(L.lib().ctrl_op_conv3x3_small_mfma(L.ptr(x), L.ptr(w_packed), L.ptr(bias), L.ptr(out), N, Cin, Cout, H, W, stride, int(silu),
+                                               L.cur_stream()))
+    return out
+
+
 def router_weights(wg, mask, equal_weights=False):
     R, E = wg.shape
     out = torch.empty(R, E, dtype=torch.float32, device=wg.device)

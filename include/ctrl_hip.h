@@ -200,6 +200,10 @@ int ctrl_op_add_rowvec(const void* x, int x_dtype, const float* v, int64_t ldv, 
                        int rows_per_img, int vmod, void* stream);
 int ctrl_op_conv3x3_direct(const void* in, int in_dtype, int in_nchw, const float* w, const float* bias, void* out,
                            int N, int Cin, int Cout, int Hin, int Win, int stride, int silu, void* stream);
+/* the same 3x3 convolution (pad 1, stride 1|2, + bias, optional SiLU) on the matrix cores for channels-last fp16 input with Cin, Cout in
+ * {16, 32}: w fp16 [Cout][9][Cin] (ctrl_op_pack_conv_w with taps = 9) */
+int ctrl_op_conv3x3_small_mfma(const void* x, const void* w, const float* bias, void* out, int N, int Cin, int Cout, int Hin, int Win,
+                               int stride, int silu, void* stream);
 /* Conditioning-image preparation feeding the path (model/ctrl_helper.py:268-296 prepare_images = per frame diffusers
  * VaeImageProcessor(do_convert_rgb, no normalisation).preprocess -> batch repeat -> CFG duplication), bit-exact with Pillow's
  * 8-bit Lanczos resampling: src uint8 RGB [F][Hin][Win][3]; per resampled axis the bounds int32 [out][2] and the 22-bit

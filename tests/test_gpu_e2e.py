@@ -543,7 +543,9 @@ def test_text_kv_cache_and_discard_when_off(P, controlnet, gpu):
             assert all(torch.equal(a, b) for a, b in zip(g, r))
         n0, n1 = len(p0.launches), len(p1.launches)
         print("PARITY text K/V cache: bit-identical; launches per step %d -> %d" % (n0, n1))
-        assert n1 <= n0 - 2 * (7 + 9)                 # 7 ControlNet + 9 adapter cross-attentions, K and V^T GEMM each
+        # 7 ControlNet + 9 adapter cross-attentions; since round 5 K | V^T are ONE launch each and the adapter's nine come as five
+        # grouped launches (three sibling groups + two single blocks): 12 launches fewer (rounds 1-4: two launches each, 32 fewer)
+        assert n1 <= n0 - (7 + 5)
         ehs_a.mul_(0.5)                               # in-place change: version counter invalidates the adapter's cache
         got = run(ts[0])
         ad.cache_text = False
@@ -1116,6 +1118,9 @@ def test_grouped_launches_are_bit_identical_and_fewer(P, gpu, which):
         kw = dict(num_frames=4, timestep=torch.tensor(961.0), encoder_hidden_states=seeded_tensor((1, 1, 1024), 991).half().to(gpu),
                   mid_block_res_sample=mid.half().to(gpu))
     ins = [d.half().to(gpu) for d in downs]
+    kw["timestep"] = kw["timestep"].to(gpu)          # (a host timestep would be copied inside the capture below)
+    ad(ins, **kw)                                    # builds the plan (weight packing: not part of the launch counts below)
+    torch.cuda.synchronize()
 
     def run(group):
         ops.set_group_launches(group)

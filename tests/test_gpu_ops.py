@@ -700,7 +700,8 @@ def test_qkv_one_launch_is_bit_identical_to_two(ops, gpu, B, Ltok, K, Cc, wide):
     report("qkv one launch q|k (B%d L%d C%d)" % (B, Ltok, Cc), rel_inf(qk1, ref[:, :2 * Cc]))
     report("qkv one launch v^T", rel_inf(vt1[:, :, :Ltok], ref[:, 2 * Cc:].reshape(B, Ltok, Cc).permute(0, 2, 1)))
     assert torch.equal(qk1, qk2) and torch.equal(vt1, vt2)
-    assert vt1[:, :, Ltok:].abs().max().item() == 0.0
+    if Lpad > Ltok:
+        assert vt1[:, :, Ltok:].abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("Cc,hw,silu,n", [(320, 32 * 32, True, 3), (640, 16 * 16, False, 2), (1280, 64, True, 8), (1280, 7 * 9, False, 2),
@@ -722,3 +723,20 @@ def test_groupnorm_fused_small_maps(ops, gpu, Cc, hw, silu, n):
         assert torch.equal(sp[..., :Cc], out)
         report("groupnorm fused split hi+lo", rel_inf(sp[..., :Cc].float() + sp[..., Cc:].float(), ref), 2e-5 if xin.dtype == torch.float32 else 2e-5)
     assert ops.groupnorm_fused(torch.zeros(1, 128 * 128, 320, dtype=torch.float32, device=gpu), g[:320].to(gpu), b[:320].to(gpu), 1, 128 * 128) is None
+
+
+@pytest.mark.parametrize("cin,cout,stride,h,w_", [(16, 16, 1, 48, 48), (16, 32, 2, 48, 48), (32, 32, 1, 32, 32), (16, 16, 1, 37, 53), (32, 16, 2, 35, 41),
+                                                  (16, 32, 1, 16, 520)])
+def test_conv3x3_small_mfma(ops, gpu, cin, cout, stride, h, w_):
+    """Round 5: the conditioning embedder's 16 / 32-channel 3x3 convolutions on the matrix cores (smallconv.hip:
+    conv3x3_small_mfma_kernel) against torch's conv2d + SiLU; ragged widths / heights exercise the masked tail lanes and rows."""
+    n = 3
+    x, w, b = rnd(n, cin, h, w_, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.1), rnd(cout, seed=3)
+    ref = F.silu(F.conv2d(x, w, b, stride=stride, padding=1))
+    wp = ops.pack_conv_w(w.to(gpu))
+    xin = x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
+    out = ops.conv3x3_small_mfma(xin, wp, b.to(gpu), cout, stride=stride, silu=True)
+    report("conv3x3_small_mfma %d->%d s%d %dx%d" % (cin, cout, stride, h, w_), rel_inf(out.permute(0, 3, 1, 2), ref))
+    wd = ops.pack_conv_w_direct(w.to(gpu))
+    old = ops.conv3x3_direct(xin, wd, b.to(gpu), cout, stride=stride, silu=True, nchw=False)
+    assert rel_inf(out, old) < 1e-3
