@@ -382,9 +382,13 @@ def main():
         order = sorted(rows, key=lambda k: -rows[k]["ms_per_step"])
         for k in order:
             r = rows[k]
-            if r["tflops"]:      # MFMA kernels: algorithmic FLOPs / HIP-event time vs the dense MFMA peak
+            # the roofline that BINDS the launch: algorithmic FLOPs / time vs the dense MFMA peak, algorithmic bytes / time vs the HBM
+            # peak, whichever fraction is larger (a K = 144 convolution on the matrix cores is an HBM kernel; a streaming kernel has no FLOPs)
+            fm = (r["tflops"] or 0.0) / MFMA_PEAK_TFLOPS
+            fh = (r["gbs"] or 0.0) / HBM_PEAK_GBS
+            if fm > 0.0 and fm >= fh:
                 bound, ach, peak = "mfma", r["tflops"], MFMA_PEAK_TFLOPS
-            elif r["gbs"]:       # streaming kernels: algorithmic bytes / time vs the HBM peak
+            elif fh > 0.0:
                 bound, ach, peak = "hbm", r["gbs"], HBM_PEAK_GBS
             else:
                 bound, ach, peak = None, None, None

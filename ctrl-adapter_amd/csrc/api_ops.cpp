@@ -40,7 +40,7 @@ int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream) {
     return op_gn_apply(x, x_dtype, stats, gamma, beta, H(y), imgs, rows_per_img, C, G, eps, silu, S(stream));
 }
-int ctrl_op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G) { return op_gn_fused_applies(x_dtype, rows_per_img, C, G) ? 1 : 0; }
+int ctrl_op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G) { return op_gn_fused_fits(x_dtype, rows_per_img, C, G) ? 1 : 0; }
 int ctrl_op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int64_t ldy, int lo_off,
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream) {
     return op_gn_fused(x, x_dtype, gamma, beta, H(y), imgs, rows_per_img, C, G, eps, silu, S(stream), (long)ldy, lo_off);

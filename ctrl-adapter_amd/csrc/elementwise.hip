@@ -371,17 +371,20 @@ unsigned grid_for(size_t n) {
 
 int op_nchw_to_nhwc(const void* x, int dtype, half_t* y, int N, int C, int HW, hipStream_t s) {
     dim3 grid((HW + 63) / 64, (C + 31) / 32, N);
+    PROF_WORK(0, (double)N * C * HW * ((dtype == DT_F32 ? 4.0 : 2.0) + 2.0));          // one read + one fp16 write
     LAUNCH("nchw_to_nhwc", nchw_to_nhwc_kernel, grid, dim3(256), 0, s, x, dtype, y, C, HW);
     return 0;
 }
 int op_nhwc_to_nchw(const half_t* x, void* y, int dtype, int N, int C, int HW, float scale, hipStream_t s, const int* img_map) {
     dim3 grid((HW + 63) / 64, (C + 31) / 32, N);
+    PROF_WORK(0, (double)N * C * HW * (2.0 + (dtype == DT_F32 ? 4.0 : 2.0)));
     LAUNCH("nhwc_to_nchw", nhwc_to_nchw_kernel, grid, dim3(256), 0, s, x, y, dtype, C, HW, scale, img_map);
     return 0;
 }
 int op_avgpool_nchw(const void* x, void* y, int dtype, int NC, int Hin, int Win, int Hout, int Wout, hipStream_t s) {
     CTRL_CHECK(Hin % Hout == 0 && Win % Wout == 0, "avgpool: only integer pooling ratios are supported");
     const size_t total = (size_t)NC * Hout * Wout;
+    PROF_WORK(0, (dtype == DT_F32 ? 4.0 : 2.0) * ((double)NC * Hin * Win + (double)total));
     LAUNCH("avgpool", avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, y, dtype, Hin, Win, Hout, Wout, total);
     return 0;
 }
@@ -389,11 +392,13 @@ int op_timestep_sincos(const float* t, int t_count, float* out, int N, int dim, 
     CTRL_CHECK(dim % 2 == 0, "timestep embedding: dim must be even");
     CTRL_CHECK(t_count == 1 || t_count == N, "timestep embedding: need 1 or N timesteps");
     const int total = N * (dim / 2);
+    PROF_WORK(0, 4.0 * N * dim);
     LAUNCH("sincos", sincos_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t, t_count, 1, out, N, dim);
     return 0;
 }
 int op_frameidx_sincos(float* out, int N, int F, int dim, hipStream_t s) {
     const int total = N * (dim / 2);
+    PROF_WORK(0, 4.0 * N * dim);
     LAUNCH("sincos", sincos_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)nullptr, 0, F, out, N, dim);
     return 0;
 }
@@ -402,6 +407,7 @@ int op_linear_small(const float* x, long ldx, const half_t* w, const float* b, f
     CTRL_CHECK(K % 8 == 0 && ldx % 4 == 0, "linear_small: K must be a multiple of 8 and ldx of 4");
     CTRL_CHECK(M >= 1 && M <= 4096, "linear_small: M out of range");
     dim3 grid((N + 3) / 4, (M + 7) / 8);
+    PROF_WORK(0, 2.0 * N * K + 4.0 * M * ((double)K + N));        // the weights once (fp16) + activations in / out (fp32): weight-streaming bound
     LAUNCH("linear_small", linear_small_kernel<8>, grid, dim3(256), 0, s, x, ldx, w, b, out, ldo, M, N, K, in_silu, out_silu);
     return 0;
 }
@@ -410,13 +416,16 @@ int op_linear_small_group(const SmallLin* probs, int count, hipStream_t s) {
         SmallLinGroup g;
         g.count = std::min(kSmallGroup, count - base);
         int blocks = 0;
+        double bytes = 0;
         for (int i = 0; i < g.count; ++i) {
             const SmallLin& q = probs[base + i];
+            bytes += 2.0 * q.N * q.K + 4.0 * q.M * ((double)q.K + q.N);
             CTRL_CHECK(q.K % 8 == 0 && q.ldx % 4 == 0 && q.M >= 1 && q.N >= 1, "linear_small_group: K must be a multiple of 8");
             g.p[i] = q;
             g.blk_begin[i] = blocks;
             blocks += ((q.N + 3) / 4) * ((q.M + 7) / 8);
         }
+        PROF_WORK(0, bytes);
         prof_detail("%d problems", g.count);
         LAUNCH("linear_small", linear_small_group_kernel, dim3(blocks), dim3(256), 0, s, g);
     }
@@ -426,6 +435,7 @@ int op_linear_small_group(const SmallLin* probs, int count, hipStream_t s) {
 int op_blend(const void* xs, int xs_dt, const void* xt, int xt_dt, const float* mix, void* y, int y_dt, size_t n, hipStream_t s) {
     CTRL_CHECK(n % 8 == 0, "blend: element count must be a multiple of 8");
     CTRL_CHECK(xs_dt != DT_BF16 && xt_dt != DT_BF16 && y_dt != DT_BF16, "blend: fp16 / fp32 only");
+    PROF_WORK(0, (double)n * ((xs_dt == DT_F32 ? 4.0 : 2.0) + (xt_dt == DT_F32 ? 4.0 : 2.0) + (y_dt == DT_F32 ? 4.0 : 2.0)));
     LAUNCH("blend", blend_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, xs, xs_dt, xt, xt_dt, mix, y, y_dt, n / 8);
     return 0;
 }
@@ -433,6 +443,7 @@ int op_add_rowvec(const void* x, int x_dt, const float* v, long ldv, void* y, in
     CTRL_CHECK(C % 8 == 0, "add_rowvec: C must be a multiple of 8");
     CTRL_CHECK(x_dt != DT_BF16 && y_dt != DT_BF16, "add_rowvec: fp16 / fp32 only");
     const size_t nch = M * (size_t)(C / 8);
+    PROF_WORK(0, (double)M * C * ((x_dt == DT_F32 ? 4.0 : 2.0) + (y_dt == DT_F32 ? 4.0 : 2.0)));
     LAUNCH("add_rowvec", add_rowvec_kernel, dim3(grid_for(nch)), dim3(256), 0, s, x, x_dt, v, ldv, y, y_dt, nch, C, rows_per_img, vmod);
     return 0;
 }
@@ -440,6 +451,7 @@ int op_add_rowvec_clip(const void* x, int x_dt, const float* v, long ldv, void* 
     CTRL_CHECK(C % 8 == 0, "add_rowvec_clip: C must be a multiple of 8");
     CTRL_CHECK(x_dt != DT_BF16 && y_dt != DT_BF16, "add_rowvec_clip: fp16 / fp32 only");
     const size_t nch = (size_t)B * F * L * (size_t)(C / 8);
+    PROF_WORK(0, (double)B * F * L * C * ((x_dt == DT_F32 ? 4.0 : 2.0) + (y_dt == DT_F32 ? 4.0 : 2.0)));
     LAUNCH("add_rowvec_clip", add_rowvec_clip_kernel, dim3(grid_for(nch)), dim3(256), 0, s, x, x_dt, v, ldv, y, y_dt, nch, C, F, L, B);
     return 0;
 }

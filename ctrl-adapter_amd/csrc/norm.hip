@@ -217,34 +217,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(Ptr4<const T*> xs, Ptr4<c
 // same rows, which still sit in L2.  The two-kernel form above costs the low-resolution levels of the ControlNet chain two launches of
 // ~10 us for a few hundred KB; it remains the form for every map whose 80-channel slice exceeds kGnFusedBytes.
 constexpr int kGnFusedCh = 80;
+constexpr int kGnFusedRL = 102;          // row lanes: 1020 of the 1024 threads, 10 lanes of 8 channels per row
+// (1024 threads: a workgroup streams its slice alone, so its memory-level parallelism is what a pass costs -- 102 rows x 4 loads in
+// flight per iteration; the first 256-thread form spent ~20 us of dependent round trips on a 32^2 map)
 template <typename T>
-__global__ __launch_bounds__(256) void gn_fused_kernel(Ptr4<const T*> xs, Ptr4<const float*> gammas, Ptr4<const float*> betas, Ptr4<half_t*> ys,
-                                                       int rows, int C, int cg, float eps, int silu, long ldy, int lo_off) {
-    __shared__ float sh[25][2 * kGnFusedCh];      // per (row lane, channel): sum | sum of squares
-    __shared__ float gst[8][2];                   // per group of the block: mean, rstd
+__global__ __launch_bounds__(1024) void gn_fused_kernel(Ptr4<const T*> xs, Ptr4<const float*> gammas, Ptr4<const float*> betas, Ptr4<half_t*> ys,
+                                                        int rows, int C, int cg, float eps, int silu, long ldy, int lo_off) {
+    __shared__ float sh[kGnFusedRL][2 * kGnFusedCh];      // per (row lane, channel): sum | sum of squares
+    __shared__ float gst[8][2];                           // per group of the block: mean, rstd
     const T* __restrict__ x = pick4(xs, blockIdx.z);
     const float* __restrict__ gamma = pick4(gammas, blockIdx.z);
     const float* __restrict__ beta = pick4(betas, blockIdx.z);
     half_t* __restrict__ y = pick4(ys, blockIdx.z);
     const int tid = threadIdx.x;
-    const int tr = tid / 10, tc = tid - tr * 10;      // 10 lanes of 8 channels per row, 25 rows per iteration
+    const int tr = tid / 10, tc = tid - tr * 10;
+    constexpr int RL = kGnFusedRL;
     const int img = blockIdx.y, c0 = blockIdx.x * kGnFusedCh;
     const T* xp = x + ((size_t)img * rows) * C + c0 + tc * 8;
-    if (tr < 25) {
+    if (tr < RL) {
         float s[8], ss[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
         int r = tr;
-        for (; r + 75 < rows; r += 100) {
+        for (; r + 3 * RL < rows; r += 4 * RL) {
             float v[4][8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) load8<T>(xp + (size_t)(r + u * 25) * C, v[u]);
+            for (int u = 0; u < 4; ++u) load8<T>(xp + (size_t)(r + u * RL) * C, v[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = v[u][j]; s[j] += f; ss[j] += f * f; }
         }
-        for (; r < rows; r += 25) {
+        for (; r < rows; r += RL) {
             float v[8];
             load8<T>(xp + (size_t)r * C, v);
 #pragma unroll
@@ -255,19 +259,19 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(Ptr4<const T*> xs, Ptr4<c
     }
     __syncthreads();
     {
-        // group g of the block = 8 lanes, fixed element -> lane assignment, fixed xor tree
-        const int g = tid >> 3, part = tid & 7, ngrp = kGnFusedCh / cg;
+        // group g of the block = 16 lanes, fixed element -> lane assignment, fixed xor tree
+        const int g = tid >> 4, part = tid & 15, ngrp = kGnFusedCh / cg;
         float a = 0.f, b = 0.f;
         if (g < ngrp) {
-            const int n = cg * 25;
-            for (int e = part; e < n; e += 8) {
+            const int n = cg * RL;
+            for (int e = part; e < n; e += 16) {
                 const int t = e / cg, c = g * cg + (e - t * cg);
                 a += sh[t][c];
                 b += sh[t][kGnFusedCh + c];
             }
         }
 #pragma unroll
-        for (int o = 4; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        for (int o = 8; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
         if (g < ngrp && part == 0) {
             const float inv_cnt = 1.0f / ((float)rows * (float)cg);
             const float mean = a * inv_cnt;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(Ptr4<const T*> xs, Ptr4<c
         }
     }
     __syncthreads();
-    if (tr >= 25) return;
+    if (tr >= RL) return;
     float sc[8], sf[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -299,14 +303,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(Ptr4<const T*> xs, Ptr4<c
         if (lo_off) *(h8*)(dst + lo_off) = l;
     };
     int r = tr;
-    for (; r + 75 < rows; r += 100) {
+    for (; r + 3 * RL < rows; r += 4 * RL) {
         float v[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) load8<T>(xp + (size_t)(r + u * 25) * C, v[u]);
+        for (int u = 0; u < 4; ++u) load8<T>(xp + (size_t)(r + u * RL) * C, v[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) emit(v[u], yp + (size_t)(r + u * 25) * ldy);
+        for (int u = 0; u < 4; ++u) emit(v[u], yp + (size_t)(r + u * RL) * ldy);
     }
-    for (; r < rows; r += 25) {
+    for (; r < rows; r += RL) {
         float v[8];
         load8<T>(xp + (size_t)r * C, v);
         emit(v, yp + (size_t)r * ldy);
@@ -579,10 +583,18 @@ int op_layernorm_group(const LnArgs* a, int n, hipStream_t s) {
 
 // ---- GroupNorm of a small map in one launch (gn_fused_kernel) ----
 constexpr size_t kGnFusedBytes = 512 * 1024;     // largest 80-channel slice of one image a workgroup takes (read twice: HBM, then L2)
-bool op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G) {
-    static const bool on = !(getenv("CTRL_GN_FUSED") && getenv("CTRL_GN_FUSED")[0] == '0');
-    if (!on || G != 32 || C % kGnFusedCh != 0 || (C / G) <= 0 || kGnFusedCh % (C / G) != 0 || kGnFusedCh / (C / G) > 8) return false;
+// the shapes the fused kernel takes: GroupNorm(32) whose 80-channel blocks hold whole groups, slice of one image <= kGnFusedBytes
+bool op_gn_fused_fits(int x_dtype, int rows_per_img, int C, int G) {
+    if (G != 32 || C % kGnFusedCh != 0 || (C / G) <= 0 || kGnFusedCh % (C / G) != 0 || kGnFusedCh / (C / G) > 8) return false;
     return (size_t)rows_per_img * kGnFusedCh * (x_dtype == DT_F32 ? 4 : 2) <= kGnFusedBytes;
+}
+// whether the PLANS use it (run_groupnorm).  OFF by default: measured in the step (one gpurun call, profiles/r05_ab_same_box.txt) the
+// fused form LOSES 0.5-0.6 ms per SDXL step -- 32 .. 128 workgroups stream a 10-20 MB map at a fraction of the chip's bandwidth (22-32 us
+// per launch against 10 + 10 us for the two launches it replaces, which run on 768-2048 workgroups); it would pay only on the 8^2 level
+// (~5 us per norm).  CTRL_GN_FUSED=1 switches it on; the op stays covered by tests/test_gpu_ops.py::test_groupnorm_fused_small_maps.
+bool op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G) {
+    static const bool on = getenv("CTRL_GN_FUSED") && getenv("CTRL_GN_FUSED")[0] == '1';
+    return on && op_gn_fused_fits(x_dtype, rows_per_img, C, G);
 }
 
 int op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* beta, half_t* y, int imgs, int rows_per_img, int C, int G,
@@ -610,7 +622,7 @@ int op_gn_fused_group(const GnApplyArgs* a, int n, hipStream_t s) {
     }
     const int x_dtype = a[0].x_dtype, imgs = a[0].imgs, rows = a[0].rows_per_img, C = a[0].C, G = a[0].G, lo_off = a[0].lo_off;
     const long ldy = a[0].ldy ? a[0].ldy : C;
-    CTRL_CHECK(op_gn_fused_applies(x_dtype, rows, C, G), "gn_fused: not a small GroupNorm(32) map");
+    CTRL_CHECK(op_gn_fused_fits(x_dtype, rows, C, G), "gn_fused: not a small GroupNorm(32) map");
     CTRL_CHECK(x_dtype == DT_F16 || x_dtype == DT_F32, "gn_fused: input must be fp16 or fp32");
     CTRL_CHECK(ldy % 8 == 0 && lo_off % 8 == 0 && (lo_off == 0 || (lo_off >= C && lo_off + C <= ldy)), "gn_fused: bad split layout");
     PROF_WORK(0, n * ((x_dtype == DT_F32 ? 6.0 : 4.0) + (lo_off ? 2.0 : 0.0)) * imgs * rows * C);     // (the second read comes from L2)
@@ -620,10 +632,10 @@ int op_gn_fused_group(const GnApplyArgs* a, int n, hipStream_t s) {
     const auto be = ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.beta; });
     const auto ys = ptrs_of<half_t*>(a, n, [](const GnApplyArgs& q) { return q.y; });
     if (x_dtype == DT_F32)
-        LAUNCH("gn_fused", gn_fused_kernel<float>, grid, dim3(256), 0, s, ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.x; }),
+        LAUNCH("gn_fused", gn_fused_kernel<float>, grid, dim3(1024), 0, s, ptrs_of<const float*>(a, n, [](const GnApplyArgs& q) { return q.x; }),
                ga, be, ys, rows, C, C / G, a[0].eps, a[0].silu, ldy, lo_off);
     else
-        LAUNCH("gn_fused", gn_fused_kernel<half_t>, grid, dim3(256), 0, s, ptrs_of<const half_t*>(a, n, [](const GnApplyArgs& q) { return q.x; }),
+        LAUNCH("gn_fused", gn_fused_kernel<half_t>, grid, dim3(1024), 0, s, ptrs_of<const half_t*>(a, n, [](const GnApplyArgs& q) { return q.x; }),
                ga, be, ys, rows, C, C / G, a[0].eps, a[0].silu, ldy, lo_off);
     return 0;
 }

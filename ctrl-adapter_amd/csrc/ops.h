@@ -181,7 +181,9 @@ int op_gn_stats_group(const GnStatsArgs* a, int n, hipStream_t s);
 int op_gn_apply_group(const GnApplyArgs* a, int n, hipStream_t s);
 int op_layernorm_group(const LnArgs* a, int n, hipStream_t s);
 // GroupNorm(32) of a SMALL map (the 80-channel slice of one image <= 512 KB) in ONE launch: statistics + apply by the same workgroup
-// (norm.hip: gn_fused_kernel); op_gn_fused_applies says whether a problem qualifies (CTRL_GN_FUSED=0: never)
+// (norm.hip: gn_fused_kernel); op_gn_fused_applies says whether the plans use it for a problem (only with CTRL_GN_FUSED=1: measured
+// slower than the two-kernel form in the step) -- op_gn_fused itself takes every small map
+bool op_gn_fused_fits(int x_dtype, int rows_per_img, int C, int G);
 bool op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G);
 int op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* beta, half_t* y, int imgs, int rows_per_img, int C, int G,
                 float eps, int silu, hipStream_t s, long ldy = 0, int lo_off = 0);

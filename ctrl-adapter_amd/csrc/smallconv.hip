@@ -165,6 +165,11 @@ int launch_direct(const void* in, int in_dt, const float* w, const float* bias, 
     const int Hout = (Hin + 2 - 3) / stride + 1, Wout = (Win + 2 - 3) / stride + 1;
     const size_t npix = (size_t)N * Hout * Wout;
     dim3 grid((unsigned)((npix + 255) / 256), Cout / COT);
+    // roofline = HBM, its maps read / written once (the weights are a few KB; 2 B per input value: the boundary tensors of the
+    // benchmark are fp16).  (Its fp32 VALU work -- 2 * 9 * Cin * Cout flops per pixel -- is what actually bounds the 16 / 32-channel
+    // layers, which is why they moved to the matrix cores: conv3x3_small_mfma_kernel.)
+    PROF_WORK(0, 2.0 * ((double)N * Hin * Win * CIN + (double)npix * Cout));
+    prof_detail("N%d %d->%d %dx%d s%d%s", N, CIN, Cout, Hin, Win, stride, NCHW_IN ? " nchw" : "");
     LAUNCH("conv3x3_direct", (conv3x3_direct_kernel<CIN, COT, NCHW_IN>), grid, dim3(256), 0, s,
            in, in_dt, w, bias, out, N, Cout, Hin, Win, Hout, Wout, stride, silu);
     return 0;

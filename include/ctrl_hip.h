@@ -180,9 +180,9 @@ int ctrl_op_gn_apply(const void* x, int x_dtype, const float* stats, const float
 /* split-operand variant: y rows are [hi | lo] (row stride ldy, lo at column offset lo_off), hi + lo = the fp32 result to ~2^-22 */
 int ctrl_op_gn_apply_split(const void* x, int x_dtype, const float* stats, const float* gamma, const float* beta, void* y,
                            int64_t ldy, int lo_off, int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);
-/* GroupNorm(32) of a small map in ONE launch (statistics + apply by the same workgroup; what the plans use whenever the 80-channel
- * slice of one image is at most 512 KB): ldy = row stride of y (0 = C), lo_off > 0 = split [hi | lo] result as above.  Fails
- * when the problem does not qualify (ctrl_op_gn_fused_applies == 0). */
+/* GroupNorm(32) of a small map in ONE launch (statistics + apply by the same workgroup; qualifies when the 80-channel slice of one
+ * image is at most 512 KB: ctrl_op_gn_fused_applies): ldy = row stride of y (0 = C), lo_off > 0 = split [hi | lo] result as above.
+ * The plans use it only with CTRL_GN_FUSED=1: measured inside the step it is slower than the two launches it replaces. */
 int ctrl_op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G);
 int ctrl_op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int64_t ldy, int lo_off,
                      int imgs, int rows_per_img, int C, int G, float eps, int silu, void* stream);

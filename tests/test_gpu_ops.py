@@ -710,7 +710,7 @@ def test_groupnorm_fused_small_maps(ops, gpu, Cc, hw, silu, n):
     """Round 5: statistics + apply of a small GroupNorm(32) map in ONE launch (gn_fused_kernel: a workgroup owns 80 channels = 8 / 4 / 2
     whole groups of one image).  Against torch's group_norm, fp16 and fp32 inputs, plain and split [hi | lo] results; the large map
     of test_groupnorm does not qualify and stays on the two-kernel form."""
-    x = rnd(n, hw, Cc, seed=1) * 1.7 + 0.5
+    x = (rnd(n, hw, Cc, seed=1) * 1.7 + 0.5).half().float()          # fp16-representable: both input dtypes see the same values
     g, b = rnd(Cc, seed=2) + 1.0, rnd(Cc, seed=3)
     ref = F.group_norm(x.permute(0, 2, 1), 32, g, b, eps=1e-6).permute(0, 2, 1)
     if silu:

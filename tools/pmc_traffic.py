@@ -23,7 +23,7 @@ def kernel_class(name):
     m = re.search(r"igemm8_kernel<\s*\d+,\s*(\d+)>", name) or re.search(r"igemm8_kernelILi\d+ELi(\d+)E", name)      # round 4's wide tile: <NI, MODE>
     if m:
         return {"0": "igemm_rows", "1": "igemm_conv", "2": "igemm_temporal"}[m.group(1)]
-    for key in ("splitk_finish", "flash_attn", "temporal_attn", "gn_stats", "gn_apply", "layernorm", "conv3x3_direct",
+    for key in ("splitk_finish", "flash_attn", "temporal_attn", "gn_stats", "gn_apply", "gn_fused", "layernorm", "conv3x3_direct", "conv3x3_small_mfma",
                 "linear_small", "nchw_to_nhwc", "nhwc_to_nchw", "avgpool", "sincos", "blend", "add_rowvec", "merge"):
         if key in name:
             return key

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r04 v1 [1 = also write the pytest parity logs (adds ~13 minutes; they run LAST)]
+#   bash tools/profile_round.sh r05 v1 [1 = also write the pytest parity logs (adds ~13 minutes; they run LAST)]
 # Writes under gpurun_out/final/; copy what should be judged into profiles/.  ~8 minutes of box time without the tests.
 set -u
-R=${1:-r04}; V=${2:-v1}; TESTS=${3:-0}
+R=${1:-r05}; V=${2:-v1}; TESTS=${3:-0}
 O=gpurun_out/final; mkdir -p $O
 export TMPDIR=/tmp
 if [ "${ONLY_TRACES:-0}" != "1" ]; then      # ONLY_TRACES=1: just the rocprofv3 passes below
