@@ -306,7 +306,22 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
             HIP_TRY(hipStreamWaitEvent(a.plan->aux, a.plan->aux_fork, 0));
             cx.s = a.plan->aux;
         }
-        for (size_t i = 0; i < tbs.size(); ++i) TRY(project_text_kv(cx, tbs[i]->attn2, e, &pre_kv[i]));
+        // (the blocks of one level project the same text states with equal shapes: recorded, then replayed in lock-step so that
+        //  they leave as grouped launches -- ops.h: OpCollector; 7 launches -> 3)
+        const bool grp_kv = group_launches_enabled() && !cx.dry && tbs.size() <= 16;
+        std::vector<OpList> kv_ops(grp_kv ? tbs.size() : 0);
+        for (size_t i = 0; i < tbs.size(); ++i) {
+            cx.rec = grp_kv ? &kv_ops[i] : nullptr;
+            const int rc = project_text_kv(cx, tbs[i]->attn2, e, &pre_kv[i]);
+            cx.rec = nullptr;
+            if (rc) return rc;
+        }
+        for (size_t i0 = 0; grp_kv && i0 < tbs.size();) {
+            size_t i1 = i0 + 1;
+            while (i1 < tbs.size() && i1 - i0 < (size_t)kMaxGroup && tbs[i1]->attn2.inner == tbs[i0]->attn2.inner) ++i1;
+            TRY(replay_lockstep(&kv_ops[i0], (int)(i1 - i0)));
+            i0 = i1;
+        }
         if (aux) {
             HIP_TRY(hipEventRecord(a.plan->aux_kv, a.plan->aux));
             cx.s = main_s;
@@ -369,6 +384,26 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     //      network is still running ----
     const size_t nout = w.zero_convs.size();
     size_t n_emitted = 0;
+    // Grouped launches (round 5): consecutive residuals of one shape -- r0..r2, r4..r5, r7..r8, r9..r11 + mid -- are held back and
+    // their zero-convs leave as ONE launch when the shape changes (13 launches -> 6).  Not in the fused step (a.out_ev): there every
+    // output is wanted as early as possible (an adapter block starts when ITS input exists).
+    const bool grp_zc = group_launches_enabled() && !a.out_ev;
+    IGemmArgs zc_pend[kMaxGroup];
+    size_t zc_first = 0;
+    int zc_n = 0;
+    auto zc_flush = [&]() -> int {
+        if (zc_n == 0) return 0;
+        hipStream_t zs = cx.s;
+        if (aux) {      // the group only reads residuals that exist since its last member was emitted (event recorded there): off the
+                        // chain, onto the auxiliary lane
+            HIP_TRY(hipStreamWaitEvent(a.plan->aux, a.plan->res_ev[zc_first + zc_n - 1], 0));
+            zs = a.plan->aux;
+        }
+        const int n = zc_n;
+        zc_n = 0;
+        RUN(cx, op_igemm_group(zc_pend, n, zs));
+        return 0;
+    };
     auto emit = [&](const TV& r, int hh, int ww) -> int {
         const size_t i = n_emitted++;
         CTRL_CHECK(i < nout, "controlnet: residual/zero-conv count mismatch");
@@ -382,6 +417,13 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         g.W = z.w; g.M = N * HW; g.Nout = z.Cout; g.Ktot = z.Cin; g.bias = z.b; g.scale = sc;
         g.nseg = 1;
         g.seg[0] = IGemmSeg{a.outs[i], HW, 0, z.Cout, SEG_TRANSPOSED, a.out_dt, HW, 0};
+        if (grp_zc) {
+            if (zc_n > 0 && (zc_n == kMaxGroup || zc_pend[0].M != g.M || zc_pend[0].Nout != g.Nout || zc_pend[0].Ktot != g.Ktot)) TRY(zc_flush());
+            if (zc_n == 0) zc_first = i;
+            zc_pend[zc_n++] = g;
+            if (aux) HIP_TRY(hipEventRecord(a.plan->res_ev[i], main_s));      // residual i exists from here on
+            return 0;
+        }
         hipStream_t zs = cx.s;
         if (aux) {      // the zero-conv only reads the residual that exists now: off the chain, onto the auxiliary lane
             HIP_TRY(hipEventRecord(a.plan->res_ev[i], main_s));
@@ -430,6 +472,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
         TRY(run_resnet(cx, w.mid_r1, m1, m2, N, h, wd, 1, tproj + w.mid_r1.temb_off, w.temb_total, c.norm_eps));
         TRY(emit(m2, h, wd));
     }
+    TRY(zc_flush());
     CTRL_CHECK(n_emitted == nout, "controlnet: residual/zero-conv count mismatch");
     if (aux) {          // join: the launch stream does not run past the forward before the auxiliary lane has finished
         HIP_TRY(hipEventRecord(a.plan->aux_done, a.plan->aux));

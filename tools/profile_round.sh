@@ -41,7 +41,7 @@ rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/stats $O/stats_lanes_off
 tail -n 2 $O/${R}_smoke_${V}.log; tail -c 600 $O/${R}_bench_${V}.json
 # the parity logs last: a budget cut must not cost the measurements above
 if [ "$TESTS" = "1" ]; then
-(python -m pytest tests/test_gpu_ops.py tests/test_image_prep.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_op_parity_${V}.log
-(python -m pytest tests/test_gpu_e2e.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|Error") > $O/${R}_e2e_parity_${V}.log
+(python -m pytest tests/test_gpu_ops.py tests/test_image_prep.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|FAILED|Error|assert") > $O/${R}_op_parity_${V}.log
+(python -m pytest tests/test_gpu_e2e.py -m gpu -q --tb=short -s 2>&1 | grep -E "PARITY|passed|failed|FAILED|Error|assert") > $O/${R}_e2e_parity_${V}.log
 fi
 
