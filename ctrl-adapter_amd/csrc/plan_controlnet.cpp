@@ -62,12 +62,16 @@ int cn_split_levels() {
 // The same depth for the ResNets' 3x3 convolutions alone (CTRL_CN_SPLIT_RESNET_LEVELS, default = CTRL_CN_SPLIT_LEVELS): the CPU emulation
 // per conv kind (tools/experiments/split_per_conv.py, round 4) says the 3x3 convolutions of the 640- and 1280-channel levels can take plain
 // operands at unchanged ControlNet / chain errors (6.2e-4 / 7.6e-4 against 6.8e-4 / 7.1e-4) while the 1x1 shortcuts, proj_in / proj_out,
-// down-samplers and zero-convs cannot; "1" halves the matrix work of 12 of the most expensive split launches.  Default 1 since round 5
-// (the full GPU suite ran with it: profiles/r05_*; CTRL_CN_SPLIT_RESNET_LEVELS=3 restores the round-4 selection).
+// down-samplers and zero-convs cannot; "1" halves the matrix work of 12 of the most expensive split launches (-0.46 ms of convolution time per
+// SDXL step, ~-2 ms per video step).  Round 5 ran the full GPU suite with "1" as the default (profiles/r05_e2e_parity_v1.log): every
+// at-shape chain stayed inside 1e-3 (SVD-16 9.6e-4) but the config-5 miniature chain (8 x 8 latents, three nets -> router -> merge -> video
+// adapter) came out at 1.001e-3 on one tensor -- the emulation's +0.5e-4 on that very chain is real, and the margins of this path are
+// thinner than that.  So the default stays = CTRL_CN_SPLIT_LEVELS (every convolution of down blocks 0-2 split) and "1" remains an opt-in.
 int cn_split_resnet_levels() {
     const char* e = getenv("CTRL_CN_SPLIT_RESNET_LEVELS");
     const int lv = cn_split_levels();
-    const int v = e ? atoi(e) : 1;
+    if (!e) return lv;
+    const int v = atoi(e);
     return v < 0 ? 0 : (v > lv ? lv : v);
 }
 // CTRL_CN_SPLIT=dup: the first form of the split (weights packed twice, [hi | lo] walked as one long K) for A/B runs
@@ -138,7 +142,8 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
     // per-conv selection of the split operands; a checkpoint whose normalisation scales have outlier channels keeps them on every level
     // the 1x1 convolutions take them on (ParamSink::norm_scale_spread)
     const int levels = cn_split_levels();
-    const bool outliers = ps.norm_scale_spread("") > kNormSpreadGate && !getenv("CTRL_CN_SPLIT_RESNET_LEVELS");
+    // (an opt-in CTRL_CN_SPLIT_RESNET_LEVELS < levels is ignored for a checkpoint with outlier norm scales)
+    const bool outliers = ps.norm_scale_spread("") > kNormSpreadGate;
     const int res_levels = outliers ? levels : cn_split_resnet_levels();
     auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r, bool dup_r, int dup_sc = -1) -> int {
         TRY(build_resnet(ps, pre, Cin, Cout, false, r, dup_r, dup_sc));
