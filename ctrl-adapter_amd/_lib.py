@@ -26,7 +26,7 @@ class IGemmDesc(C.Structure):
                 ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_ld", C.c_int32), ("rows_per_img", C.c_int32),
                 ("res", C.c_void_p), ("ldres", C.c_int64), ("scale", C.c_float), ("geglu", C.c_int32),
                 ("nseg", C.c_int32), ("act", C.c_int32), ("res_f32", C.c_int32), ("a_split", C.c_int32),
-                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("splitk_tickets", C.c_void_p),
                 ("out16", C.c_void_p), ("ld16", C.c_int64),
                 ("blend_mix", C.c_void_p), ("blend_x", C.c_void_p), ("ld_blend", C.c_int64), ("blend_f32", C.c_int32), ("out16_lo_off", C.c_int32), ("scale2", C.c_float), ("scale2_from", C.c_int32),
                 ("res_up", C.c_int32), ("scale2_to", C.c_int32),
@@ -83,7 +83,7 @@ class ClipComm(C.Structure):
 
 
 # every symbol include/ctrl_hip.h declares (tests check the library exports all of them)
-ABI_VERSION = 5       # CTRL_ABI_VERSION of include/ctrl_hip.h
+ABI_VERSION = 6       # CTRL_ABI_VERSION of include/ctrl_hip.h
 EXPORTS = [
     "ctrl_abi_version", "ctrl_last_error", "ctrl_prof_begin", "ctrl_prof_end", "ctrl_prof_count", "ctrl_prof_get",
     "ctrl_prof_launch_count", "ctrl_prof_launch_get",

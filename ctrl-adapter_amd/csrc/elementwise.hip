@@ -462,8 +462,60 @@ int op_upsample2x_nhwc(const half_t* x, half_t* y, int N, int H, int W, int C, h
     LAUNCH("upsample2x", upsample2x_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, y, H, W, C / 8, total);
     return 0;
 }
+// Zero fill as a KERNEL, not hipMemsetAsync (round 5): captured into a hipGraph on ONE stream (CTRL_ADAPTER_LANES=1), the forwards'
+// memset nodes -- GroupNorm ticket / statistics pool, split-K ticket words, zero slots -- were not ordered against the kernels around
+// them from the second replay on (every output of replay 1.. differed, the eager forward and the 4-lane graph did not: tools/diag/
+// graph_1lane.py, ROCm 7.2); a kernel node always is.  16-byte stores, byte-wise head / tail.
+namespace {
+struct FillArgs { unsigned char* p[kMaxGroup]; size_t head[kMaxGroup], n16[kMaxGroup], tail[kMaxGroup]; };
+__global__ __launch_bounds__(256) void fill_zero_kernel(FillArgs a) {
+    const int z = blockIdx.y;
+    unsigned char* p = z == 0 ? a.p[0] : (z == 1 ? a.p[1] : (z == 2 ? a.p[2] : a.p[3]));
+    const size_t head = z == 0 ? a.head[0] : (z == 1 ? a.head[1] : (z == 2 ? a.head[2] : a.head[3]));
+    const size_t n16 = z == 0 ? a.n16[0] : (z == 1 ? a.n16[1] : (z == 2 ? a.n16[2] : a.n16[3]));
+    const size_t tail = z == 0 ? a.tail[0] : (z == 1 ? a.tail[1] : (z == 2 ? a.tail[2] : a.tail[3]));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4* body = (u4*)(p + head);
+    for (size_t k = i; k < n16; k += stride) body[k] = u4{0u, 0u, 0u, 0u};
+    if (i < head) p[i] = 0;
+    if (i < tail) p[head + n16 * 16 + i] = 0;
+}
+}  // namespace
 int op_fill_zero(void* p, size_t bytes, hipStream_t s) {
-    HIP_TRY(hipMemsetAsync(p, 0, bytes, s));
+    if (bytes == 0) return 0;
+    if (t_collect) {                                 // lock-step replay of sibling blocks: deposited, launched by the collector's flush()
+        int rc = 0;
+        const int i = t_collect->slot(OpCollector::FILL, s, &rc);
+        if (i < 0) return rc;
+        t_collect->fz[i].p = p; t_collect->fz[i].bytes = bytes;
+        return 0;
+    }
+    return op_fill_zero_group(&p, &bytes, 1, s);
+}
+int op_fill_zero_group(void* const* ps, const size_t* bytes, int n, hipStream_t s) {
+    CTRL_CHECK(ps && bytes && n >= 1 && n <= kMaxGroup, "fill_zero_group: 1..4 fills");
+    static_assert(kMaxGroup == 4, "fill_zero_kernel selects among four problems");
+    FillArgs a = {};
+    size_t most = 0;
+    double total = 0;
+    for (int i = 0; i < n; ++i) {
+        a.p[i] = (unsigned char*)ps[i];
+        size_t head = (16 - ((uintptr_t)ps[i] & 15)) & 15;
+        if (head > bytes[i]) head = bytes[i];
+        a.head[i] = head;
+        a.n16[i] = (bytes[i] - head) / 16;
+        a.tail[i] = bytes[i] - head - a.n16[i] * 16;
+        if (a.n16[i] > most) most = a.n16[i];
+        total += (double)bytes[i];
+    }
+    size_t blocks = (most + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    PROF_WORK(0, total);
+    if (n > 1) prof_detail("x%d", n);
+    LAUNCH("fill_zero", fill_zero_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, a);
     return 0;
 }
 int op_weighted_merge(const void* const* xs, const float* w, const int* widx, int K, void* out, int dtype, size_t n, hipStream_t s) {

@@ -39,6 +39,12 @@ int OpCollector::flush() {
         case LAYERNORM: rc = op_layernorm_group(ln, n, s); break;
         case ATTN: rc = op_flash_attn_group(at, n, s); break;
         case GN_FUSED: rc = op_gn_fused_group(ga, n, s); break;
+        case FILL: {
+            void* ps[kMaxGroup]; size_t bs[kMaxGroup];
+            for (int i = 0; i < n; ++i) { ps[i] = fz[i].p; bs[i] = fz[i].bytes; }
+            rc = op_fill_zero_group(ps, bs, n, s);
+            break;
+        }
         default: break;
     }
     t_collect = me;

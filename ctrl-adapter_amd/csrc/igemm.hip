@@ -884,9 +884,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmGroup kargs, int pe
     const int gbid = blockIdx.x - gp * per;
     if (gbid >= ntm * ntn * splitk) return;
     const IGemmArgs& a = IGEMM_GROUP_ARGS(gp);
-    // in-launch split-K reduction (red_off >= 0): fragment slabs at the start of the problem's split-K scratch, ticket words at red_off
+    // in-launch split-K reduction (red_off != -1): fragment slabs at the start of the problem's split-K scratch; ticket words at red_off
+    // inside it, or (red_off == -2) the descriptor's own zeroed ticket words
     float* const red_ws = (float*)a.splitk_ws;
-    int* const red_cnt = red_off >= 0 ? (int*)((char*)a.splitk_ws + red_off) : nullptr;
+    int* const red_cnt = red_off >= 0 ? (int*)((char*)a.splitk_ws + red_off) : (red_off == -2 ? (int*)a.splitk_tickets : nullptr);
     typedef g8::Lds<NI> L;
     constexpr int BM = 256, BN = 64 * NI, BK = 64, WN = 16 * NI, NL = L::NL;
     typedef void __attribute__((address_space(3)))* lptr_t;
@@ -1499,16 +1500,18 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         // 2..4 splits: reduced inside the launch by the last-arriving workgroup of every tile (see the kernel); the workspace then
         // holds tile-shaped fragment slabs [tile][split][fragment][thread] + one ticket word per tile (zeroed by a memset node)
         const size_t slabs = (size_t)ntm * ntn * splitk * BM * BN * sizeof(float);
-        const size_t need = (slabs + 255) / 256 * 256 + (size_t)ntm * ntn * sizeof(int);
+        const bool own_tickets = a.splitk_tickets != nullptr;       // (igemm_same_form: all of the group or none)
+        const size_t need = own_tickets ? slabs : (slabs + 255) / 256 * 256 + (size_t)ntm * ntn * sizeof(int);
         static int inlaunch = -1;
         if (inlaunch < 0) { const char* e = getenv("CTRL_SPLITK_INLAUNCH"); inlaunch = (e && e[0] == '0') ? 0 : 1; }
         bool fits = true;
         for (int i = 0; i < G; ++i) fits = fits && (size_t)grp_at(a, i).splitk_ws_bytes >= need;
         if (inlaunch && splitk <= 4 && fits) {
-            const long red_off = (long)((slabs + 255) / 256 * 256);
+            const long red_off = own_tickets ? -2L : (long)((slabs + 255) / 256 * 256);
             for (int i = 0; i < G; ++i) {
                 grp.a[i] = grp_at(a, i);
-                HIP_TRY(hipMemsetAsync((char*)grp.a[i].splitk_ws + red_off, 0, (size_t)ntm * ntn * sizeof(int), s));
+                // ticket words: the caller's zeroed ones, or the tail of the scratch, zeroed here (a kernel node: see op_fill_zero)
+                if (!own_tickets) TRY(op_fill_zero((char*)grp.a[i].splitk_ws + red_off, (size_t)ntm * ntn * sizeof(int), s));
             }
             char ex[40]; snprintf(ex, sizeof(ex), " splitk%d in-launch", splitk);
             prof_igemm(a, ex);
@@ -1560,6 +1563,13 @@ size_t igemm_splitk_ws_bytes(const IGemmArgs& a, int sk) {
     if (sk > 4) return rows;                     // the in-launch reduction serves 2..4 splits only
     const size_t frag = (tiles * sk * 256 * bn * sizeof(float) + 255) / 256 * 256 + tiles * sizeof(int);
     return rows > frag ? rows : frag;
+}
+
+// ticket words (one per 256-row output tile) of the in-launch reduction for `sk` splits; 0 when that form does not apply
+size_t igemm_splitk_ticket_words(const IGemmArgs& a, int sk) {
+    if (sk < 2 || sk > 4) return 0;
+    const int bn = (a.Nout % 320 == 0) ? 320 : 256;
+    return (size_t)((a.M + 255) / 256) * ((a.Nout + bn - 1) / bn);
 }
 
 int igemm_splitk_factor(const IGemmArgs& a) {
@@ -1723,7 +1733,7 @@ static bool igemm_same_form(const IGemmArgs& x, const IGemmArgs& y) {
               SAME(ldres) && SAME(scale) && SAME(geglu) && SAME(nseg) && SAME(act) && SAME(res_f32) && SAME(a_split) &&
               SAME(splitk_ws_bytes) && SAME(ld16) && SAME(ld_blend) && SAME(blend_f32) && SAME(out16_lo_off) && SAME(scale2) &&
               SAME(scale2_from) && SAME(scale2_to) && SAME(res_up) &&
-              SAMEP(A) && SAMEP(W) && SAMEP(bias) && SAMEP(rowvec) && SAMEP(res) && SAMEP(splitk_ws) && SAMEP(out16) && SAMEP(blend_mix) &&
+              SAMEP(A) && SAMEP(W) && SAMEP(bias) && SAMEP(rowvec) && SAMEP(res) && SAMEP(splitk_ws) && ((x.splitk_tickets == nullptr) == (y.splitk_tickets == nullptr)) && SAMEP(out16) && SAMEP(blend_mix) &&
               SAMEP(blend_x) && SAMEP(nonfinite);
     for (int i = 0; ok && i < x.nseg; ++i)
         ok = SAME(seg[i].ld) && SAME(seg[i].col_begin) && SAME(seg[i].ncols) && SAME(seg[i].fmt) && SAME(seg[i].dtype) && SAME(seg[i].L) &&

@@ -19,6 +19,8 @@ int op_igemm(const IGemmArgs& a, hipStream_t s);
 int igemm_splitk_factor(const IGemmArgs& a);
 // scratch bytes for that factor (>= factor * M * Nout * sizeof(float): the in-launch reduction of 2..4 splits keeps tile-shaped slabs)
 size_t igemm_splitk_ws_bytes(const IGemmArgs& a, int sk);
+// ticket words (ctrl_igemm_desc::splitk_tickets) the in-launch reduction of `sk` splits uses; 0 = that form does not apply
+size_t igemm_splitk_ticket_words(const IGemmArgs& a, int sk);
 // tile walk order of the implicit GEMM (tile_order.h): "legacy" | "auto" | "m,G" | "n,G"; 0 = accepted
 int igemm_set_order(const char* spec);
 // which problems take the 8-phase wide-tile kernel (igemm8_kernel): 0 none, 1 where the grid fills the chip (default), 2 every
@@ -123,6 +125,7 @@ int op_add_rowvec_clip(const void* x, int x_dt, const float* v, long ldv, void* 
 int op_upsample2x_nhwc(const half_t* x, half_t* y, int N, int H, int W, int C, hipStream_t s);
 // fill fp16/any
 int op_fill_zero(void* p, size_t bytes, hipStream_t s);
+int op_fill_zero_group(void* const* p, const size_t* bytes, int n, hipStream_t s);      // up to kMaxGroup fills in one launch
 // K-way weighted merge of NCHW tensors: out = sum_e w[widx[e]] * x_e   (router merge; weights on device)
 int op_weighted_merge(const void* const* xs_dev, const float* w, const int* widx_dev, int K, void* out, int dtype,
                       size_t n, hipStream_t s);
@@ -190,7 +193,7 @@ int op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* bet
 int op_gn_fused_group(const GnApplyArgs* a, int n, hipStream_t s);
 
 struct OpCollector {
-    enum { NONE = 0, IGEMM, GN_STATS, GN_APPLY, LAYERNORM, ATTN, GN_FUSED };
+    enum { NONE = 0, IGEMM, GN_STATS, GN_APPLY, LAYERNORM, ATTN, GN_FUSED, FILL };
     int type = NONE, n = 0;
     hipStream_t s = nullptr;
     IGemmArgs ig[kMaxGroup];
@@ -198,6 +201,7 @@ struct OpCollector {
     GnApplyArgs ga[kMaxGroup];
     LnArgs ln[kMaxGroup];
     AttnArgs at[kMaxGroup];
+    struct Fill { void* p; size_t bytes; } fz[kMaxGroup];
     // make room for one more problem of `type` on stream `s` (flushes what is pending when it cannot join); returns its index or -1
     int slot(int type_, hipStream_t s_, int* rc);
     int flush();

@@ -464,7 +464,11 @@ int run_block(Ctx& cx, const AdapterBlockW& b, const ctrl_adapter_config& c, con
             TRY(run_groupnorm(cx, b.norm, x, n, N, Lt, 1e-6f, false));
             // the spatial transformer's token stream: three residual updates on a stream that proj_in starts afresh, so it can be
             // kept in fp16 where the error budget allows (adapter_tok_f16(): measured per workload)
-            const bool tok16 = st && adapter_tok_f16() && cx.f32stream && !b.tok_f32;
+            // Round 5 narrowed it to the blocks it was measured on and pays on -- ONE layer, no temporal transformer (the SDXL adapters):
+            // with a temporal transformer behind it or a second layer on top, the fp16 stream costs 15-30 % of the error budget of the
+            // small-grid chains (config-5 miniature 1.00e-3 -> 7.1e-4, two-layer SDXL variant 8.5e-4 -> 5.9e-4 with the fp32 stream:
+            // profiles/r05_margin_sweep.txt); CTRL_ADAPTER_TOK_F16=force applies it everywhere as rounds 4 did.
+            const bool tok16 = st && adapter_tok_f16() && cx.f32stream && !b.tok_f32 && (adapter_tok_f16_forced() || (!tt && nl == 1));
             if (tok16) cx.f32stream = false;
             TV tok = stream_alloc(cx, (size_t)M * INNER, false);
             // the first LayerNorm of the spatial transformer rides on proj_in's epilogue

@@ -98,6 +98,10 @@ int run_conv(Ctx& cx, const ConvW& c, const half_t* x, const TV& y, int N, int H
     if (sk > 1) {
         g.splitk_ws_bytes = (int64_t)igemm_splitk_ws_bytes(g, sk);
         g.splitk_ws = cx.alloc((size_t)g.splitk_ws_bytes);
+        // ticket words of the in-launch reduction: a slice of the pool the forward zeroes ONCE (with the GroupNorm tickets) instead
+        // of a fill launch in front of every split-K convolution
+        const size_t tw = igemm_splitk_ticket_words(g, sk);
+        if (tw) g.splitk_tickets = (int32_t*)cx.stats(tw);
     }
     RUN(cx, op_igemm(g, cx.s));
     cx.release(mk);

@@ -494,6 +494,11 @@ inline bool adapter_tok_f16() {
     return !(e && e[0] == '0');
 }
 
+inline bool adapter_tok_f16_forced() {
+    const char* e = getenv("CTRL_ADAPTER_TOK_F16");
+    return e && e[0] == 'f';
+}
+
 // the adapter ResNets' conv1 -> GroupNorm intermediate in fp16 (CTRL_ADAPTER_H1_F16=1)
 inline bool adapter_h1_f16() {
     const char* e = getenv("CTRL_ADAPTER_H1_F16");

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTRL_ABI_VERSION 5
+#define CTRL_ABI_VERSION 6
 
 /* element types of boundary tensors */
 enum { CTRL_F32 = 0, CTRL_F16 = 1, CTRL_BF16 = 2 };
@@ -87,6 +87,9 @@ typedef struct ctrl_igemm_desc {
                            2: W = the plain pack [Cout][taps][Cin/2]; k-tiles alternate hi / lo chunk of the same channels and
                               each weight tile is staged once per pair (Cin/2 % 64 == 0) */
     void* splitk_ws; int64_t splitk_ws_bytes;   /* optional fp32 scratch: enables split-K for small-M / long-K problems */
+    int32_t* splitk_tickets;   /* optional (device): one ZEROED word per 256-row output tile for the in-launch reduction of 2..4 splits (the
+                                  plans hand out slices of a pool they zero once per forward); NULL = the library zeroes ticket words
+                                  at the end of splitk_ws with a fill launch of its own */
     void* out16; int64_t ld16;   /* optional fp16 row-major mirror of the (single, row-major) output: GEMM-operand copy of an fp32 stream */
     /* optional AlphaBlender fold (diffusers AlphaBlender, model/adapter_spatial_temporal.py:229,282), row-major outputs
      * only: out = (1-a) * y + a * blend_x[m*ld_blend + n], a = sigmoid(*blend_mix), y = the epilogue result above */

@@ -24,7 +24,7 @@ def kernel_class(name):
     if m:
         return {"0": "igemm_rows", "1": "igemm_conv", "2": "igemm_temporal"}[m.group(1)]
     for key in ("splitk_finish", "flash_attn", "temporal_attn", "gn_stats", "gn_apply", "gn_fused", "layernorm", "conv3x3_direct", "conv3x3_small_mfma",
-                "linear_small", "nchw_to_nhwc", "nhwc_to_nchw", "avgpool", "sincos", "blend", "add_rowvec", "merge"):
+                "linear_small", "nchw_to_nhwc", "nhwc_to_nchw", "avgpool", "sincos", "blend", "add_rowvec", "merge", "fill_zero"):
         if key in name:
             return key
     return None
