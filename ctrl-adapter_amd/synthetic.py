@@ -33,9 +33,11 @@ def seeded_init(module, seed=1234, fp16_round=True, gain=1.0, dist="normal", gam
                 z = torch.randn(p.shape, generator=g)
                 chi = torch.randn((4,) + tuple(p.shape), generator=g).pow(2).sum(0)
                 v = z / (chi / 4.0).sqrt() / 2.0 ** 0.5
+                v = v / fan_in ** 0.5
             else:
-                v = torch.randn(p.shape, generator=g)
-            v = v * (gain / fan_in ** 0.5)
+                v = torch.randn(p.shape, generator=g) / fan_in ** 0.5      # (exactly this expression: the committed goldens were drawn with it)
+            if gain != 1.0:
+                v = v * gain
         elif leaf == "weight":            # 1-D weight = GroupNorm / LayerNorm scale
             v = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
             if gamma_outliers > 0.0:
