@@ -221,6 +221,8 @@ def main():
     ap.add_argument("--clip-lanes", type=int, default=4, help="--clip-split, native transport: communicators = stream lanes of the adapter (1 = one stream)")
     ap.add_argument("--clip-transport", default="rccl", choices=["rccl", "torch"],
                     help="--clip-split: native RCCL enqueued from C++ (graph-capturable, default) or torch.distributed callbacks (eager)")
+    ap.add_argument("--profile-scope", default="step", choices=["step", "controlnet", "adapter"],
+                    help="what the per-kernel (HIP-event) leg runs: the whole step, the controlnet(...) call(s) alone, or the adapter(...) call alone")
     ap.add_argument("--fused", action="store_true",
                     help="time the fused controlled_step(controlnet, adapter, ...) instead of the pipelines' two calls "
                          "controlnet(...) ; adapter(...) (same arithmetic, bit-identical results)")
@@ -345,6 +347,15 @@ def main():
         ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
         median_ms = round(ts[len(ts) // 2], 3)
 
+    # what the LAST graph replay wrote (the timed artifact itself: replay number warmup + steps + len(evs)), copied out before
+    # anything else runs on these plans -- compared with the oracle in the cpu_baseline leg below
+    replay_out, replays = None, 0
+    if rank == 0 and mode == "hipgraph" and comm is None and not args.fused:
+        replays = args.warmup + args.steps + max(args.steps, 20)
+        (gd, gm), (ga, gam) = static_out
+        torch.cuda.synchronize()
+        replay_out = [v.float().cpu() for v in gd] + [gm.float().cpu()] + [v.float().cpu() for v in ga] + ([gam.float().cpu()] if gam is not None else [])
+
     # ---- the same step through the fused entry point (ControlNet on its own stream, adapter blocks start when their input
     #      exists): same arithmetic, bit-identical results; reported beside the headline, never as `value` ----
     fused = None
@@ -367,12 +378,24 @@ def main():
 
     # ---- roofline leg: eager steps with HIP events around every launch, on the launch stream (lanes off) ----
     kernels, per_kernel, roof = {}, [], None
+    below_quarter_ms, below_quarter_launches = 0.0, 0.0
     if rank == 0:
         from ctrl_adapter_amd import ops
         reps = 3
+        if args.profile_scope == "step":
+            prof_fn = step
+        else:
+            s_ = P.pool_latents(x["latents"], (64, 64))
+            down_, mid_ = controlnets(s_)
+            torch.cuda.synchronize()
+            if args.profile_scope == "controlnet":
+                prof_fn = lambda: controlnets(s_)      # noqa: E731
+            else:
+                kw_ = dict(clip_comm=comm) if comm is not None else {}
+                prof_fn = lambda: ad(down_, mid_block_res_sample=mid_, num_frames=nf, timestep=t, encoder_hidden_states=x["ehs_a"], **kw_)      # noqa: E731
         with ops.Profiler() as prof:
             for _ in range(reps):
-                step()
+                prof_fn()
         for k, v in prof.rows.items():
             ms = v[0] / reps
             kernels[k] = {"ms_per_step": round(ms, 4), "launches_per_step": v[1] // reps,
@@ -387,15 +410,22 @@ def main():
             fm = (r["tflops"] or 0.0) / MFMA_PEAK_TFLOPS
             fh = (r["gbs"] or 0.0) / HBM_PEAK_GBS
             if fm > 0.0 and fm >= fh:
-                bound, ach, peak = "mfma", r["tflops"], MFMA_PEAK_TFLOPS
+                nearest, ach, peak = "mfma", r["tflops"], MFMA_PEAK_TFLOPS
             elif fh > 0.0:
-                bound, ach, peak = "hbm", r["gbs"], HBM_PEAK_GBS
+                nearest, ach, peak = "hbm", r["gbs"], HBM_PEAK_GBS
             else:
-                bound, ach, peak = None, None, None
+                nearest, ach, peak = None, None, None
+            # a launch below a quarter of BOTH roofs is bound by neither (latency / epilogue / occupancy): it is labelled "none" and
+            # its time is summed into the headline's `ms_below_quarter_roof`
+            bound = nearest if max(fm, fh) >= 0.25 else ("none" if nearest else None)
+            if bound == "none":
+                below_quarter_ms += r["ms_per_step"]
+                below_quarter_launches += r["launches_per_step"]
             per_kernel.append({"kernel": k, "class": r["tag"], "launches_per_step": round(r["launches_per_step"], 2),
                                "ms_per_step": round(r["ms_per_step"], 4), "avg_launch_ms": round(r["avg_launch_ms"], 5),
-                               "bound": bound, "achieved": round(ach, 1) if ach else None,
-                               "frac": round(ach / peak, 4) if ach else None, "grid": r["grid"]})
+                               "bound": bound, "nearest_roof": nearest, "achieved": round(ach, 1) if ach else None,
+                               "frac": round(ach / peak, 4) if ach else None, "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+                               "grid": r["grid"]})
         dom = next((k for k in order if rows[k]["tflops"] or rows[k]["gbs"]), None)
         if dom is not None:
             r = rows[dom]
@@ -463,16 +493,40 @@ def main():
             e = ((a - b).abs().max() / den).item()
             if not (e <= worst):                     # NaN-propagating maximum
                 worst, worst_name = e, name
-        parity = {"rel_inf_worst": float("%.3e" % worst), "tensor": worst_name, "tensors": ntens, "zero_slots_exact": zeros_ok,
-                  "bound": 1e-3, "ok": bool(worst <= 1e-3 and zeros_ok),
-                  "what": "HIP step (these plans, these %d distinct inputs) vs fp32 oracle -> oracle chain" % n}
+        eager = {"rel_inf_worst": float("%.3e" % worst), "tensor": worst_name, "zero_slots_exact": zeros_ok,
+                 "what": "a separate EAGER step of the same plans / inputs vs the oracle"}
+
+        def worst_vs_oracle(outs):
+            wv, wn_, zok, nt = 0.0, None, True, 0
+            for (name, _), a, b in zip(hip_out, outs, ref_out):
+                nt += 1
+                den = b.abs().max().item()
+                if den == 0.0:                       # non-selected adapter slots are zeros_like (model/ctrl_adapter.py:193)
+                    zok = zok and a.abs().max().item() == 0.0
+                    continue
+                e = ((a - b).abs().max() / den).item()
+                if not (e <= wv):                    # NaN-propagating maximum
+                    wv, wn_ = e, name
+            return wv, wn_, zok, nt
+        if replay_out is not None:
+            # the headline's parity is that of the thing that was TIMED: the tensors the last hipGraph replay left behind
+            wv, wn_, zok, nt = worst_vs_oracle(replay_out)
+            same = all(torch.equal(a, b) for (_, a), b in zip(hip_out, replay_out))
+            parity = {"rel_inf_worst": float("%.3e" % wv), "tensor": wn_, "tensors": nt, "zero_slots_exact": zok,
+                      "bound": 1e-3, "ok": bool(wv <= 1e-3 and zok),
+                      "what": "hipGraph replay #%d (the timed graph's own output tensors, %d distinct inputs) vs fp32 oracle -> oracle chain" % (replays, n),
+                      "replay_bit_identical_to_eager": bool(same), "eager": eager}
+        else:
+            parity = dict(eager, tensors=ntens, bound=1e-3, ok=bool(worst <= 1e-3 and zeros_ok),
+                          what="HIP step (eager; these plans, these %d distinct inputs) vs fp32 oracle -> oracle chain" % n)
 
     # ---- the other north-star workloads (BASELINE configs 3, 4, 5 and the CFG-doubled SDXL batch), after the headline's timed
     #      region, the default single-GPU invocation only (the N > 1 scaling runs stay short): `other_workloads` of the headline ----
     others = None
     if args.workload == "sdxl" and args.batch == 8 and world == 1 and comm is None and not args.no_graph and not args.fused and not args.no_other_workloads:
         others = {}
-        for name, wn, b in (("svd16", "svd16", 0), ("i2vgen16", "i2vgen16", 0), ("multi3", "multi3", 0), ("sdxl_b16", "sdxl", 16)):
+        for name, wn, b in (("svd16", "svd16", 0), ("i2vgen16", "i2vgen16", 0), ("multi3", "multi3", 0), ("sdxl_b16", "sdxl", 16),
+                               ("sdxl_b2_cfg_pair", "sdxl", 2)):      # (the last one: BASELINE config 1's shape, one image + its CFG twin)
             try:
                 others[name] = quick_time(dev, wn, b, 20, 3, world)
             except Exception as e:
@@ -485,7 +539,8 @@ def main():
         if kernels or per_kernel:
             try:
                 with open(args.per_kernel_out, "w") as fh:
-                    json.dump({"workload": args.workload, "batch_per_gpu": n, "ms_per_step": round(ms_per_step, 3),
+                    json.dump({"workload": args.workload, "batch_per_gpu": n, "ms_per_step": round(ms_per_step, 3), "scope": args.profile_scope,
+                               "scope_ms": round(sum(v["ms_per_step"] for v in kernels.values()), 3),
                                "kernels": kernels, "per_kernel": per_kernel}, fh, indent=0)
             except OSError as e:
                 print("bench: per-kernel table not written (%s)" % e, file=sys.stderr)
@@ -508,7 +563,11 @@ def main():
             "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
             "mfma_frac_whole_step": round(flops_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "launches_per_step": launches,        # kernel launches of one step (HIP-event leg: eager, lanes off)
-            "hbm_gb_per_step": hbm_gb, "hbm_gb_source": hbm_src,      # PMC counters of the committed profile run of this workload
+            # time of the launches below a quarter of BOTH roofs (per_kernel rows with bound "none"), same HIP-event leg
+            "ms_below_quarter_roof": round(below_quarter_ms, 3) if per_kernel else None,
+            "launches_below_quarter_roof": int(round(below_quarter_launches)) if per_kernel else None,
+            # NOT measured by this run: PMC counters of the newest committed profile of this workload (tools/profile_round.sh)
+            "committed_profile": {"hbm_gb_per_step": hbm_gb, "source": hbm_src} if hbm_gb else None,
             "fused_step": fused, "roofline": roof, "cpu_baseline": cpu, "parity_at_bench_config": parity, "other_workloads": others,
             "next_kernels": top, "per_kernel_file": os.path.basename(args.per_kernel_out) if (kernels or per_kernel) else None,
         }

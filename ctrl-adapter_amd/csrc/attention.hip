@@ -510,7 +510,7 @@ static int flash_attn_launch(const AttnArgs& a, hipStream_t s) {
         case 64:
             if (attn_variant() > 0 && flash_attn_d64_applies(a)) return op_flash_attn_d64(a, s, attn_variant());
             // long sequences: 256 queries per workgroup halve the K/V LDS-DMA traffic per FLOP (the limiter at L = 16384)
-            if (a.Lq >= 2048 && !getenv("CTRL_ATTN_NW4")) return launch_attn<64, 8, false>(a, s);
+            if (a.Lq >= 2048 && !policy_raw(P_ATTN_NW4)) return launch_attn<64, 8, false>(a, s);
             return launch_attn<64, 4, true>(a, s);
         case 40: return launch_attn<40, 4, true>(a, s);
         case 80: return launch_attn<80, 4, true>(a, s);

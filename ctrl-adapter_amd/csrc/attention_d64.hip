@@ -665,7 +665,7 @@ bool flash_attn_d64_applies(const AttnArgs& a) {
 int attn_set_variant(int v) { g_variant = v; return 0; }
 int attn_variant() {
     if (g_variant < 0) {
-        const char* e = getenv("CTRL_ATTN_VARIANT");
+        const char* e = policy_raw(P_ATTN_VARIANT);
         g_variant = e ? atoi(e) : 2;
         if (g_variant < 0 || g_variant > 14) {        // (a bad value used to surface as "unknown variant" inside every long-sequence forward)
             fprintf(stderr, "ctrl: CTRL_ATTN_VARIANT=%s is not a variant (0..14), using the default\n", e);

@@ -5,15 +5,14 @@
 
 thread_local OpCollector* t_collect = nullptr;
 
-static int g_group = -1;
 static int group_mode() {
-    if (g_group < 0) { const char* e = getenv("CTRL_GROUP"); g_group = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)); }
-    return g_group;
+    const char* e = policy_raw(P_GROUP);
+    return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1));
 }
 bool group_launches_enabled() { return group_mode() != 0; }
 bool group_tiles_as_alone() { return group_mode() == 2; }
 extern "C" int ctrl_group_launches(int on) {
-    if (on >= 0 && on <= 2) g_group = on;
+    if (on >= 0 && on <= 2) { const char* v[3] = {"0", "1", "2"}; (void)ctrl_policy_set("CTRL_GROUP", v[on]); }
     return group_mode();
 }
 

@@ -1332,7 +1332,7 @@ OrderSpec parse_order(const char* t) {
 // splitting the weight panels over the XCDs instead ("n,G") never won.  Everything else keeps the legacy walk.
 int plan_order(const IGemmArgs& a, int BM, int BN, int ntm, int ntn) {
     if (g_order_spec.kind == -1) {
-        const char* e = getenv("CTRL_IGEMM_ORDER");
+        const char* e = policy_raw(P_IGEMM_ORDER);
         g_order_spec = e ? parse_order(e) : OrderSpec{1, 0, 0};
         if (g_order_spec.kind == -2) { fprintf(stderr, "ctrl: CTRL_IGEMM_ORDER not understood, using auto\n"); g_order_spec = {1, 0, 0}; }
     }
@@ -1456,8 +1456,9 @@ bool can_swap(const IGemmArgs& a) {
 // through it this way), default = where the grid fills the chip
 int g_igemm8_mode = -1;
 int igemm8_mode() {
-    if (g_igemm8_mode < 0) { const char* e = getenv("CTRL_IGEMM8"); g_igemm8_mode = !e ? 1 : (e[0] == '0' ? 0 : (!strcmp(e, "force") ? 2 : 1)); }
-    return g_igemm8_mode;
+    if (g_igemm8_mode >= 0) return g_igemm8_mode;      // ctrl_igemm_set_wide (test ABI)
+    const char* e = policy_raw(P_IGEMM8);
+    return !e ? 1 : (e[0] == '0' ? 0 : (!strcmp(e, "force") ? 2 : 1));
 }
 bool can_use8(const IGemmArgs& a) {
     if (!igemm8_mode() || !can_swap(a)) return false;
@@ -1502,8 +1503,7 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         const size_t slabs = (size_t)ntm * ntn * splitk * BM * BN * sizeof(float);
         const bool own_tickets = a.splitk_tickets != nullptr;       // (igemm_same_form: all of the group or none)
         const size_t need = own_tickets ? slabs : (slabs + 255) / 256 * 256 + (size_t)ntm * ntn * sizeof(int);
-        static int inlaunch = -1;
-        if (inlaunch < 0) { const char* e = getenv("CTRL_SPLITK_INLAUNCH"); inlaunch = (e && e[0] == '0') ? 0 : 1; }
+        const int inlaunch = policy_is0(P_SPLITK_INLAUNCH) ? 0 : 1;
         bool fits = true;
         for (int i = 0; i < G; ++i) fits = fits && (size_t)grp_at(a, i).splitk_ws_bytes >= need;
         if (inlaunch && splitk <= 4 && fits) {
@@ -1631,7 +1631,8 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
             return launch_cfg2<256, 256, 32, 2, 4, 4, MODE, true>(a, s, sk);
         }
     }
-    if (const char* f = getenv("CTRL_IGEMM_FORCE")) {      // tile experiments (tools/tile_experiment.py), row outputs only
+    const char* const forced = policy_raw(P_IGEMM_FORCE);
+    if (const char* f = forced) {      // tile experiments (tools/tile_experiment.py), row outputs only
         if (can_swap(a) && MODE == IG_ROWS && a.nseg == 1 && !a.geglu) {
             // round 5, short launches of the small-M chain (tools/gemm_order_bench small): 4-wave tiles at three workgroups per CU
             if (!strcmp(f, "128x128x32")) return launch_cfg2<128, 128, 32, 2, 2, 3, MODE, true>(a, s);
@@ -1643,11 +1644,13 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
                 if (a.Nout % 256 == 0) return launch8<4, MODE>(a, s);
             }
         }
+        // (a mixed-layout problem -- Q | K row-major + V^T transposed -- only takes a forced tile whose width divides the transposed
+        // segment's first column: a tile must lie in one segment, the epilogue's choice is workgroup-uniform)
         if (can_swap(a) && MODE == IG_ROWS) {
-            if (!strcmp(f, "128x256")) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
-            if (!strcmp(f, "256x128")) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
-            if (!strcmp(f, "4w256x128")) return launch_cfg2<256, 128, 32, 2, 2, 3, MODE, true>(a, s);      // 4 waves x 256 registers, two workgroups per CU
-            if (!strcmp(f, "4w128x256")) return launch_cfg2<128, 256, 32, 1, 4, 3, MODE, true>(a, s);
+            if (!strcmp(f, "128x256") && al(256)) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
+            if (!strcmp(f, "256x128") && al(128)) return launch_cfg2<256, 128, 32, 4, 2, 3, MODE, true>(a, s);
+            if (!strcmp(f, "4w256x128") && al(128)) return launch_cfg2<256, 128, 32, 2, 2, 3, MODE, true>(a, s);      // 4 waves x 256 registers, two workgroups per CU
+            if (!strcmp(f, "4w128x256") && al(256)) return launch_cfg2<128, 256, 32, 1, 4, 3, MODE, true>(a, s);
         }
     }
     // Epilogue-heavy token GEMMs at large M with a SHORT k-loop (measured, tools/tile_experiment.py -> profiles/r02_tile_experiment.log,
@@ -1663,12 +1666,12 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
         // fp16 stream updates (the adapter's token stream since round 4) with a k-loop of <= 8 k-tiles: the residual read + store of
         // the epilogue still outweighs the loop -- M131072 N512 K320 + residual: 0.164 ms (8-phase) vs 0.128 ms (this pair tile),
         // -0.12 ms per SDXL step, -0.27 ms fused (one call, gpurun_out/r4p); CTRL_SHORTK_PAIR=0 switches it off
-        static const bool pair16 = !(getenv("CTRL_SHORTK_PAIR") && getenv("CTRL_SHORTK_PAIR")[0] == '0');
+        const bool pair16 = !policy_is0(P_SHORTK_PAIR);
         if (pair16 && a.res && a.Ktot <= 512) return launch_cfg2<128, 256, 32, 2, 4, 3, MODE, true>(a, s);
     }
     // the 8-phase wide tiles wherever the grid fills the chip with them (1.3-1.5x the BK = 32 ring kernel on plain epilogues and
     // long k-loops: convolutions 543 -> 671 TFLOP/s as a class)
-    if (can_use8(a) && (getenv("CTRL_IGEMM_FORCE") == nullptr)) {
+    if (can_use8(a) && forced == nullptr) {
         if (a.Nout % 320 == 0 && (tiles(256, 320) >= 160 || force8) && !a.geglu && al(320)) return launch8<5, MODE>(a, s);
         if (a.Nout % 256 == 0 && (tiles(256, 256) >= 200 || force8) && al(256)) return launch8<4, MODE>(a, s);
     }
@@ -1687,7 +1690,7 @@ int dispatch(const IGemmArgs& a, hipStream_t s) {
     // path's shapes (tools/gemm_order_bench small -> profiles/r05_gemm_small_tiles.txt): the 4-wave 128 x 128 x 32 tile at three
     // workgroups per CU beats the 8-wave 128 x 128 x 64 tile (one per CU) by 10-18 % from ~500 tiles on, the 64 x 64 x 64 tile
     // (three per CU) by 10-20 % below that for N <= 1280.  CTRL_SMALL_TILES=0: the round-4 choice.
-    static const bool small_tiles = !(getenv("CTRL_SMALL_TILES") && getenv("CTRL_SMALL_TILES")[0] == '0');
+    const bool small_tiles = !policy_is0(P_SMALL_TILES);
     if (small_tiles && MODE == IG_ROWS && can_swap(a) && !a.geglu) {
         if (tiles(128, 128) >= 512 && eff(128) > 0.8 && al(128)) return launch_cfg2<128, 128, 32, 2, 2, 3, MODE, true>(a, s);
         if (tiles(128, 128) < 512 && a.Nout <= 1280 && al(64)) return launch_cfg2<64, 64, 64, 2, 2, 3, MODE, true>(a, s);

@@ -593,8 +593,7 @@ bool op_gn_fused_fits(int x_dtype, int rows_per_img, int C, int G) {
 // per launch against 10 + 10 us for the two launches it replaces, which run on 768-2048 workgroups); it would pay only on the 8^2 level
 // (~5 us per norm).  CTRL_GN_FUSED=1 switches it on; the op stays covered by tests/test_gpu_ops.py::test_groupnorm_fused_small_maps.
 bool op_gn_fused_applies(int x_dtype, int rows_per_img, int C, int G) {
-    static const bool on = getenv("CTRL_GN_FUSED") && getenv("CTRL_GN_FUSED")[0] == '1';
-    return on && op_gn_fused_fits(x_dtype, rows_per_img, C, G);
+    return policy_is1(P_GN_FUSED) && op_gn_fused_fits(x_dtype, rows_per_img, C, G);
 }
 
 int op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* beta, half_t* y, int imgs, int rows_per_img, int C, int G,

@@ -4,6 +4,7 @@
 // normalisation statistics, softmax and all epilogue math are fp32.
 #pragma once
 #include "common.h"
+#include "policy.h"
 #include "../../include/ctrl_hip.h"
 
 // ------------------------------------------------------------------------------------------

@@ -364,8 +364,7 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
 // token in the K|V all_gather form (C = 320 .. 1280): 4x .. 27x fewer bytes at G = 8.  The AlphaBlender of the block's
 // output with the spatial branch (:282) is applied after the way back (op_blend).
 bool clip_a2a_enabled() {
-    static const bool on = [] { const char* e = getenv("CTRL_CLIP_A2A"); return !(e && e[0] == '0'); }();
-    return on;
+    return !policy_is0(P_CLIP_A2A);
 }
 int run_temporal_tb_pixel_sharded(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, const AFwd& a, int L,
                                   const float* blend_mix, const TV& blend_other, const float* ov) {
@@ -879,9 +878,8 @@ static int adapter_forward_impl(ctrl_adapter* h, const void* const* ins, int in_
         N_out = N;
     }
     // lanes are off while the per-launch profiler is recording (overlapping kernels make per-kernel times meaningless)
-    static const bool split_top = getenv("CTRL_ADAPTER_SPLIT_TOP") && atoi(getenv("CTRL_ADAPTER_SPLIT_TOP")) != 0;
-    static const int env_lanes = getenv("CTRL_ADAPTER_LANES") ? atoi(getenv("CTRL_ADAPTER_LANES"))
-                                                              : (split_top ? (int)ctrl_adapter::kLanes : (int)ctrl_adapter::kLevelLanes);
+    const bool split_top = policy_int(P_ADAPTER_SPLIT_TOP, 0) != 0;
+    const int env_lanes = policy_int(P_ADAPTER_LANES, split_top ? (int)ctrl_adapter::kLanes : (int)ctrl_adapter::kLevelLanes);
     // frame-sharded clips: the exchanges of one communicator must be issued and executed in the same order on every rank, so
     // there are as many lanes as the caller chained transports (ctrl_clip_comm::next_lane; one = everything on the caller's stream)
     int comm_lanes = 0;

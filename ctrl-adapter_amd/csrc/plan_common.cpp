@@ -187,7 +187,7 @@ static int run_self_attn(Ctx& cx, const AttnW& w, const half_t* xn, int dim, con
     // the attention kernel's A operand) through the LDS-transposed one -- a tile lies in one segment because the dispatcher only
     // picks tile widths that divide 2 * Ci (ctrl_igemm_desc::seg), so the activation panel is read once instead of twice and the
     // grid has 1.5 x the tiles of the Q|K launch.  CTRL_QKV_ONE=0: the two launches of rounds 1-4 (bit-identical results).
-    static const bool qkv_one = !(getenv("CTRL_QKV_ONE") && getenv("CTRL_QKV_ONE")[0] == '0');
+    const bool qkv_one = !policy_is0(P_QKV_ONE);
     IGemmArgs g = {};
     g.A = xn; g.lda = dim; g.mode = IG_ROWS; g.Cin = dim; g.taps = 1;
     g.W = w.qkv.w; g.M = M; g.Nout = 2 * Ci; g.Ktot = dim; g.scale = 1.f;
@@ -245,7 +245,7 @@ int project_text_kv(Ctx& cx, const AttnW& w, const EhsCtx& e, PreKV* out) {
         if (e.Lk % 8) RUN(cx, op_fill_zero(vt, (size_t)e.batch * Ci * Lkpad * sizeof(half_t), cx.s));   // finite pad columns
         // K | V^T of the text states in ONE launch (round 5; 77 tokens per prompt are not a multiple of 8, so the mixed segment list
         // takes the scalar epilogue -- as the V launch always did; these GEMMs have 616 rows): K pre-scaled, V plain
-        static const bool kv_one = !(getenv("CTRL_QKV_ONE") && getenv("CTRL_QKV_ONE")[0] == '0');
+        const bool kv_one = !policy_is0(P_QKV_ONE);
         IGemmArgs g = {};
         g.A = e.h16; g.lda = e.cross; g.mode = IG_ROWS; g.Cin = e.cross; g.taps = 1;
         g.W = w.kv.w; g.M = Mk; g.Nout = Ci; g.Ktot = e.cross; g.scale = attn_k_scale(w.D);     // pre-scaled K

@@ -483,26 +483,23 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
 
 // fp32 residual streams are the default; CTRL_STREAM_F32=0 selects fp16 streams (faster by a few %, ~2x the error)
 inline bool stream_f32_enabled() {
-    const char* e = getenv("CTRL_STREAM_F32");
-    return !(e && e[0] == '0');
+    return !policy_is0(P_STREAM_F32);
 }
 
 // the adapter's spatial-transformer token stream in fp16 (default since round 4; CTRL_ADAPTER_TOK_F16=0: fp32 like the ControlNet's
 // and the temporal streams, which stay fp32)
 inline bool adapter_tok_f16() {
-    const char* e = getenv("CTRL_ADAPTER_TOK_F16");
-    return !(e && e[0] == '0');
+    return !policy_is0(P_ADAPTER_TOK_F16);
 }
 
 inline bool adapter_tok_f16_forced() {
-    const char* e = getenv("CTRL_ADAPTER_TOK_F16");
+    const char* e = policy_raw(P_ADAPTER_TOK_F16);
     return e && e[0] == 'f';
 }
 
 // the adapter ResNets' conv1 -> GroupNorm intermediate in fp16 (CTRL_ADAPTER_H1_F16=1)
 inline bool adapter_h1_f16() {
-    const char* e = getenv("CTRL_ADAPTER_H1_F16");
-    return e && e[0] == '1';
+    return policy_is1(P_ADAPTER_H1_F16);
 }
 
 // ------------------------------------------------------------------------------------------ tensor views

@@ -45,8 +45,7 @@ struct ControlNetW {
 };
 
 bool cn_split_enabled() {
-    const char* e = getenv("CTRL_CN_SPLIT");
-    return !(e && e[0] == '0') && stream_f32_enabled();
+    return !policy_is0(P_CN_SPLIT) && stream_f32_enabled();
 }
 // How deep the split goes (CTRL_CN_SPLIT_LEVELS, default 3): down blocks 0 .. levels-1 take split operands (mid block =
 // level 4); the 13 zero-convs always do.  Round 3: the 8x8 level (down block 3 + mid block) is where a split conv costs
@@ -55,8 +54,7 @@ bool cn_split_enabled() {
 // the all-exact level (+0..5e-5), while also un-splitting the 16x16 level costs ~1e-4 -- measured on the GPU at the SVD-16
 // shapes: chain mid output 1.01e-3 with levels = 2 (profiles/r03_split_levels.md), over the bound.
 int cn_split_levels() {
-    const char* e = getenv("CTRL_CN_SPLIT_LEVELS");
-    const int v = e ? atoi(e) : 3;
+    const int v = policy_int(P_CN_SPLIT_LEVELS, 3);
     return v < 0 ? 0 : (v > 5 ? 5 : v);
 }
 // The same depth for the ResNets' 3x3 convolutions alone (CTRL_CN_SPLIT_RESNET_LEVELS, default = CTRL_CN_SPLIT_LEVELS): the CPU emulation
@@ -68,7 +66,7 @@ int cn_split_levels() {
 // adapter) came out at 1.001e-3 on one tensor -- the emulation's +0.5e-4 on that very chain is real, and the margins of this path are
 // thinner than that.  So the default stays = CTRL_CN_SPLIT_LEVELS (every convolution of down blocks 0-2 split) and "1" remains an opt-in.
 int cn_split_resnet_levels() {
-    const char* e = getenv("CTRL_CN_SPLIT_RESNET_LEVELS");
+    const char* e = policy_raw(P_CN_SPLIT_RESNET_LEVELS);
     const int lv = cn_split_levels();
     if (!e) return lv;
     const int v = atoi(e);
@@ -76,7 +74,7 @@ int cn_split_resnet_levels() {
 }
 // CTRL_CN_SPLIT=dup: the first form of the split (weights packed twice, [hi | lo] walked as one long K) for A/B runs
 bool cn_split_paired() {
-    const char* e = getenv("CTRL_CN_SPLIT");
+    const char* e = policy_raw(P_CN_SPLIT);
     return !(e && e[0] == 'd');
 }
 
@@ -367,7 +365,7 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
             } else if ((int)i < w.n_direct) {
                 CTRL_CHECK(!last, "controlnet: the conditioning embedder must end with an implicit-GEMM layer");
                 // channels-last 16 / 32-channel layers: on the matrix cores (round 5; CTRL_SMALLCONV_MFMA=0: the direct VALU kernel)
-                static const bool small_mfma = !(getenv("CTRL_SMALLCONV_MFMA") && getenv("CTRL_SMALLCONV_MFMA")[0] == '0');
+                const bool small_mfma = !policy_is0(P_SMALLCONV_MFMA);
                 if (small_mfma && !nchw && cur_dt == DT_F16 && w.ce_direct[i].w16)
                     RUN(cx, op_conv3x3_small_mfma((const half_t*)cur, w.ce_direct[i].w16, w.ce_direct[i].b, y16, N, ch, co, hh, ww, st, 1, cx.s));
                 else
@@ -580,7 +578,7 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
         }
         cache = h->cond_cache;
     }
-    static const bool aux_env = !(getenv("CTRL_CN_AUX") && atoi(getenv("CTRL_CN_AUX")) == 0);
+    const bool aux_env = policy_int(P_CN_AUX, 1) != 0;
     FwdArgs a = {sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
                  controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, out_ev, cache, reuse,
                  h, aux_env && !g_prof_on && out_ev == nullptr};

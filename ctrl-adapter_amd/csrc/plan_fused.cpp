@@ -30,7 +30,7 @@ extern "C" int ctrl_step_forward(ctrl_controlnet* cn, ctrl_adapter* ad, const vo
                                  void* stream) {
     CTRL_CHECK(cn && ad && cn_outs && outs, "step_forward: null argument");
     hipStream_t s = (hipStream_t)stream;
-    static const bool env_off = getenv("CTRL_STEP_OVERLAP") && atoi(getenv("CTRL_STEP_OVERLAP")) == 0;
+    const bool env_off = policy_int(P_STEP_OVERLAP, 1) == 0;
     const bool async = !g_prof_on && !env_off;      // per-launch profiling needs one kernel at a time
     hipEvent_t* out_ev = nullptr; hipEvent_t done = nullptr;
     TRY(controlnet_forward_async(cn, sample, sample_dtype, N, Hs, Ws, cn_timesteps, cn_t_count, cn_ehs, cn_ehs_dtype, cn_Lk,

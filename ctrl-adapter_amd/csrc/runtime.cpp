@@ -1,6 +1,7 @@
 // Runtime glue of libctrlhip: thread-local error string and the per-kernel-class HIP-event profiler
 // used by bench.py's roofline leg (events are recorded on the stream the kernels are launched on).
 #include "common.h"
+#include "policy.h"
 #include "../../include/ctrl_hip.h"
 #include <map>
 #include <mutex>
@@ -28,7 +29,7 @@ const void* device_zero_page() {
 // ---- range check of the fp16 activations (ctrl_range_check / CTRL_CHECK_FINITE) ----
 static int g_range_on = -1;
 bool range_check_on() {
-    if (g_range_on < 0) { const char* e = getenv("CTRL_CHECK_FINITE"); g_range_on = (e && e[0] == '1') ? 1 : 0; }
+    if (g_range_on < 0) g_range_on = policy_is1(P_CHECK_FINITE) ? 1 : 0;
     return g_range_on == 1;
 }
 int* range_flag() {
@@ -112,7 +113,7 @@ int ctrl_prof_end(void) {
     HIP_TRY(hipDeviceSynchronize());
     std::map<std::string, Sum> acc;
     FILE* dump = nullptr;
-    if (const char* path = getenv("CTRL_PROF_DUMP")) dump = fopen(path, "w");
+    if (const char* path = policy_raw(P_PROF_DUMP)) dump = fopen(path, "w");
     for (auto& r : g_recs) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.e0, r.e1);

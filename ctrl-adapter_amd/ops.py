@@ -114,6 +114,26 @@ def set_group_launches(mode):
     return int(L.lib().ctrl_group_launches(-1 if mode is None else int(mode)))
 
 
+def set_policy(name, value):
+    """overrides one CTRL_* variable of the library's policy table for this process (csrc/policy.h; value None = unset, as if the
+    variable were absent from the environment); returns the previous value (None = unset).  Test / experiment hook."""
+    prev = L.lib().ctrl_policy_get(name.encode())
+    L.check(L.lib().ctrl_policy_set(name.encode(), None if value is None else str(value).encode()))
+    return None if prev is None else prev.decode()
+
+
+def policy():
+    """{name: value} of every CTRL_* variable that is set (environment snapshot + overrides)"""
+    lib = L.lib()
+    out = {}
+    for i in range(lib.ctrl_policy_count()):
+        n = lib.ctrl_policy_name(i)
+        v = lib.ctrl_policy_get(n)
+        if v is not None:
+            out[n.decode()] = v.decode()
+    return out
+
+
 def set_attn_variant(v):
     """instruction-selection variant of the head_dim-64 long-sequence attention kernel (0 = the round-2 kernel); every
     variant computes the same function (csrc/attention_d64.hip)"""

@@ -138,6 +138,15 @@ int ctrl_igemm_set_wide(int mode);
    size; 2 on with the tile every problem would get alone: bit-identical to the one-by-one forward; 0 off; -1 queries.  Returns the
    mode.  Every mode is bit-reproducible run to run. */
 int ctrl_group_launches(int on);
+/* Run-time policy table (csrc/policy.h): every CTRL_* environment variable the library understands is read ONCE, at the first query, into
+   one table -- no dispatcher, plan or op calls getenv().  Test / experiment ABI: ctrl_policy_set(name, value) overrides an entry for the
+   process (value NULL = unset; 0 = accepted, 1 = unknown name), ctrl_policy_get(name) returns the value in force (NULL = unset or unknown),
+   ctrl_policy_count / ctrl_policy_name(i) list the names (a bench line can record what a run was taken with).  Not to be called
+   concurrently with a forward. */
+int ctrl_policy_set(const char* name, const char* value);
+const char* ctrl_policy_get(const char* name);
+int ctrl_policy_count(void);
+const char* ctrl_policy_name(int i);
 int ctrl_igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, int* tile_n);
 
 typedef struct ctrl_attn_desc {

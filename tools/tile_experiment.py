@@ -45,14 +45,11 @@ def main():
                       out16=mir, ld16=on)
         line = "%-22s M%d N%d K%d:" % (name, M, N, K)
         for tile in ("", "128x256", "256x128", "128x320"):
-            if tile:
-                os.environ["CTRL_IGEMM_FORCE"] = tile
-            else:
-                os.environ.pop("CTRL_IGEMM_FORCE", None)
+            ops.set_policy("CTRL_IGEMM_FORCE", tile or None)
             ms = timeit(run)
             line += "  %s %.3f ms %.0f TF" % (tile or "default", ms, 2.0 * M * N * K / ms / 1e9)
         print(line)
-    os.environ.pop("CTRL_IGEMM_FORCE", None)
+    ops.set_policy("CTRL_IGEMM_FORCE", None)
 
 
 if __name__ == "__main__":
