@@ -10,6 +10,14 @@ int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream) {
     CTRL_CHECK(d != nullptr, "igemm: null descriptor");
     return op_igemm(*d, S(stream));
 }
+int ctrl_op_ffn(const ctrl_ffn_desc* d, void* stream) {
+    CTRL_CHECK(d != nullptr, "ffn: null descriptor");
+    return op_ffn_fused_group(d, 1, S(stream));
+}
+int ctrl_op_ffn_pack_w2(const void* w2_packed, void* out, int N, int K, void* stream) {
+    CTRL_CHECK(w2_packed && out, "ffn_pack_w2: null argument");
+    return op_ffn_pack_w2((const half_t*)w2_packed, (half_t*)out, N, K, S(stream));
+}
 int ctrl_igemm_set_order(const char* spec) { return igemm_set_order(spec); }
 int ctrl_igemm_set_wide(int mode) {
     CTRL_CHECK(mode >= -1 && mode <= 2, "igemm_set_wide: mode must be -1 (default), 0 (never), 1 (auto) or 2 (every eligible problem)");

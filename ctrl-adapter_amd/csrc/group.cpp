@@ -38,6 +38,14 @@ int OpCollector::flush() {
         case LAYERNORM: rc = op_layernorm_group(ln, n, s); break;
         case ATTN: rc = op_flash_attn_group(at, n, s); break;
         case GN_FUSED: rc = op_gn_fused_group(ga, n, s); break;
+        case FFN: {
+            // (problems of different M cannot share the launch: one by one then)
+            bool same = true;
+            for (int i = 1; i < n; ++i) same = same && ff[i].out.M == ff[0].out.M;
+            if (same) rc = op_ffn_fused_group(ff, n, s);
+            else for (int i = 0; i < n && !rc; ++i) rc = op_ffn_fused_group(&ff[i], 1, s);
+            break;
+        }
         case FILL: {
             void* ps[kMaxGroup]; size_t bs[kMaxGroup];
             for (int i = 0; i < n; ++i) { ps[i] = fz[i].p; bs[i] = fz[i].bytes; }

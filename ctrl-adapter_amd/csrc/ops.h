@@ -34,6 +34,13 @@ void igemm_tile_of(int bid, int ntm, int ntn, int mode, int group, int* tile_m, 
 constexpr int kMaxIGemmGroup = 4;
 constexpr int kMaxGroup = kMaxIGemmGroup;
 int op_igemm_group(const IGemmArgs* a, int n, hipStream_t s);
+// Fused GEGLU feed-forward, dim 512 / hidden 2048 (ffn.hip; include/ctrl_hip.h: ctrl_ffn_desc): one launch instead of the GEGLU GEMM +
+// the K = 2048 GEMM; op_ffn_fused deposits into an installed collector like op_igemm does
+typedef ctrl_ffn_desc FfnArgs;
+bool op_ffn_fused_shape_ok(int dim, int inner);
+int op_ffn_fused(const FfnArgs& a, hipStream_t s);
+int op_ffn_fused_group(const FfnArgs* a, int n, hipStream_t s);
+int op_ffn_pack_w2(const half_t* w2, half_t* out, int N, int K, hipStream_t s);
 // convenience: plain linear out[M][N] (fp16 row-major) = A[M][K] * W[N][K]^T + bias
 int op_linear(const half_t* A, long lda, const half_t* W, const float* bias, half_t* out, long ldo,
               int M, int N, int K, const half_t* res, long ldres, hipStream_t s);
@@ -194,7 +201,7 @@ int op_gn_fused(const void* x, int x_dtype, const float* gamma, const float* bet
 int op_gn_fused_group(const GnApplyArgs* a, int n, hipStream_t s);
 
 struct OpCollector {
-    enum { NONE = 0, IGEMM, GN_STATS, GN_APPLY, LAYERNORM, ATTN, GN_FUSED, FILL };
+    enum { NONE = 0, IGEMM, GN_STATS, GN_APPLY, LAYERNORM, ATTN, GN_FUSED, FILL, FFN };
     int type = NONE, n = 0;
     hipStream_t s = nullptr;
     IGemmArgs ig[kMaxGroup];
@@ -202,6 +209,7 @@ struct OpCollector {
     GnApplyArgs ga[kMaxGroup];
     LnArgs ln[kMaxGroup];
     AttnArgs at[kMaxGroup];
+    FfnArgs ff[kMaxGroup];
     struct Fill { void* p; size_t bytes; } fz[kMaxGroup];
     // make room for one more problem of `type` on stream `s` (flushes what is pending when it cannot join); returns its index or -1
     int slot(int type_, hipStream_t s_, int* rc);

@@ -94,6 +94,39 @@ def igemm(A, lda, W, M, Nout, Cin, taps=1, mode=IG_ROWS, geom=None, bias=None, r
     L.check(L.lib().ctrl_op_igemm(C.byref(d), L.cur_stream()))
 
 
+def ffn_pack_w2(w2_packed):
+    """fp16 [512][2048] linear pack of ff.net.2 -> the layout / k order of the fused feed-forward kernel (csrc/ffn.hip)"""
+    N, K = w2_packed.shape
+    out = torch.empty_like(w2_packed)
+    L.check(L.lib().ctrl_op_ffn_pack_w2(L.ptr(w2_packed), L.ptr(out), N, K, L.cur_stream()))
+    return out
+
+
+def ffn_fused(x, w1p, b1p, w2pp, b2=None, res=None, out=None, out16=None):
+    """out = res + ((x W1h^T + b1h) * gelu(x W1g^T + b1g)) W2^T + b2 in ONE launch (csrc/ffn.hip): x fp16 [M][512]; w1p / b1p the GEGLU
+    packs of ff.net.0.proj (pack_linear_w / pack_vec with geglu=True), w2pp = ffn_pack_w2(pack_linear_w(W2)); res fp32 or fp16 [M][512];
+    out fp32 or fp16 [M][512] (default fp16), out16 an optional fp16 mirror of an fp32 out"""
+    M, K = x.shape
+    if out is None:
+        out = _f16(M, 512)
+    d = L.FfnDesc()
+    d.X = x.data_ptr(); d.ldx = K; d.W1 = w1p.data_ptr(); d.b1 = b1p.data_ptr(); d.W2p = w2pp.data_ptr()
+    o = d.out
+    o.M = M; o.Nout = 512; o.Ktot = 2048; o.Cin = 2048; o.taps = 1; o.scale = 1.0; o.rows_per_img = 1
+    o.Hin = o.Win = o.Hout = o.Wout = o.stride = o.up = 1
+    o.bias = b2.data_ptr() if b2 is not None else None
+    o.res = res.data_ptr() if res is not None else None
+    o.ldres = 512
+    o.res_f32 = int(res is not None and res.dtype == torch.float32)
+    o.out16 = out16.data_ptr() if out16 is not None else None
+    o.ld16 = 512
+    o.nseg = 1
+    o.seg[0].out = out.data_ptr(); o.seg[0].ld = 512; o.seg[0].col_begin = 0; o.seg[0].ncols = 512
+    o.seg[0].fmt = SEG_ROW; o.seg[0].dtype = L.dtype_code(out.dtype); o.seg[0].L = 1
+    L.check(L.lib().ctrl_op_ffn(C.byref(d), L.cur_stream()))
+    return out
+
+
 def set_igemm_order(spec):
     """tile walk of the implicit GEMM over the XCDs: "auto" (default) | "legacy" | "m,G" | "n,G" (csrc/tile_order.h); results
     do not depend on it"""

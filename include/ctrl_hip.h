@@ -111,6 +111,21 @@ typedef struct ctrl_igemm_desc {
                             (ctrl_range_check / CTRL_CHECK_FINITE=1) */
 } ctrl_igemm_desc;
 int ctrl_op_igemm(const ctrl_igemm_desc* d, void* stream);
+/* Fused GEGLU feed-forward of a transformer block with dim 512 / hidden 2048 (csrc/ffn.hip; diffusers FeedForward(GEGLU) under
+   BasicTransformerBlock / TemporalBasicTransformerBlock, model/adapter_spatial_temporal.py:108-130):
+       out = epilogue( ((X W1h^T + b1h) * gelu_erf(X W1g^T + b1g)) W2^T )
+   in ONE launch -- the [M][2048] hidden activation never reaches HBM.  X fp16 [M][ldx] (the LayerNorm output), W1 / b1 the GEGLU-
+   interleaved pack of ff.net.0.proj (ctrl_op_pack_linear_w / ctrl_op_pack_vec with geglu = 1: [4096][512], [4096]), W2p the pack of
+   ff.net.2 re-ordered along K by ctrl_op_ffn_pack_w2, `out` the descriptor of the OUTPUT GEMM ([M][512]: bias, res / ldres / res_f32,
+   seg[0] row-major, out16 ...; its A / W / K fields are ignored).  ctrl_op_ffn_pack_w2: fp16 [512][2048] linear pack -> fp16 [512][2048]. */
+typedef struct ctrl_ffn_desc {
+    const void* X; int64_t ldx;
+    const void* W1; const float* b1;
+    const void* W2p;
+    ctrl_igemm_desc out;
+} ctrl_ffn_desc;
+int ctrl_op_ffn(const ctrl_ffn_desc* d, void* stream);
+int ctrl_op_ffn_pack_w2(const void* w2_packed, void* out, int N, int K, void* stream);
 /* Range safety of the fp16 activations (debug aid for real checkpoints: the synthetic N(0, 0.02^2) weights never leave the fp16 range).
    ctrl_range_check(1) -- or CTRL_CHECK_FINITE=1 in the environment -- makes every GEMM / convolution epilogue OR "this fp16 value is
    inf / nan" into a per-device flag word; ctrl_range_check(0) turns it off, ctrl_range_check(-1) only queries.  ctrl_range_status(reset)

@@ -740,3 +740,69 @@ def test_conv3x3_small_mfma(ops, gpu, cin, cout, stride, h, w_):
     wd = ops.pack_conv_w_direct(w.to(gpu))
     old = ops.conv3x3_direct(xin, wd, b.to(gpu), cout, stride=stride, silu=True, nchw=False)
     assert rel_inf(out, old) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 6: the fused GEGLU feed-forward (csrc/ffn.hip)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _ffn_case(M, seed, gpu, ops, scale_w=0.03):
+    x = rnd(M, 512, seed=seed)
+    w1, b1 = rnd(4096, 512, seed=seed + 1, scale=scale_w), rnd(4096, seed=seed + 2, scale=0.1)
+    w2, b2 = rnd(512, 2048, seed=seed + 3, scale=scale_w), rnd(512, seed=seed + 4, scale=0.1)
+    r = torch.randn(M, 512, generator=torch.Generator().manual_seed(seed + 5))          # fp32 stream: NOT fp16-representable
+    w1p, b1p = ops.pack_linear_w(w1.to(gpu), geglu=True), ops.pack_vec(b1.to(gpu), geglu=True)
+    w2p = ops.pack_linear_w(w2.to(gpu))
+    return x, w1, b1, w2, b2, r, w1p, b1p, w2p
+
+
+def _ffn_ref(x, w1, b1, w2, b2, r, chunk=16384):
+    """fp32 torch reference of FeedForward(GEGLU) + residual (diffusers GEGLU: hidden * gelu(gate), exact erf), on the fp16-rounded
+    operands, in row chunks (M = 131072 x 4096 fp32 would be 2 GB at once)"""
+    xh, w1h, w2h = x.half().float(), w1.half().float(), w2.half().float()
+    out = torch.empty(x.shape[0], 512)
+    for i in range(0, x.shape[0], chunk):
+        y = xh[i:i + chunk] @ w1h.t() + b1
+        h = y[:, :2048] * F.gelu(y[:, 2048:])
+        out[i:i + chunk] = h @ w2h.t() + b2 + r[i:i + chunk]
+    return out
+
+
+@pytest.mark.parametrize("M", [128, 1000, 32768, 131072])
+def test_ffn_fused_vs_fp32_torch_and_two_launch_form(ops, gpu, M):
+    """ONE launch for LayerNorm'd tokens -> GEGLU projection -> output projection + bias + fp32 residual (csrc/ffn.hip), against fp32
+    torch (<= 3e-4 rel-inf: the hidden activation is rounded to fp16 once, exactly as the two-launch form rounds it) and against the
+    two-launch form of igemm.hip on the same packed weights; M = 1000: a ragged last tile; fp32 master + fp16 mirror out."""
+    torch.set_num_threads(8)
+    x, w1, b1, w2, b2, r, w1p, b1p, w2p = _ffn_case(M, 7000 + M % 97, gpu, ops)
+    w2pp = ops.ffn_pack_w2(w2p)
+    xg, rg, b2g = x.half().to(gpu), r.to(gpu), b2.to(gpu)
+    out = torch.full((M, 512), float("nan"), dtype=torch.float32, device=gpu)
+    mir = torch.full((M, 512), float("nan"), dtype=torch.float16, device=gpu)
+    ops.ffn_fused(xg, w1p, b1p, w2pp, b2=b2g, res=rg, out=out, out16=mir)
+    # the two-launch form
+    hid = ops.linear(xg, w1p, bias=b1p, geglu=True)
+    out2 = torch.empty(M, 512, dtype=torch.float32, device=gpu)
+    ops.igemm(hid, 2048, w2p, M, 512, 2048, bias=b2g, res=rg, ldres=512, segs=[(out2, 512, 0, 512, ops.SEG_ROW, 1)])
+    torch.cuda.synchronize()
+    e2 = rel_inf(out, out2.cpu())
+    ref = _ffn_ref(x, w1, b1, w2, b2, r)
+    report("ffn fused M%d vs fp32 torch" % M, rel_inf(out, ref), 3e-4)
+    report("ffn fused M%d fp16 mirror" % M, rel_inf(mir, ref))
+    report("ffn fused M%d vs two launches" % M, e2, 1e-4)
+    # deterministic: a second launch gives the same bits
+    outb = torch.empty_like(out)
+    ops.ffn_fused(xg, w1p, b1p, w2pp, b2=b2g, res=rg, out=outb)
+    assert torch.equal(out, outb)
+
+
+def test_ffn_fused_fp16_stream_and_no_residual(ops, gpu):
+    """the other epilogue forms the plans use: fp16 token stream in and out (the SDXL adapter's default), and no residual / bias"""
+    M = 4096 + 64
+    x, w1, b1, w2, b2, r, w1p, b1p, w2p = _ffn_case(M, 7100, gpu, ops)
+    w2pp = ops.ffn_pack_w2(w2p)
+    xg = x.half().to(gpu)
+    r16 = r.half()
+    o16 = ops.ffn_fused(xg, w1p, b1p, w2pp, b2=b2.to(gpu), res=r16.to(gpu))
+    report("ffn fused fp16 stream", rel_inf(o16, _ffn_ref(x, w1, b1, w2, b2, r16.float())))
+    o0 = ops.ffn_fused(xg, w1p, b1p, w2pp)
+    report("ffn fused plain", rel_inf(o0, _ffn_ref(x, w1, b1, w2, torch.zeros(512), torch.zeros(M, 512))))

@@ -88,7 +88,7 @@ static int ksweep() {
     say("\nK sweep  M%d N%d, fp16 row output, no epilogue terms\n", M, N);
     const char* forces[] = {"", "256x128", "128x256"};
     for (const char* f : forces) {
-        if (*f) setenv("CTRL_IGEMM_FORCE", f, 1); else unsetenv("CTRL_IGEMM_FORCE");
+        ctrl_policy_set("CTRL_IGEMM_FORCE", *f ? f : nullptr);      // (the library reads its environment once: overrides go through the policy table)
         for (int alias = 0; alias < 2; ++alias) {
             say(" tile %s, A rows %s\n", *f ? f : "default (256x256)", alias ? "aliased (lda = 0)" : "distinct");
             for (int K : {256, 512, 1024, 2048, 4096}) {
@@ -116,7 +116,7 @@ static int ksweep() {
             }
         }
     }
-    unsetenv("CTRL_IGEMM_FORCE");
+    ctrl_policy_set("CTRL_IGEMM_FORCE", nullptr);
     say("\ndone\n");
     return 0;
 }
