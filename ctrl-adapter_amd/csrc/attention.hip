@@ -160,6 +160,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
     for (int t = 0; t < ntiles; ++t) {
         if (t + NSTAGE - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Every fragment read of tile t-1 is RETIRED before this barrier (round 6): the workgroup re-stages that tile's ring slot right
+        // behind it, and hipcc, left alone, schedules the barrier ABOVE the tile's last MFMA and the lgkmcnt wait of its operand -- the
+        // read is then still in flight when another wave's LDS-DMA overwrites the slot.  Found as a 3-8 % per-replay flake of the captured,
+        // multi-lane adapter forward (one wave's 32 queries of one head slightly off; tools/diag/graph_replay_stress.py); never seen with
+        // one kernel at a time on the chip.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // tile t visible to every wave; the slot of tile t-1 is free
         if (t + NSTAGE - 1 < ntiles) {
             int ns = cur + NSTAGE - 1;

@@ -129,6 +129,12 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
         constexpr int SLOT = decltype(slot_c)::value;
         if (t + NSTAGE - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Every fragment read of tile t-1 is RETIRED before this barrier (round 6): the workgroup re-stages that tile's ring slot right
+        // behind it, and hipcc, left alone, schedules the barrier ABOVE the tile's last MFMA and the lgkmcnt wait of its operand -- the
+        // read is then still in flight when another wave's LDS-DMA overwrites the slot.  Found as a 3-8 % per-replay flake of the captured,
+        // multi-lane adapter forward (one wave's 32 queries of one head slightly off; tools/diag/graph_replay_stress.py); never seen with
+        // one kernel at a time on the chip.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // tile t visible to every wave; the slot of tile t-1 is free
         if (t + NSTAGE - 1 < ntiles) stage(t + NSTAGE - 1, (SLOT + NSTAGE - 1) % NSTAGE);
         const char* Kb = smem_raw + SLOT * TILEB;
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64p_kernel(AttnGroup kargs
     auto step = [&](auto slot_c, const int t) {
         constexpr int S0 = decltype(slot_c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;     // t % 3, (t+1) % 3, (t+2) % 3 = (t-1) % 3
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K(t+1), V(t) (issued one tile ago) have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and this wave's reads of the slots re-staged below are retired (see flash_attn_d64_kernel)
         __builtin_amdgcn_s_barrier();
         if (t + 2 < ntiles) stage_k(t + 2, S2);
         if (t + 1 < ntiles) stage_v(t + 1, S1);

@@ -74,6 +74,11 @@ __host__ __device__ constexpr int slot(int piece) { return (piece & 7) * PIECE; 
     __builtin_amdgcn_s_barrier();                          \
     __builtin_amdgcn_sched_barrier(0);
 
+// JIT (tests only, CTRL_FF_FUSED=jitter): every wave sleeps a pseudo-random 0 .. 31 x 64 cycles at the head of both segments of every phase, a
+// different amount per wave, phase and chunk -- the waves of a workgroup then arrive at their barriers in every order, which is what turns a
+// missing wait or a too-early re-staging into wrong numbers instead of a coincidence (a co-resident kernel of another stream lane does the
+// same to the product kernel, rarely).  The result must be bit-identical to the plain kernel's.
+template <bool JIT>
 __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per, int ntm) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int gp = __builtin_amdgcn_readfirstlane(blockIdx.x / per);      // grouped launch: see igemm_kernel
@@ -91,6 +96,14 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int m0 = gbid * 128;
+    unsigned jit_state = 0x9E3779B9u * (unsigned)(wave + 1) + (unsigned)gbid * 0x85EBCA6Bu;
+    auto jitter = [&]() __attribute__((always_inline)) {
+        if constexpr (JIT) {
+            jit_state = jit_state * 1664525u + 1013904223u;
+            const int n = (int)(__builtin_amdgcn_readfirstlane(jit_state) >> 27);
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+    };
 
     // ---- staging coordinates.  Pass i of a piece: this wave writes LDS rows i*64 + wave*8 + lane/8, 16-byte chunk lane%8; the chunk
     //      swizzle of LDS row r is (r >> 1) & 7 = ((wave & 1) * 4 + (lane / 16)) & 7 for both passes ----
@@ -192,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
     // one G1 phase: k-step KK of k-tile T
 #define FF_G1_READ(T, KK)                                                                                                       \
     {                                                                                                                           \
+        jitter();                                                                                                               \
         /* (the per-lane bases are made opaque at every use: left alone, hipcc hoists all 40 `base + slot` sums of the chunk body   \
            out of the chunk loop and spills them -- scratch reloads inside the loop, which the in-order vmcnt turns into drains     \
            of the DMA queue) */                                                                                                 \
@@ -204,12 +218,14 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) wf[ni] = *(lds_h8_t)(size_t)(unsigned)(wb_ + ni * 2048);              \
     }
 #define FF_G1_MMA()                                                                                                             \
+    jitter();                                                                                                                   \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                            \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                                        \
             sacc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], sacc[mi][ni], 0, 0, 0);
     // one G2 phase: k-step KAP (k-tile KAP >> 1, half KAP & 1), output fragments 4 NH .. 4 NH + 3
 #define FF_G2_READ(KAP, NH)                                                                                                     \
     {                                                                                                                           \
+        jitter();                                                                                                               \
         int rb_ = rbase;                                                                                                        \
         asm volatile("" : "+v"(rb_));                                                                                           \
         if ((KAP) & 1) rb_ ^= 64;                                                                                               \
@@ -219,6 +235,7 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) wf[ni] = *(lds_h8_t)(size_t)(unsigned)(wb_ + ni * 2048);              \
     }
 #define FF_G2_MMA(NH, MI)                                                                                                       \
+    if ((MI) == 0) jitter();                                                                                                    \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                                            \
         oacc[MI][(NH) * 4 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[MI], oacc[MI][(NH) * 4 + ni], 0, 0, 0);
 
@@ -247,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
         //                   published to the wave row by one more barrier =================
         // (scheduling fences between the token fragments: hipcc otherwise overlaps all eight evaluations and needs more registers for
         // their temporaries than the accumulators leave -- 16 accumulator registers went to scratch across this block)
+        jitter();
         FF_GEGLU(0, 0); FF_GEGLU(1, 0); __builtin_amdgcn_sched_barrier(0);
         FF_GEGLU(0, 1); FF_GEGLU(1, 1); __builtin_amdgcn_sched_barrier(0);
         FF_GEGLU(0, 2); FF_GEGLU(1, 2); __builtin_amdgcn_sched_barrier(0);
@@ -342,7 +360,8 @@ int op_ffn_fused_group(const FfnArgs* as, int n, hipStream_t s) {
     static bool attr_done[kMaxDevices] = {};
     const int dev = cur_device();
     if (!attr_done[dev]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
         attr_done[dev] = true;
     }
     PROF_WORK(n * 2.0 * M * (double)(2 * ff::H * ff::D + ff::H * ff::D),
@@ -351,7 +370,9 @@ int op_ffn_fused_group(const FfnArgs* as, int n, hipStream_t s) {
     char grp[16] = "";
     if (n > 1) snprintf(grp, sizeof(grp), " x%d", n);
     prof_detail("M%d dim512 hidden2048 geglu fused%s", M, grp);
-    LAUNCH("ffn_fused", ffn512_kernel, dim3((unsigned)(per * n)), dim3(512), ff::LDS_TOTAL, s, g, per, ntm);
+    const char* pol = policy_raw(P_FF_FUSED);
+    if (pol && pol[0] == 'j') LAUNCH("ffn_fused", (ffn512_kernel<true>), dim3((unsigned)(per * n)), dim3(512), ff::LDS_TOTAL, s, g, per, ntm);
+    else LAUNCH("ffn_fused", (ffn512_kernel<false>), dim3((unsigned)(per * n)), dim3(512), ff::LDS_TOTAL, s, g, per, ntm);
     return 0;
 }
 

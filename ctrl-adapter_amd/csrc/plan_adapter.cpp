@@ -300,12 +300,10 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
         xn = cx.h((size_t)M * dim);
         TRY(run_layernorm(cx, w.norm_in, X, xn, M, dim));
     }
-    half_t* mid = cx.h((size_t)M * 4 * dim);
-    TRY(run_linear(cx, w.ffin1, xn, dim, tv16(mid), 4 * dim, M, TV(), 0));
     TV x0 = stream_alloc(cx, (size_t)M * dim, false);
-    // (every LayerNorm below rides on the epilogue of the GEMM that produces its input: xn is free again once ff_in.net.0 has
+    // (every LayerNorm below rides on the epilogue of the GEMM that produces its input: xn is free again once ff_in has
     // read it, and this stream is in order)
-    TRY(run_linear(cx, w.ffin2, mid, 4 * dim, x0, dim, M, X, dim, nullptr, 0, 0, nullptr, TV(), &w.norm1, xn));
+    TRY(run_ffn(cx, w.ffin1, w.ffin2, xn, dim, x0, M, X, nullptr, TV(), &w.norm1, xn));
     // x = attn1(norm1(x)) + x  (sequence = frames)
     half_t* o = nullptr;
     if (!a.comm) {
@@ -350,9 +348,7 @@ int run_temporal_tb(Ctx& cx, const TemporalTBW& w, const TV& X, const TV& out, c
     }
     TRY(run_linear(cx, w.attn1.out, o, Ci, x2, dim, M, x0, dim, ov, ov ? dim : 0, ov ? M : 0, nullptr, TV(), &w.norm3, xn));
     // x = ff(norm3(x)) + x
-    half_t* mid2 = mid;
-    TRY(run_linear(cx, w.ff1, xn, dim, tv16(mid2), 4 * dim, M, TV(), 0));
-    TRY(run_linear(cx, w.ff2, mid2, 4 * dim, out, dim, M, x2, dim, nullptr, 0, 0, blend_mix, blend_other));
+    TRY(run_ffn(cx, w.ff1, w.ff2, xn, dim, out, M, x2, blend_mix, blend_other));
     cx.release(mk);
     return 0;
 }

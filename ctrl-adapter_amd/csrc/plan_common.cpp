@@ -43,6 +43,7 @@ int build_basic_tb(ParamSink& ps, const std::string& pre, int dim, int heads, in
     TRY(ps.norm(pre + ".norm3", dim, &w->norm3));
     TRY(ps.linear(pre + ".ff.net.0.proj", 8 * dim, dim, true, true, &w->ff1));
     TRY(ps.linear(pre + ".ff.net.2", dim, 4 * dim, true, false, &w->ff2));
+    TRY(ps.ffn_perm(&w->ff2));
     return 0;
 }
 
@@ -51,6 +52,7 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
     TRY(ps.norm(pre + ".norm_in", dim, &w->norm_in));
     TRY(ps.linear(pre + ".ff_in.net.0.proj", 8 * dim, dim, true, true, &w->ffin1));
     TRY(ps.linear(pre + ".ff_in.net.2", dim, 4 * dim, true, false, &w->ffin2));
+    TRY(ps.ffn_perm(&w->ffin2));
     TRY(ps.norm(pre + ".norm1", dim, &w->norm1));
     TRY(build_attn_self(ps, pre + ".attn1", dim, heads, D, &w->attn1));
     TRY(ps.norm(pre + ".norm2", dim, &w->norm2));
@@ -58,6 +60,7 @@ int build_temporal_tb(ParamSink& ps, const std::string& pre, int dim, int heads,
     TRY(ps.norm(pre + ".norm3", dim, &w->norm3));
     TRY(ps.linear(pre + ".ff.net.0.proj", 8 * dim, dim, true, true, &w->ff1));
     TRY(ps.linear(pre + ".ff.net.2", dim, 4 * dim, true, false, &w->ff2));
+    TRY(ps.ffn_perm(&w->ff2));
     return 0;
 }
 
@@ -315,10 +318,33 @@ static int run_ff(Ctx& cx, const Norm& ln, const Lin& ff1, const Lin& ff2, const
         TRY(run_layernorm(cx, ln, x, xb, M, dim));
         xn = xb;
     }
+    TRY(run_ffn(cx, ff1, ff2, xn, dim, out, M, x));
+    cx.release(mk);
+    return 0;
+}
+
+int run_ffn(Ctx& cx, const Lin& ff1, const Lin& ff2, const half_t* xn, int dim, const TV& out, int M, const TV& res,
+            const float* blend_mix, const TV& blend_other, const Norm* ln, half_t* ln_out) {
     const int inner = ff1.N / 2;
+    const bool fused = ff1.geglu && op_ffn_fused_shape_ok(dim, inner) && ff2.N == dim && ff2.K == inner && ff2.wperm &&
+                       ff1.b && M >= kFfnFusedMinM && !policy_is0(P_FF_FUSED);
+    if (fused) {
+        FfnArgs f = {};
+        f.X = xn; f.ldx = dim; f.W1 = ff1.w; f.b1 = ff1.b; f.W2p = ff2.wperm;
+        IGemmArgs& g = f.out;
+        g.mode = IG_ROWS; g.Cin = inner; g.taps = 1; g.M = M; g.Nout = dim; g.Ktot = inner;
+        g.bias = ff2.b; g.scale = 1.f; g.rows_per_img = 1;
+        set_res(g, res, dim);
+        set_out(g, out, dim, dim);
+        set_blend(g, blend_mix, blend_other, dim);
+        RUN(cx, op_ffn_fused(f, cx.s));
+        if (ln && ln_out) TRY(run_layernorm(cx, *ln, out, ln_out, M, dim));
+        return 0;
+    }
+    const size_t mk = cx.mark();
     half_t* hmid = cx.h((size_t)M * inner);
     TRY(run_linear(cx, ff1, xn, dim, tv16(hmid), inner, M, TV(), 0));
-    TRY(run_linear(cx, ff2, hmid, inner, out, ff2.N, M, x, dim));
+    TRY(run_linear(cx, ff2, hmid, inner, out, ff2.N, M, res, dim, nullptr, 0, 0, blend_mix, blend_other, ln, ln_out));
     cx.release(mk);
     return 0;
 }

@@ -14,7 +14,8 @@
 #include <vector>
 
 // ------------------------------------------------------------------------------------------ packed params
-struct Lin { half_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; bool geglu = false; };
+// wperm: ff.net.2 only -- the weights once more in the layout / k order of the fused feed-forward kernel (ffn.hip; dim 512 blocks)
+struct Lin { half_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; bool geglu = false; half_t* wperm = nullptr; };
 // dup: split-operand convolution -- Cin is the K per tap the kernel walks (2 x the logical width: [hi | lo] halves of the
 // operand rows against the weights repeated twice), see ctrl_igemm_desc::a_split
 // paired: the split operand is walked in (hi, lo) pairs against the PLAIN weight pack (ctrl_igemm_desc::a_split == 2)
@@ -39,6 +40,8 @@ struct ParamSink {
     virtual int scalar(const std::string& name, float** out) = 0;
     // raw fp32 copy of a small tensor (router weights ...)
     virtual int raw_f32(const std::string& name, const std::vector<int64_t>& shape, float** out) = 0;
+    // second pack of a feed-forward's output projection for the fused GEGLU kernel (op_ffn_pack_w2), where its shape qualifies
+    virtual int ffn_perm(Lin* ff2) { (void)ff2; return 0; }
     // spread of the normalisation scales under `prefix`: max over its GroupNorm / LayerNorm weights of max|gamma| / median|gamma|
     // (0 = unknown: the parameter inventory pass).  Outlier channels in a trained checkpoint's norm scales are what the precision
     // selections of the path (fp16 adapter token stream, plain operands for the ControlNet's low-resolution 3x3 convolutions) are
@@ -206,6 +209,11 @@ struct Packer : ParamSink {
     int scalar(const std::string& name, float** out) override {
         TRY(dalloc(sizeof(float), (void**)out));
         return vec(name, 1, false, *out);
+    }
+    int ffn_perm(Lin* ff2) override {
+        if (!op_ffn_fused_shape_ok(ff2->N, ff2->K) || !ff2->w) return 0;
+        TRY(dalloc((size_t)ff2->N * ff2->K * sizeof(half_t), (void**)&ff2->wperm));
+        return op_ffn_pack_w2(ff2->w, ff2->wperm, ff2->N, ff2->K, s);
     }
     // load-time scan of every 1-D "...norm....weight" tensor (converted on the device, read back once: plan creation only)
     std::unordered_map<std::string, float> spread_by_name;
@@ -589,3 +597,9 @@ int run_basic_tb(Ctx& cx, const BasicTBW& w, const TV& X, const TV& out, int B, 
 // [e.batch][dim] fp32 output of a one-key cross-attention (query independent, note N5)
 int single_key_vector(Ctx& cx, const AttnW& w, int dim, const EhsCtx& e, float** out);
 int run_layernorm(Ctx& cx, const Norm& n, const TV& x, half_t* y, int M, int dim);
+// out = res + ff2(GEGLU(ff1(xn)))  [+ AlphaBlender fold]  -- diffusers FeedForward(GEGLU) on LayerNorm'd tokens xn [M][dim]; ONE launch
+// (ffn.hip) for the dim-512 blocks at M >= kFfnFusedMinM unless CTRL_FF_FUSED=0, else the GEGLU GEMM + the output GEMM.
+// ln / ln_out (optional): the LayerNorm the next op applies to `out`, launched right behind (as run_linear does)
+constexpr int kFfnFusedMinM = 16384;
+int run_ffn(Ctx& cx, const Lin& ff1, const Lin& ff2, const half_t* xn, int dim, const TV& out, int M, const TV& res,
+            const float* blend_mix = nullptr, const TV& blend_other = TV(), const Norm* ln = nullptr, half_t* ln_out = nullptr);

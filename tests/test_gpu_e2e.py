@@ -1247,3 +1247,39 @@ def test_captured_two_call_step_replays_equal_eager_and_oracle(P, gpu, which, la
         del graph
     finally:
         ops.set_policy("CTRL_ADAPTER_LANES", prev)
+
+
+def test_captured_multi_lane_adapter_forward_many_replays(P, gpu):
+    """A RACE that one kernel at a time never shows: the captured adapter forward runs its pyramid levels on four stream lanes, so kernels of
+    different levels share CUs and the waves of a workgroup drift apart.  Round 6 found the long-sequence attention kernels re-staging a
+    K / V^T ring slot while another wave's last fragment read of it was still in flight (hipcc had scheduled the per-tile barrier above the
+    tile's last MFMA and its lgkmcnt wait): 3-8 % of the REPLAYS of this very graph came out with one wave's 32 queries slightly off
+    (max abs ~1e-2), in every build since round 3 -- the three replays of the older tests almost never hit it.  150 replays, every one
+    bit-identical to the one-kernel-at-a-time forward (tools/diag/graph_replay_stress.py is the same loop with a bounding-box report)."""
+    from ctrl_adapter_amd import ops
+    torch.set_grad_enabled(False)
+    N = 4
+    ad = seeded_init(P.ControlNetAdapter(**cases.ADAPTER_SDXL), seed=22).to(gpu)
+    downs, _ = cases.pyramid_inputs(N=N, h0=32, seed=900, with_mid=False)
+    kw = dict(num_frames=1, timestep=torch.tensor(499.0).to(gpu), encoder_hidden_states=seeded_tensor((N, 77, 2048), 990).half().to(gpu))
+    ins = [d.half().to(gpu) for d in downs]
+    ad(ins, **kw)
+    with ops.Profiler():                       # one lane, one kernel at a time
+        ref = [x.clone() for x in ad(ins, **kw)[0]]
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ad(ins, **kw)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = list(ad(ins, **kw)[0])
+    bad = []
+    for k in range(150):
+        g.replay()
+        torch.cuda.synchronize()
+        bad += [(k, i) for i, (a, b) in enumerate(zip(outs, ref)) if not torch.equal(a, b)]
+    print("PARITY captured multi-lane adapter forward: 150 replays, %d (replay, output) pairs differ from the serial forward" % len(bad))
+    assert not bad, "replays that differ from the serial forward (replay, output): %s" % bad[:10]
+    del g

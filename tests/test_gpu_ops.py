@@ -806,3 +806,27 @@ def test_ffn_fused_fp16_stream_and_no_residual(ops, gpu):
     report("ffn fused fp16 stream", rel_inf(o16, _ffn_ref(x, w1, b1, w2, b2, r16.float())))
     o0 = ops.ffn_fused(xg, w1p, b1p, w2pp)
     report("ffn fused plain", rel_inf(o0, _ffn_ref(x, w1, b1, w2, torch.zeros(512), torch.zeros(M, 512))))
+
+
+@pytest.mark.parametrize("M", [16384, 131072])
+def test_ffn_fused_under_wave_jitter_is_bit_identical(ops, gpu, M):
+    """The fused kernel's intra-workgroup protocol (counted vmcnt waits, re-staging one phase after the last read, the P hand-over between
+    the wave columns) under UNEVEN wave timing: the jitter build of the kernel (CTRL_FF_FUSED=jitter) makes every wave sleep a pseudo-random
+    time at the head of every phase segment.  Its result must equal the plain kernel's bit for bit, on inputs where neighbouring workgroups
+    hold different rows (a stale LDS slot then holds OTHER data, not a lucky copy), several rounds."""
+    x, w1, b1, w2, b2, r, w1p, b1p, w2p = _ffn_case(M, 7300, gpu, ops)
+    w2pp = ops.ffn_pack_w2(w2p)
+    xg, rg, b2g = x.half().to(gpu), r.to(gpu), b2.to(gpu)
+    ref = torch.empty(M, 512, dtype=torch.float32, device=gpu)
+    ops.ffn_fused(xg, w1p, b1p, w2pp, b2=b2g, res=rg, out=ref)
+    prev = ops.set_policy("CTRL_FF_FUSED", "jitter")
+    try:
+        for rnd_ in range(3):
+            out = torch.full((M, 512), float("nan"), dtype=torch.float32, device=gpu)
+            ops.ffn_fused(xg, w1p, b1p, w2pp, b2=b2g, res=rg, out=out)
+            torch.cuda.synchronize()
+            nbad = int((out != ref).sum().item())
+            assert nbad == 0, "round %d: %d of %d values differ under wave jitter (worst %.3e)" % (rnd_, nbad, out.numel(), (out - ref).abs().max().item())
+    finally:
+        ops.set_policy("CTRL_FF_FUSED", prev)
+    print("PARITY ffn fused M%d under wave jitter: 3 rounds bit-identical" % M)
