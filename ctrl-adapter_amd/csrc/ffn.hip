@@ -33,6 +33,7 @@
 // interleaved with the MFMAs of k-steps 0, 1; the first half is exposed (it is what frees the registers the interleaved half needs).
 #include "ops.h"
 #include <cstdio>
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -78,8 +79,15 @@ __host__ __device__ constexpr int slot(int piece) { return (piece & 7) * PIECE; 
 // different amount per wave, phase and chunk -- the waves of a workgroup then arrive at their barriers in every order, which is what turns a
 // missing wait or a too-early re-staging into wrong numbers instead of a coincidence (a co-resident kernel of another stream lane does the
 // same to the product kernel, rarely).  The result must be bit-identical to the plain kernel's.
-template <bool JIT>
+// Ablation builds (tools/bin/ffn_bench only; WRONG results by construction): ABL_NODMA stages nothing inside the chunk loop, ABL_NOGEGLU replaces
+// the GEGLU math by a plain product, ABL_NOREAD skips the fragment reads -- what each costs is the time that build does NOT take.
+enum { FF_PLAIN = 0, FF_JITTER = 1, ABL_NODMA = 2, ABL_NOGEGLU = 3, ABL_NOREAD = 4, FF_BULK = 5 };
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per, int ntm) {
+    constexpr bool JIT = MODE == FF_JITTER;
+    // (measured and dropped, profiles/r06_ffn_variants.txt: the LDS-DMA issued between the MFMAs instead of in the load segment, 0.93-0.95 vs
+    // 0.90-0.92 ms at M = 131072; only a quarter of the GEGLU exposed with the rest one k-step ahead of its MFMAs -- all of S live through
+    // k-step 0 --, 0.97-0.98 ms.)  FF_BULK: the first schedule (a k-tile's three pieces issued together), kept for A/B runs.
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int gp = __builtin_amdgcn_readfirstlane(blockIdx.x / per);      // grouped launch: see igemm_kernel
     const int gbid = blockIdx.x - gp * per;
@@ -145,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
         }
     };
 #define FF_ISSUE(I, cc) issue(std::integral_constant<int, (I)>{}, (cc))
+#define FF_ISSUE_L(I, cc) do { if constexpr (MODE != ABL_NODMA) issue(std::integral_constant<int, (I)>{}, (cc)); } while (0)
 
     // ---- fragment read coordinates: row (lane & 15) of a 16-row fragment, logical 16-byte chunk (lane >> 4) [+ 4 for the second k-step
     //      = address ^ 64]; everything else is an immediate ----
@@ -164,6 +173,10 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) oacc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
     h8 xf[4], wf[4], pf[4];
+    if constexpr (MODE == ABL_NOREAD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xf[i] = h8{1, 1, 1, 1, 1, 1, 1, 1}; wf[i] = xf[i]; pf[i] = xf[i]; }
+    }
 
     auto s_init = [&](const int cc) __attribute__((always_inline)) {      // S = b1 (the bias rides in the accumulator)
 #pragma unroll
@@ -178,8 +191,13 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
     float pmax = 0.f;                 // range check of the fp16 hidden activation: branch-free in the loop, one test at the end
 #define FF_GEGLU(KAP, MI)                                                                                              \
     do {                                                                                                               \
-        const float p0_ = sacc[MI][2 * ((KAP) >> 1)][2 * ((KAP) & 1)] * gelu_erf_f(sacc[MI][2 * ((KAP) >> 1) + 1][2 * ((KAP) & 1)]);          \
-        const float p1_ = sacc[MI][2 * ((KAP) >> 1)][2 * ((KAP) & 1) + 1] * gelu_erf_f(sacc[MI][2 * ((KAP) >> 1) + 1][2 * ((KAP) & 1) + 1]);  \
+        float p0_ = sacc[MI][2 * ((KAP) >> 1)][2 * ((KAP) & 1)], p1_ = sacc[MI][2 * ((KAP) >> 1)][2 * ((KAP) & 1) + 1];                      \
+        if constexpr (MODE == ABL_NOGEGLU) {                                                                          \
+            p0_ *= sacc[MI][2 * ((KAP) >> 1) + 1][2 * ((KAP) & 1)]; p1_ *= sacc[MI][2 * ((KAP) >> 1) + 1][2 * ((KAP) & 1) + 1];                 \
+        } else {                                                                                                       \
+            p0_ *= gelu_erf_f(sacc[MI][2 * ((KAP) >> 1) + 1][2 * ((KAP) & 1)]);                                         \
+            p1_ *= gelu_erf_f(sacc[MI][2 * ((KAP) >> 1) + 1][2 * ((KAP) & 1) + 1]);                                     \
+        }                                                                                                              \
         /* (in place, one instruction: left to the compiler the maximum chain sinks to the end of the chunk body and keeps every    \
            product alive -- in scratch -- until there) */                                                                  \
         asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(pmax) : "v"(p0_), "v"(p1_));                                \
@@ -214,8 +232,10 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
         if (KK) rb_ ^= 64;                                                                                                      \
         const int xb_ = rb_ + (sx + ff::slot(3 * (T)));                                                                         \
         const int wb_ = rb_ + (sw1 + ((wn >> 1) ? ff::slot(3 * (T) + 2) : ff::slot(3 * (T) + 1)));                              \
+        if constexpr (MODE != ABL_NOREAD) {                                                                                     \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) xf[mi] = *(lds_h8_t)(size_t)(unsigned)(xb_ + mi * 2048);              \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) wf[ni] = *(lds_h8_t)(size_t)(unsigned)(wb_ + ni * 2048);              \
+        } else { asm volatile("" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) : "v"(xb_), "v"(wb_)); }   \
     }
 #define FF_G1_MMA()                                                                                                             \
     jitter();                                                                                                                   \
@@ -231,8 +251,10 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
         if ((KAP) & 1) rb_ ^= 64;                                                                                               \
         const int pb_ = rb_ + sp;                                                                                               \
         const int wb_ = rb_ + (sw2 + ((KAP) >> 1) * 4 * ff::PIECE + (NH) * 4 * 2048);                                           \
+        if constexpr (MODE != ABL_NOREAD) {                                                                                     \
         if ((NH) == 0) { _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) pf[mi] = *(lds_h8_t)(size_t)(unsigned)(pb_ + mi * 2048); }   \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) wf[ni] = *(lds_h8_t)(size_t)(unsigned)(wb_ + ni * 2048);              \
+        } else { asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) : "v"(pb_), "v"(wb_)); }   \
     }
 #define FF_G2_MMA(NH, MI)                                                                                                       \
     if ((MI) == 0) jitter();                                                                                                    \
@@ -242,57 +264,12 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
 #pragma clang loop unroll(disable)
     for (int c = 0; c < ff::NCH; ++c) {
         const bool more = c + 1 < ff::NCH;
-        // ================= G1: phases 0 .. 15 (k-tile t = phases 2t, 2t + 1) =================
-        // phase 0: pieces 4..7 of this chunk go where the last G2 k-tile of the previous chunk was (chunk 0: staged by the prologue)
-        FF_G1_READ(0, 0); if (c > 0) { FF_ISSUE(4, c); FF_ISSUE(5, c); FF_ISSUE(6, c); FF_ISSUE(7, c); } FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(0, 1); FF_VMCNT(4); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(1, 0); FF_ISSUE(8, c); FF_ISSUE(9, c); FF_ISSUE(10, c); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(1, 1); FF_VMCNT(4); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(2, 0); FF_ISSUE(11, c); FF_ISSUE(12, c); FF_ISSUE(13, c); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(2, 1); FF_VMCNT(4); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(3, 0); FF_ISSUE(14, c); FF_ISSUE(15, c); FF_ISSUE(16, c); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(3, 1); FF_VMCNT(4); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(4, 0); FF_ISSUE(17, c); FF_ISSUE(18, c); FF_ISSUE(19, c); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(4, 1); FF_VMCNT(4); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(5, 0); FF_ISSUE(20, c); FF_ISSUE(21, c); FF_ISSUE(22, c); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(5, 1); FF_VMCNT(4); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(6, 0); FF_ISSUE(23, c); FF_ISSUE(24, c); FF_ISSUE(25, c); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(6, 1); FF_VMCNT(4); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(7, 0); FF_ISSUE(26, c); FF_ISSUE(27, c); FF_ISSUE(28, c); FF_PRE(); FF_G1_MMA(); FF_POST();
-        FF_G1_READ(7, 1); FF_VMCNT(2); FF_PRE(); FF_G1_MMA(); FF_POST();
-        // ================= GEGLU of k-steps 0 and 1 (the hidden units 0-15 of every wave column: the exposed half; it frees half of S),
-        //                   published to the wave row by one more barrier =================
-        // (scheduling fences between the token fragments: hipcc otherwise overlaps all eight evaluations and needs more registers for
-        // their temporaries than the accumulators leave -- 16 accumulator registers went to scratch across this block)
-        jitter();
-        FF_GEGLU(0, 0); FF_GEGLU(1, 0); __builtin_amdgcn_sched_barrier(0);
-        FF_GEGLU(0, 1); FF_GEGLU(1, 1); __builtin_amdgcn_sched_barrier(0);
-        FF_GEGLU(0, 2); FF_GEGLU(1, 2); __builtin_amdgcn_sched_barrier(0);
-        FF_GEGLU(0, 3); FF_GEGLU(1, 3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ================= G2: phases 16 .. 23 (k-step kap = phases 16 + 2 kap, + 1).  The GEGLU of k-steps 2 / 3 runs between the MFMAs of
-        //                   k-steps 0 / 1 and goes into the P slot that k-step has just read (its reads retired before the phase's barrier) ======
-        FF_G2_READ(0, 0); FF_ISSUE(29, c); FF_ISSUE(30, c); FF_ISSUE(31, c); FF_PRE();
-        FF_G2_MMA(0, 0); FF_GEGLU(2, 0); FF_G2_MMA(0, 1); FF_GEGLU(2, 1); FF_G2_MMA(0, 2); FF_G2_MMA(0, 3); FF_POST_P();
-        FF_G2_READ(0, 1); FF_PRE();
-        FF_G2_MMA(1, 0); FF_GEGLU(2, 2); FF_G2_MMA(1, 1); FF_GEGLU(2, 3); FF_G2_MMA(1, 2); FF_G2_MMA(1, 3); FF_POST_P();
-        FF_G2_READ(1, 0); FF_PRE();
-        FF_G2_MMA(0, 0); FF_GEGLU(3, 0); FF_G2_MMA(0, 1); FF_GEGLU(3, 1); FF_G2_MMA(0, 2); FF_G2_MMA(0, 3); FF_POST_P();
-        FF_G2_READ(1, 1); FF_VMCNT(0); FF_PRE();
-        FF_G2_MMA(1, 0); FF_GEGLU(3, 2); FF_G2_MMA(1, 1); FF_GEGLU(3, 3); FF_G2_MMA(1, 2); FF_G2_MMA(1, 3); FF_POST_P();
-        FF_G2_READ(2, 0); if (more) { FF_ISSUE(0, c + 1); FF_ISSUE(1, c + 1); FF_ISSUE(2, c + 1); FF_ISSUE(3, c + 1); } FF_PRE();
-        FF_G2_MMA(0, 0); FF_G2_MMA(0, 1); FF_G2_MMA(0, 2); FF_G2_MMA(0, 3); FF_POST();
-        FF_G2_READ(2, 1); FF_PRE();
-        FF_G2_MMA(1, 0); FF_G2_MMA(1, 1); FF_G2_MMA(1, 2); FF_G2_MMA(1, 3); FF_POST();
-        FF_G2_READ(3, 0); FF_PRE();
-        FF_G2_MMA(0, 0); FF_G2_MMA(0, 1); FF_G2_MMA(0, 2); FF_G2_MMA(0, 3); FF_POST();
-        FF_G2_READ(3, 1); if (more) { FF_VMCNT(2); } FF_PRE();
-        // (S is re-initialised unconditionally -- after the last chunk with that chunk's bias again, unused: a conditional
-        // initialisation keeps the consumed S values alive, in scratch, through all of G2)
-        FF_G2_MMA(1, 0); FF_G2_MMA(1, 1); s_init(more ? c + 1 : c); FF_G2_MMA(1, 2); FF_G2_MMA(1, 3); FF_POST();
+        // the 24 phases of a chunk: generated (and hazard-checked) by tools/gen_ffn_schedule.py from the schedule named in the file name
+        if constexpr (MODE == FF_BULK) {
+#include "ffn_body_bulk.inc"
+        } else {
+#include "ffn_body_spread.inc"
+        }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
     if (e.nonfinite) flag_nonfinite(e.nonfinite, out_of_half(pmax));
@@ -360,8 +337,12 @@ int op_ffn_fused_group(const FfnArgs* as, int n, hipStream_t s) {
     static bool attr_done[kMaxDevices] = {};
     const int dev = cur_device();
     if (!attr_done[dev]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
-        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<FF_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<FF_JITTER>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<ABL_NODMA>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<ABL_NOGEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<ABL_NOREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<FF_BULK>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
         attr_done[dev] = true;
     }
     PROF_WORK(n * 2.0 * M * (double)(2 * ff::H * ff::D + ff::H * ff::D),
@@ -371,8 +352,13 @@ int op_ffn_fused_group(const FfnArgs* as, int n, hipStream_t s) {
     if (n > 1) snprintf(grp, sizeof(grp), " x%d", n);
     prof_detail("M%d dim512 hidden2048 geglu fused%s", M, grp);
     const char* pol = policy_raw(P_FF_FUSED);
-    if (pol && pol[0] == 'j') LAUNCH("ffn_fused", (ffn512_kernel<true>), dim3((unsigned)(per * n)), dim3(512), ff::LDS_TOTAL, s, g, per, ntm);
-    else LAUNCH("ffn_fused", (ffn512_kernel<false>), dim3((unsigned)(per * n)), dim3(512), ff::LDS_TOTAL, s, g, per, ntm);
+    const dim3 grid((unsigned)(per * n)), blk(512);
+    if (pol && pol[0] == 'j') LAUNCH("ffn_fused", (ffn512_kernel<FF_JITTER>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
+    else if (pol && !strcmp(pol, "abl_nodma")) LAUNCH("ffn_fused", (ffn512_kernel<ABL_NODMA>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
+    else if (pol && !strcmp(pol, "abl_nogeglu")) LAUNCH("ffn_fused", (ffn512_kernel<ABL_NOGEGLU>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
+    else if (pol && !strcmp(pol, "bulk")) LAUNCH("ffn_fused", (ffn512_kernel<FF_BULK>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
+    else if (pol && !strcmp(pol, "abl_noread")) LAUNCH("ffn_fused", (ffn512_kernel<ABL_NOREAD>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
+    else LAUNCH("ffn_fused", (ffn512_kernel<FF_PLAIN>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
     return 0;
 }
 

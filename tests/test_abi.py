@@ -25,13 +25,13 @@ def test_struct_sizes_match_header():
     import subprocess
     import tempfile
     from ctrl_adapter_amd import _lib
-    src = '#include "ctrl_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ctrl_igemm_seg), sizeof(ctrl_igemm_desc), sizeof(ctrl_attn_desc), sizeof(ctrl_tattn_desc), sizeof(ctrl_tensor_ref), sizeof(ctrl_controlnet_config), sizeof(ctrl_adapter_config), sizeof(ctrl_clip_comm));return 0;}\n'
+    src = '#include "ctrl_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ctrl_igemm_seg), sizeof(ctrl_igemm_desc), sizeof(ctrl_attn_desc), sizeof(ctrl_tattn_desc), sizeof(ctrl_tensor_ref), sizeof(ctrl_controlnet_config), sizeof(ctrl_adapter_config), sizeof(ctrl_clip_comm), sizeof(ctrl_ffn_desc));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
     got = [ctypes.sizeof(c) for c in (_lib.IGemmSeg, _lib.IGemmDesc, _lib.AttnDesc, _lib.TAttnDesc, _lib.TensorRef,
-                                     _lib.ControlNetConfig, _lib.AdapterConfig, _lib.ClipComm)]
+                                     _lib.ControlNetConfig, _lib.AdapterConfig, _lib.ClipComm, _lib.FfnDesc)]
     assert [int(v) for v in out] == got, (out, got)
 
 

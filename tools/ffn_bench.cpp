@@ -72,6 +72,9 @@ static void* dev_float(size_t n, float scale) {
 
 int main(int argc, char** argv) {
     if (argc > 1) g_out = fopen(argv[1], "w");
+    // argv[2] (optional): value of CTRL_FF_FUSED for the fused launches -- "jitter", or an ablation build ("abl_nodma", "abl_nogeglu",
+    // "abl_noread": WRONG results by construction; what each build does not take is what that part costs)
+    if (argc > 2) { ctrl_policy_set("CTRL_FF_FUSED", argv[2]); }
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -87,7 +90,7 @@ int main(int argc, char** argv) {
     void* W2p = nullptr;
     CK(hipMalloc(&W2p, (size_t)D * H * 2));
     if (ctrl_op_ffn_pack_w2(W2, W2p, D, H, st) != 0) { say("pack failed: %s\n", ctrl_last_error()); return 3; }
-    say("fused GEGLU feed-forward vs the two-launch form (fp32 residual stream in, fp32 master + fp16 mirror out)\n");
+    say("fused GEGLU feed-forward%s%s vs the two-launch form (fp32 residual stream in, fp32 master + fp16 mirror out)\n", argc > 2 ? " build " : "", argc > 2 ? argv[2] : "");
     for (int M : {131072, 32768, 8192, 131072 + 40}) {
         void* X = dev_half((size_t)M * D, 1.0f);
         void* res = dev_float((size_t)M * D, 1.0f);
