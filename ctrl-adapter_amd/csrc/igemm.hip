@@ -693,20 +693,33 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmGroup kargs, int pe
 
     int slab = split;
     if (red_cnt != nullptr) {
-        // In-launch split-K reduction (2..4 splits; cdna_hip_programming.md "in-launch split-K reduction", MI355X_MICROARCH.md
+        // In-launch split-K reduction (cdna_hip_programming.md "in-launch split-K reduction", MI355X_MICROARCH.md
         // "Workgroup dispatch ... inter-workgroup visibility"): every split writes its accumulators to its slab of the tile in
         // FRAGMENT layout (16 bytes per lane, 8 KiB contiguous per instruction), publishes them (write-through stores, drained) and takes a
         // ticket; the workgroup that draws the last ticket acquires once, adds the slabs in split order -- a fixed order whoever arrives
-        // last, so the result is bit-reproducible -- and runs the full epilogue.  No workgroup waits for another: the others just exit.
-        // It replaces the fp32 row slabs + splitk_finish_kernel launch of the higher split factors (round 3: 36 launches, 1.1 ms per step).
+        // last, so the result is bit-reproducible -- and goes on.  No workgroup waits for another: the others just exit.
+        //   2..4 splits: one level -- the last arriver of the tile runs the full epilogue (round 4).
+        //   5..16 splits (round 6, opt-in: CTRL_SPLITK_INLAUNCH=all): two levels -- the splits form groups of four; the last arriver of a
+        //   GROUP sums the group's slabs into the group's first slab, publishes it and takes the tile's second-level ticket; the last of
+        //   those sums the <= 4 group sums and runs the epilogue.  Nobody reads more than four slabs -- and it still LOSES to the finish
+        //   kernel (see launch8): a lone workgroup streams its slabs at a fraction of what the finish kernel's 4096 workgroups get.
+        // It replaces the fp32 row slabs + splitk_finish_kernel launch (round 3: 36 launches, 1.1 ms per step).
         const int tile = first_bid;
         constexpr int NF = 8 * NI;
         f4* const tile_ws = (f4*)red_ws + (size_t)tile * splitk * NF * 512;
+        const bool two = splitk > 4;
+        const int gsz = two ? 4 : splitk;                       // splits per group
+        const int ngrp = (splitk + gsz - 1) / gsz;
+        const int grp_i = split / gsz;
+        const int g_first = grp_i * gsz, g_n = min(gsz, splitk - g_first);
+        // ticket words of a tile: [0] = the last level, [1 + g] = group g (two levels only)
+        int* const cnt_last = red_cnt + (size_t)tile * (two ? 1 + 4 : 1);
+        int* const flag = (int*)smem_raw;
         // The slab leaves by WRITE-THROUGH stores (sc1) and is published by draining them: a release fence writes back every
         // dirty line of the XCD's L2 -- with 320 KB freshly written by each of the XCD's 32 workgroups that cost 40-66 us per launch
         // (MI355X_MICROARCH.md price list, "publish-large"), more than the finish kernel it replaces.
-        {
-            const __amdgpu_buffer_rsrc_t ws_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tile_ws + (size_t)split * NF * 512), 0, NF * 512 * 16, 0x00020000);
+        auto publish = [&](const int slab_i, int* const counter, const int last_ticket) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t ws_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tile_ws + (size_t)slab_i * NF * 512), 0, NF * 512 * 16, 0x00020000);
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
@@ -716,30 +729,38 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(IGemmGroup kargs, int pe
                     __builtin_memcpy(&v, &acc[mi][ni], 16);
                     __builtin_amdgcn_raw_buffer_store_b128(v, ws_rs, ((mi * NI + ni) * 512 + tid) * 16, 0, /*sc1*/ 16);
                 }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                       // (also: every wave is done with the LDS ring)
-        int* const flag = (int*)smem_raw;
-        if (tid == 0) {
-            const int ticket = __hip_atomic_fetch_add(&red_cnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ticket == splitk - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            *flag = ticket;
-        }
-        __syncthreads();
-        if (*flag != splitk - 1) return;
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < splitk; ++sp) {
-            const f4* src = tile_ws + (size_t)sp * NF * 512 + tid;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                       // (also: every wave is done with the LDS ring / the flag word)
+            if (tid == 0) {
+                const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ticket == last_ticket) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                *flag = ticket;
+            }
+            __syncthreads();
+            const bool last = *flag == last_ticket;
+            __syncthreads();                                       // the flag word is re-used by the next level / the epilogue's staging area
+            return last;
+        };
+        auto sum_slabs = [&](const int first, const int count, const int stride) __attribute__((always_inline)) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += src[(mi * NI + ni) * 512];
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < count; ++sp) {
+                const f4* src = tile_ws + (size_t)(first + sp * stride) * NF * 512 + tid;
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += src[(mi * NI + ni) * 512];
+            }
+        };
+        if (!publish(split, two ? cnt_last + 1 + grp_i : cnt_last, g_n - 1)) return;
+        sum_slabs(g_first, g_n, 1);
+        if (two) {
+            if (!publish(g_first, cnt_last, ngrp - 1)) return;      // the group's sum replaces the group's first slab (every slab of the group has been read)
+            sum_slabs(0, ngrp, gsz);
         }
         slab = 0;
-        __syncthreads();                                       // the flag word is part of the epilogue's staging area
     }
     igemm_epilogue<BM, BN, 2, 4, true, 1>(a, acc, m0, n0, wm, wn, lane, wave, slab, smem_raw);
 }
@@ -1020,16 +1041,23 @@ int launch8(const IGemmArgs& a, hipStream_t s, int splitk = 1) {
         // holds tile-shaped fragment slabs [tile][split][fragment][thread] + one ticket word per tile (zeroed by a memset node)
         const size_t slabs = (size_t)ntm * ntn * splitk * BM * BN * sizeof(float);
         const bool own_tickets = a.splitk_tickets != nullptr;       // (igemm_same_form: all of the group or none)
-        const size_t need = own_tickets ? slabs : (slabs + 255) / 256 * 256 + (size_t)ntm * ntn * sizeof(int);
-        const int inlaunch = policy_is0(P_SPLITK_INLAUNCH) ? 0 : 1;
+        const size_t twords = (size_t)ntm * ntn * (splitk > 4 ? 5 : 1);      // ticket words: see the kernel
+        const size_t need = own_tickets ? slabs : (slabs + 255) / 256 * 256 + twords * sizeof(int);
+        // CTRL_SPLITK_INLAUNCH: 0 = always the finish kernel; default = in-launch for 2..4 splits; "all" = also the two-level form for 5..16
+        // splits -- built and measured in round 6, NOT the default: the last arrivers read their <= 4 slabs of 256-320 KB alone, at the
+        // 60-120 GB/s one workgroup gets (MI355X_MICROARCH.md "handoff-payload"), twice; M512 N1280 K11520 x15: 52 + 14 us (GEMM + finish
+        // kernel over the whole chip) -> 128 us, the ControlNet 8.16 -> 9.14 ms (profiles/r06_splitk_two_level.txt)
+        const char* const il = policy_raw(P_SPLITK_INLAUNCH);
+        const int inlaunch = (il && il[0] == '0') ? 0 : 1;
+        const int inlaunch_max = (il && il[0] == 'a') ? 16 : 4;
         bool fits = true;
         for (int i = 0; i < G; ++i) fits = fits && (size_t)grp_at(a, i).splitk_ws_bytes >= need;
-        if (inlaunch && splitk <= 4 && fits) {
+        if (inlaunch && splitk <= inlaunch_max && fits) {
             const long red_off = own_tickets ? -2L : (long)((slabs + 255) / 256 * 256);
             for (int i = 0; i < G; ++i) {
                 grp.a[i] = grp_at(a, i);
                 // ticket words: the caller's zeroed ones, or the tail of the scratch, zeroed here (a kernel node: see op_fill_zero)
-                if (!own_tickets) TRY(op_fill_zero((char*)grp.a[i].splitk_ws + red_off, (size_t)ntm * ntn * sizeof(int), s));
+                if (!own_tickets) TRY(op_fill_zero((char*)grp.a[i].splitk_ws + red_off, twords * sizeof(int), s));
             }
             char ex[40]; snprintf(ex, sizeof(ex), " splitk%d in-launch", splitk);
             prof_igemm(a, ex);
@@ -1078,16 +1106,17 @@ size_t igemm_splitk_ws_bytes(const IGemmArgs& a, int sk) {
     const size_t rows = (size_t)sk * a.M * a.Nout * sizeof(float);
     const int bn = (a.Nout % 320 == 0) ? 320 : 256;
     const size_t tiles = (size_t)((a.M + 255) / 256) * ((a.Nout + bn - 1) / bn);
-    if (sk > 4) return rows;                     // the in-launch reduction serves 2..4 splits only
-    const size_t frag = (tiles * sk * 256 * bn * sizeof(float) + 255) / 256 * 256 + tiles * sizeof(int);
+    // (fragment slabs + ticket words for callers that do not hand in their own: one word per tile for 2..4 splits, five for the
+    //  two-level reduction of 5..16 splits)
+    const size_t frag = (tiles * sk * 256 * bn * sizeof(float) + 255) / 256 * 256 + tiles * (sk > 4 ? 5 : 1) * sizeof(int);
     return rows > frag ? rows : frag;
 }
 
 // ticket words (one per 256-row output tile) of the in-launch reduction for `sk` splits; 0 when that form does not apply
 size_t igemm_splitk_ticket_words(const IGemmArgs& a, int sk) {
-    if (sk < 2 || sk > 4) return 0;
+    if (sk < 2 || sk > 16) return 0;
     const int bn = (a.Nout % 320 == 0) ? 320 : 256;
-    return (size_t)((a.M + 255) / 256) * ((a.Nout + bn - 1) / bn);
+    return (size_t)((a.M + 255) / 256) * ((a.Nout + bn - 1) / bn) * (sk > 4 ? 5 : 1);
 }
 
 int igemm_splitk_factor(const IGemmArgs& a) {

@@ -18,7 +18,7 @@ typedef ctrl_igemm_desc IGemmArgs;
 int op_igemm(const IGemmArgs& a, hipStream_t s);
 // K-split factor op_igemm would use given scratch (1 = no split); scratch needed = factor * M * Nout * sizeof(float)
 int igemm_splitk_factor(const IGemmArgs& a);
-// scratch bytes for that factor (>= factor * M * Nout * sizeof(float): the in-launch reduction of 2..4 splits keeps tile-shaped slabs)
+// scratch bytes for that factor (>= factor * M * Nout * sizeof(float): the in-launch reduction keeps tile-shaped slabs)
 size_t igemm_splitk_ws_bytes(const IGemmArgs& a, int sk);
 // ticket words (ctrl_igemm_desc::splitk_tickets) the in-launch reduction of `sk` splits uses; 0 = that form does not apply
 size_t igemm_splitk_ticket_words(const IGemmArgs& a, int sk);

@@ -87,7 +87,8 @@ typedef struct ctrl_igemm_desc {
                            2: W = the plain pack [Cout][taps][Cin/2]; k-tiles alternate hi / lo chunk of the same channels and
                               each weight tile is staged once per pair (Cin/2 % 64 == 0) */
     void* splitk_ws; int64_t splitk_ws_bytes;   /* optional fp32 scratch: enables split-K for small-M / long-K problems */
-    int32_t* splitk_tickets;   /* optional (device): one ZEROED word per 256-row output tile for the in-launch reduction of 2..4 splits (the
+    int32_t* splitk_tickets;   /* optional (device): ZEROED ticket words for the in-launch reduction -- one per 256-row output tile for 2..4 splits, five per tile
+                                  for the two-level reduction of 5..16 splits (ctrl-adapter_amd/csrc/igemm.hip: igemm_splitk_ticket_words) (the
                                   plans hand out slices of a pool they zero once per forward); NULL = the library zeroes ticket words
                                   at the end of splitk_ws with a fill launch of its own */
     void* out16; int64_t ld16;   /* optional fp16 row-major mirror of the (single, row-major) output: GEMM-operand copy of an fp32 stream */

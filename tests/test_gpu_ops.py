@@ -594,11 +594,14 @@ def test_wide_tile_is_bit_reproducible_and_close_to_the_ring_kernels(ops, gpu):
     report("wide tile vs ring kernel", rel_inf(outs[1], outs[0].float().cpu()), 1e-3)
 
 
-@pytest.mark.parametrize("cin,cout,h,n,res_up", [(640, 640, 32, 8, 0), (320, 320, 64, 8, 0), (1280, 1280, 32, 8, 0), (640, 640, 32, 8, 2)])
+@pytest.mark.parametrize("cin,cout,h,n,res_up", [(640, 640, 32, 8, 0), (320, 320, 64, 8, 0), (1280, 1280, 32, 8, 0), (640, 640, 32, 8, 2),
+                                                 (1280, 1280, 8, 8, 0), (1280, 1280, 16, 8, 0), (640, 640, 16, 8, 0), (1280, 640, 16, 3, 0)])
 def test_splitk_reduced_inside_the_launch(ops, gpu, cin, cout, h, n, res_up):
-    """2..4 K-splits of the wide tile are summed by the last-arriving workgroup of every tile (agent-scope release / ticket / acquire,
+    """The K-splits of the wide tile are summed by the last-arriving workgroup of every tile (agent-scope release / ticket / acquire,
     csrc/igemm.hip) instead of a finish kernel: against the fp32 reference, and bit-identical from run to run (the slabs are added
-    in split order whoever arrives last) -- 4, 2, 2 and 4 splits here, with bias, time vector and a (half-resolution) residual"""
+    in a fixed order whoever arrives last) -- 4, 2, 2 and 4 splits in the first four cases (one level), then 15, 8, 8 and 16 splits
+    (round 6: two levels, groups of four; the ControlNet's 8^2 / 16^2 convolutions at b = 8), with bias, time vector and a
+    (half-resolution) residual.  No splitk_finish launch may be left."""
     x = rnd(n, cin, h, h, seed=1)
     w = rnd(cout, cin, 3, 3, seed=2, scale=0.02)
     b, temb = rnd(cout, seed=3), rnd(n, cout, seed=4)
@@ -608,11 +611,22 @@ def test_splitk_reduced_inside_the_launch(ops, gpu, cin, cout, h, n, res_up):
     ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + r_full.permute(0, 3, 1, 2)
     wp = ops.pack_conv_w(w.to(gpu))
     xh = x.permute(0, 2, 3, 1).contiguous().half().to(gpu)
-    ws = torch.empty(16 * n * h * h * cout, dtype=torch.float32, device=gpu)
+    ws = torch.empty(20 * max(n * h * h, 256) * cout, dtype=torch.float32, device=gpu)      # (tile-padded slabs + ticket words)
+    prev = ops.set_policy("CTRL_SPLITK_INLAUNCH", "all")      # (the two-level form is opt-in: measured slower than the finish kernel)
+    try:
+        _splitk_inlaunch_body(ops, gpu, xh, wp, cout, b, temb, r, res_up, ws, ref, cin, h, n)
+    finally:
+        ops.set_policy("CTRL_SPLITK_INLAUNCH", prev)
+
+
+def _splitk_inlaunch_body(ops, gpu, xh, wp, cout, b, temb, r, res_up, ws, ref, cin, h, n):
     outs = []
     for _ in range(4):
         ws.fill_(float("nan"))                       # a slab read before it was written would poison the result
         outs.append(ops.conv2d(xh, wp, cout, taps=9, bias=b.to(gpu), rowvec=temb.to(gpu), res=r.to(gpu), res_up=res_up, splitk_ws=ws))
+    with ops.Profiler() as prof:
+        ops.conv2d(xh, wp, cout, taps=9, bias=b.to(gpu), rowvec=temb.to(gpu), res=r.to(gpu), res_up=res_up, splitk_ws=ws)
+    assert any("in-launch" in rec[2] for rec in prof.launches) and "splitk_finish" not in prof.rows, (prof.rows.keys(), [rec[2] for rec in prof.launches])
     report("in-launch split-K conv %d->%d @%d n%d" % (cin, cout, h, n), rel_inf(outs[0].permute(0, 3, 1, 2), ref))
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "split-K result differs from run to run"
