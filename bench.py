@@ -569,6 +569,7 @@ def main():
             # NOT measured by this run: PMC counters of the newest committed profile of this workload (tools/profile_round.sh)
             "committed_profile": {"hbm_gb_per_step": hbm_gb, "source": hbm_src} if hbm_gb else None,
             "fused_step": fused, "roofline": roof, "cpu_baseline": cpu, "parity_at_bench_config": parity, "other_workloads": others,
+            "policy": __import__("ctrl_adapter_amd").ops.policy() or None,      # every CTRL_* switch that is set (csrc/policy.h): None = all defaults
             "next_kernels": top, "per_kernel_file": os.path.basename(args.per_kernel_out) if (kernels or per_kernel) else None,
         }
         out = json.dumps(line)

@@ -100,7 +100,7 @@ EXPORTS = [
     "ctrl_controlnet_destroy", "ctrl_controlnet_forward",
     "ctrl_adapter_param_count", "ctrl_adapter_param_spec", "ctrl_adapter_create", "ctrl_adapter_destroy",
     "ctrl_adapter_forward",
-    "ctrl_adapter_forward_scatter", "ctrl_adapter_forward_clip_sharded", "ctrl_controlnet_text_cache", "ctrl_adapter_text_cache", "ctrl_controlnet_trim", "ctrl_adapter_trim",
+    "ctrl_adapter_forward_scatter", "ctrl_adapter_forward_clip_sharded", "ctrl_controlnet_text_cache", "ctrl_adapter_text_cache", "ctrl_controlnet_trim", "ctrl_adapter_trim", "ctrl_controlnet_selection", "ctrl_adapter_selection",
     "ctrl_step_forward", "ctrl_rccl_unique_id", "ctrl_rccl_comm_create", "ctrl_rccl_comm_destroy", "ctrl_rccl_comm_bind", "ctrl_rccl_comm_bytes_sent",
     "ctrl_router_weights", "ctrl_router_merge", "ctrl_prepare_images",
 ]

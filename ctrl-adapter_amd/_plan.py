@@ -155,6 +155,20 @@ class ParamTreeModule(PretrainedMixin, nn.Module):
         except Exception:
             pass
 
+    selection = None      # what plan creation selected for this checkpoint (ctrl_*_selection), set with the plan
+
+    def _note_selection(self, query):
+        """reads the plan's selection line; a checkpoint whose normalisation scales have outlier channels takes the conservative (slower)
+        selection -- said once, instead of silently running at another speed than the benchmarks"""
+        import ctypes
+        buf = ctypes.create_string_buffer(256)
+        L.check(query(self._plan, buf, 256))
+        self.selection = buf.value.decode()
+        if "conservative" in self.selection or ("token_stream_fp32_blocks=" in self.selection and "token_stream_fp32_blocks=0" not in self.selection):
+            import warnings
+            warnings.warn("%s: this checkpoint's normalisation scales have outlier channels: the plan keeps the conservative precision "
+                          "selection (%s)" % (type(self).__name__, self.selection))
+
     WEIGHT_GAIN_WARN = 1.5
 
     def _warn_on_hot_weights(self, sd):

@@ -92,6 +92,7 @@ class ControlNetModel(ParamTreeModule):
             h = C.c_void_p()
             L.check(L.lib().ctrl_controlnet_create(C.byref(self._cfg), refs, n, L.cur_stream(), C.byref(h)))
             self._plan = h
+            self._note_selection(L.lib().ctrl_controlnet_selection)
         return self._plan
 
     def _drop_plan(self):

@@ -33,7 +33,9 @@ namespace {
 // pyramid level (model/ctrl_adapter.py:181-191 runs them one after the other; they are independent) -- share one launch: the
 // descriptors travel as an array in the kernel-argument segment, workgroup b works on problem b / per.  A 32^2 / 16^2 GEMM then
 // has 2-4 x the tiles (the wide tile instead of the 128 x 128 / 64 x 64 ring tiles) and the step has fewer launches.  A plain launch
-// is a group of one.  Every problem is computed exactly as it would be alone (same tiles, same k order): results are bit-identical.
+// is a group of one.  Given the tile, every problem is computed exactly as it would be alone (same k order); the DISPATCHER, though, sizes the
+// tile for the whole group by default (ctrl_group_launches(1): another tile family for some problems, last-bit differences) -- with
+// ctrl_group_launches(2) it picks the tile a lone problem would get and the results are bit-identical to one-by-one launches.
 struct IGemmGroup { IGemmArgs a[kMaxIGemmGroup]; };
 // descriptor of this workgroup's problem, read from the kernel-argument segment (constant memory: scalar loads; the group is the first
 // kernel parameter, i.e. offset 0 of the segment).  Not `kargs.a[gp]`: a dynamic index into the by-value parameter would pin its

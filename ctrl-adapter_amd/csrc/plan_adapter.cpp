@@ -693,7 +693,10 @@ int adapter_run(Ctx& cx, const AdapterW& w, const AdapterCall& k) {
     //      the mid block joins the 8^2 ones).  Siblings are recorded and replayed in lock-step, so every GEMM / norm / attention of
     //      theirs leaves as ONE grouped launch (ops.h: OpCollector): 2-4 x the tiles per launch at the 64^2 .. 8^2 levels, where
     //      a single block fills less than the chip, and 40 % fewer launches per step.  Each sibling owns a disjoint workspace
-    //      region (sized by the dry pass: slot_need).  Bit-identical to running them one by one (CTRL_GROUP=0).
+    //      region (sized by the dry pass: slot_need).  Every problem is computed as it would be alone; with CTRL_GROUP=2 the GEMM dispatcher also
+    //      picks the tile a lone problem would get and the forward is bit-identical to the one-by-one forward (CTRL_GROUP=0).  In the default
+    //      mode (1) the dispatcher sizes the tile for the whole group -- another tile family for some GEMMs, last-bit differences
+    //      (<= 3e-4 rel-inf asserted by tests/test_gpu_e2e.py::test_grouped_launches_are_bit_identical_and_fewer), like another batch size.
     struct Job { int slot, lane, h, wd, C; const AdapterBlockW* bw; const BlockPre* bp; const void* in; void* out; size_t frame_elems; };
     std::vector<Job> jobs;
     size_t bi = 0;
@@ -810,6 +813,16 @@ int ctrl_adapter_trim(ctrl_adapter* h) {
     HIP_TRY(hipDeviceSynchronize());
     h->arena.trim();
     h->kvc.trim();
+    return 0;
+}
+
+int ctrl_adapter_selection(ctrl_adapter* h, char* buf, int len) {
+    CTRL_CHECK(h && buf && len > 0, "adapter_selection: null argument");
+    int n32 = 0, n = 0;
+    for (const AdapterBlockW& b : h->w.blocks) { ++n; n32 += b.tok_f32 ? 1 : 0; }
+    if (h->w.has_mid) { ++n; n32 += h->w.mid.tok_f32 ? 1 : 0; }
+    snprintf(buf, (size_t)len, "blocks=%d token_stream_fp32_blocks=%d (outlier norm scales, gate %.1f) token_stream_fp16=%d stream_f32=%d ff_fused=%d", n, n32,
+             kNormSpreadGate, adapter_tok_f16() ? 1 : 0, stream_f32_enabled() ? 1 : 0, policy_is0(P_FF_FUSED) ? 0 : 1);
     return 0;
 }
 

@@ -42,6 +42,11 @@ struct ControlNetW {
     // The ControlNet's ~25 residual branches otherwise accumulate the fp16 operand rounding to ~1e-3 rel-inf on its outputs
     // (tools/experiments/fp16_error_budget.py), which the adapter chain inherits; costs 2 x the MFMA work of those convs.
     bool split = true;
+    // what plan creation selected (ctrl_controlnet_selection): levels with split operands, levels whose ResNet 3x3 convolutions take them, and
+    // the largest max|gamma| / median|gamma| of the checkpoint's normalisation scales that decided it
+    int sel_levels = 0, sel_res_levels = 0;
+    float sel_norm_spread = 0.f;
+    bool sel_outliers = false;
 };
 
 bool cn_split_enabled() {
@@ -141,8 +146,10 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
     // the 1x1 convolutions take them on (ParamSink::norm_scale_spread)
     const int levels = cn_split_levels();
     // (an opt-in CTRL_CN_SPLIT_RESNET_LEVELS < levels is ignored for a checkpoint with outlier norm scales)
-    const bool outliers = ps.norm_scale_spread("") > kNormSpreadGate;
+    const float spread = ps.norm_scale_spread("");
+    const bool outliers = spread > kNormSpreadGate;
     const int res_levels = outliers ? levels : cn_split_resnet_levels();
+    w->sel_levels = dup ? levels : 0; w->sel_res_levels = dup ? res_levels : 0; w->sel_norm_spread = spread; w->sel_outliers = outliers;
     auto add_resnet = [&](const std::string& pre, int Cin, int Cout, ResnetW* r, bool dup_r, int dup_sc = -1) -> int {
         TRY(build_resnet(ps, pre, Cin, Cout, false, r, dup_r, dup_sc));
         r->temb_off = w->temb_total;
@@ -534,6 +541,14 @@ int ctrl_controlnet_trim(ctrl_controlnet* h) {
     h->kvc.trim();
     for (void* p : h->cond_retired) (void)hipFree(p);
     h->cond_retired.clear();
+    return 0;
+}
+
+int ctrl_controlnet_selection(ctrl_controlnet* h, char* buf, int len) {
+    CTRL_CHECK(h && buf && len > 0, "controlnet_selection: null argument");
+    snprintf(buf, (size_t)len, "split_operands=%d split_levels=%d split_resnet_levels=%d norm_scale_spread=%.2f gate=%.1f selection=%s", h->w.split ? 1 : 0,
+             h->w.sel_levels, h->w.sel_res_levels, h->w.sel_norm_spread, kNormSpreadGate,
+             h->w.sel_outliers ? "conservative(outlier norm scales)" : "default");
     return 0;
 }
 

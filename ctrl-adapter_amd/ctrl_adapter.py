@@ -68,6 +68,7 @@ class ControlNetAdapter(ParamTreeModule):
             h = C.c_void_p()
             L.check(L.lib().ctrl_adapter_create(C.byref(self._cfg), refs, n, L.cur_stream(), C.byref(h)))
             self._plan = h
+            self._note_selection(L.lib().ctrl_adapter_selection)
         return self._plan
 
     @torch.no_grad()

@@ -351,6 +351,11 @@ int ctrl_adapter_text_cache(ctrl_adapter* h, int mode);
  * call it when no captured graph that was recorded before the last growth will be replayed again.  A plan has no lock: trim
  * must not run concurrently with a forward of the same plan, and it is refused (non-zero) while a stream capture of that plan's
  * forward is still open (its device synchronisation would invalidate the capture). */
+/* Which precision selection plan creation took for this checkpoint (a short key=value line): split-operand levels, whether outlier
+   normalisation scales (max|gamma| / median|gamma| above the gate) switched it to the conservative selection, fp32 token-stream blocks of
+   the adapter.  The Python mirrors expose it as `module.selection` and warn once when a conservative selection was taken. */
+int ctrl_controlnet_selection(ctrl_controlnet* h, char* buf, int len);
+int ctrl_adapter_selection(ctrl_adapter* h, char* buf, int len);
 int ctrl_controlnet_trim(ctrl_controlnet* h);
 int ctrl_adapter_trim(ctrl_adapter* h);
 

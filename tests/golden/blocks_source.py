@@ -1,7 +1,8 @@
 """Which `diffusers` the reference's files run on when the goldens are made / the live check runs.
 
-The reference imports its transformer / ResNet blocks from diffusers (requirements_inference.txt: diffusers==0.27.2 --
-model/adapter_spatial_temporal.py:96-134, controlnet/controlnet.py:371-424, model/resnet_block_2d.py:28).  That package is not
+The reference imports its transformer / ResNet blocks from diffusers (model/adapter_spatial_temporal.py:96-134,
+controlnet/controlnet.py:371-424, model/resnet_block_2d.py:28).  Its requirements_inference.txt names `diffusers` WITHOUT a version; 0.27.2
+(PINNED below) is inferred from the "copied from .../diffusers/blob/v0.27.2/..." headers of the reference's own files.  That package is not
 installable in the build container (no network), so the goldens committed here were made over oracle/_shim, a minimal
 `diffusers` whose blocks ARE oracle/blocks.py: they pin the reference's own glue and are circular for the diffusers arithmetic.
 This module closes that: when a REAL diffusers is importable it is used instead of the shim, and every golden file carries

@@ -1078,6 +1078,10 @@ def test_weight_distribution_sweep_sdxl_chain(P, gpu, tag):
         torch.cuda.synchronize()
         e_cn = max(rel_inf(a, b) for a, b in zip(list(d) + [m], list(rd) + [rm]))
         e_ch = max(rel_inf(a, b) for a, b in zip(o[:9], ro[:9]))
+        # the plans SAY which selection they took (ctrl_*_selection): outlier norm scales -> conservative, everything else default
+        print("PARITY weight sweep %-14s selections: controlnet [%s] adapter [%s]" % (tag, cn.selection, ad.selection))
+        assert ("conservative" in cn.selection) == (tag == "gamma_outliers"), cn.selection
+        assert ("token_stream_fp32_blocks=0 " in ad.selection) == (tag != "gamma_outliers"), ad.selection
         return e_cn, e_ch
 
     P._lib.range_check(True)                  # an activation beyond the fp16 range raises instead of passing silently as inf
