@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r05 v1 [1 = also write the pytest parity logs (adds ~13 minutes; they run LAST)]
+#   bash tools/profile_round.sh r06 v1 [1 = also write the pytest parity logs (adds ~13 minutes; they run LAST)]
 # Writes under gpurun_out/final/; copy what should be judged into profiles/.  ~8 minutes of box time without the tests.
 set -u
 R=${1:-r05}; V=${2:-v1}; TESTS=${3:-0}
@@ -17,6 +17,11 @@ python bench.py --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --per-kernel-
 python bench.py --workload i2vgen16 --clip-split --steps 5 --warmup 2 --no-cpu-baseline --per-kernel-out $O/${R}_per_kernel_clip_${V}.json > $O/${R}_bench_clip_split_world1_${V}.json 2>> $O/bench.err
 timeout 120 tools/bin/gemm_order_bench $O/${R}_gemm_path_shapes_${V}.txt shapes > /dev/null 2>&1
 timeout 120 tools/bin/attn_bench $O/${R}_attention_variants_${V}.txt > /dev/null 2>&1
+timeout 120 tools/bin/ffn_bench $O/${R}_ffn_bench_${V}.txt > /dev/null 2>&1
+# the ControlNet call alone, per kernel (round 6)
+python bench.py --no-cpu-baseline --no-other-workloads --steps 5 --warmup 2 --profile-scope controlnet --per-kernel-out $O/${R}_per_kernel_controlnet_${V}.json > /dev/null 2>> $O/bench.err
+# counters of the fused feed-forward kernel and of the two-launch form beside it
+bash tools/ffn_pmc.sh ${R}_${V} > /dev/null 2>&1; cp gpurun_out/ffn_pmc/summary_${R}_${V}.txt $O/${R}_ffn_pmc_${V}.txt 2>/dev/null
 fi
 # per-kernel time of the same command (its own run: no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 --per-kernel-out $O/tmp_pk.json > $O/stats.log 2>&1
