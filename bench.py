@@ -130,17 +130,16 @@ def quick_time(dev, wname, batch, steps, warmup, world):
     x = make_inputs(dev, w, n, seed=4321)
     t = torch.tensor([499.0], device=dev)
     masks = [1] * w["n_cn"]
+    multi = P.MultiControlNetModel(cns) if w["n_cn"] > 1 else None
 
     def step():
         s = P.pool_latents(x["latents"], (64, 64))
         if w["n_cn"] == 1:
             down, mid = cns[0](s, t, x["ehs_c"], x["cond0"], conditioning_scale=1.0, return_dict=False, skip_conv_in=w["skip_conv_in"])
         else:
-            downs, mids = [], []
-            for k, cn in enumerate(cns):
-                d, m = cn(s, t, x["ehs_c"], x["cond%d" % k], conditioning_scale=1.0, return_dict=False, skip_conv_in=w["skip_conv_in"])
-                downs.append(d)
-                mids.append(m)
+            # MultiControlNetModel.forward (controlnet/multicontrolnet.py:45-99): per-net lists
+            downs, mids = multi(s, t, x["ehs_c"], [x["cond%d" % k] for k in range(len(cns))], [1.0] * len(cns), return_dict=False,
+                                skip_conv_in=w["skip_conv_in"])
             dw, mw = router(sparse_mask=masks)
             down, mid = router.merge(downs, mids, dw, mw, masks, num_frames=nf, inference_quirk=True)
         return ad(down, mid_block_res_sample=mid, num_frames=nf, timestep=t, encoder_hidden_states=x["ehs_a"])
@@ -277,15 +276,14 @@ def main():
         x = make_inputs(dev, w, n, seed=1234 + rank)   # every rank owns different images / clips (no collective)
     t = torch.tensor([499.0], device=dev)
     masks = [1] * w["n_cn"]
+    multi = P.MultiControlNetModel(cns) if w["n_cn"] > 1 else None
 
     def controlnets(s):
         if w["n_cn"] == 1:
             return cns[0](s, t, x["ehs_c"], x["cond0"], conditioning_scale=1.0, return_dict=False, skip_conv_in=w["skip_conv_in"])
-        downs, mids = [], []
-        for k, cn in enumerate(cns):                  # MultiControlNetModel.forward (controlnet/multicontrolnet.py:45-99)
-            d, m = cn(s, t, x["ehs_c"], x["cond%d" % k], conditioning_scale=1.0, return_dict=False, skip_conv_in=w["skip_conv_in"])
-            downs.append(d)
-            mids.append(m)
+        # MultiControlNetModel.forward (controlnet/multicontrolnet.py:45-99): per-net lists (the mirror runs the nets on stream lanes)
+        downs, mids = multi(s, t, x["ehs_c"], [x["cond%d" % k] for k in range(len(cns))], [1.0] * len(cns), return_dict=False,
+                            skip_conv_in=w["skip_conv_in"])
         dw, mw = router(sparse_mask=masks)            # model/ctrl_router.py:85-112, then the pipeline's merge (:1000-1022)
         return router.merge(downs, mids, dw, mw, masks, num_frames=nf, inference_quirk=True)
 

@@ -180,12 +180,36 @@ class MultiControlNetModel(torch.nn.Module):
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, class_labels=None,
                 timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
                 guess_mode=False, return_dict=True, skip_conv_in=False, skip_time_emb=False):
-        downs, mids = [], []
-        for image, scale, net in zip(controlnet_cond, conditioning_scale, self.nets):   # positional zip (quirk N6)
-            d, m = net(sample, timestep, encoder_hidden_states, image, scale, guess_mode=guess_mode, return_dict=False,
+        jobs = list(zip(controlnet_cond, conditioning_scale, self.nets))                # positional zip (quirk N6)
+
+        def run(image, scale, net):
+            return net(sample, timestep, encoder_hidden_states, image, scale, guess_mode=guess_mode, return_dict=False,
                        skip_conv_in=skip_conv_in, skip_time_emb=skip_time_emb)
-            downs.append(d)
-            mids.append(m)
+
+        from . import ops
+        lanes = len(jobs) > 1 and sample.is_cuda and (ops.policy().get("CTRL_MULTI_CN_LANES", "1") != "0")
+        if not lanes:
+            outs = [run(*j) for j in jobs]
+        else:
+            # Round 6: the K nets are independent (same latents / prompt, their own condition image and weights), and a ControlNet forward
+            # is a dependent chain of ~220 launches most of which fill a fraction of the chip -- so net k runs on its own stream lane,
+            # forked from and joined to the caller's stream with events (hipGraph-capturable: bench.py captures it), and the chains overlap.
+            # Same kernels, same order per net: results are bit-identical to the serial loop (CTRL_MULTI_CN_LANES=0).
+            cur = torch.cuda.current_stream(sample.device)
+            if getattr(self, "_lanes", None) is None or len(self._lanes) < len(jobs) - 1:
+                self._lanes = [torch.cuda.Stream(device=sample.device) for _ in range(len(jobs) - 1)]
+            outs = [None] * len(jobs)
+            for k, j in enumerate(jobs[1:], start=1):
+                s = self._lanes[k - 1]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    outs[k] = run(*j)
+            outs[0] = run(*jobs[0])                       # net 0 on the caller's stream, beside the others
+            for k in range(1, len(jobs)):
+                cur.wait_stream(self._lanes[k - 1])
+                for t_ in list(outs[k][0]) + [outs[k][1]]:
+                    t_.record_stream(cur)                 # allocated on the lane, consumed on the caller's stream
+        downs, mids = [o[0] for o in outs], [o[1] for o in outs]
         return downs, mids
 
 

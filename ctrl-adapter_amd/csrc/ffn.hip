@@ -81,7 +81,7 @@ __host__ __device__ constexpr int slot(int piece) { return (piece & 7) * PIECE; 
 // same to the product kernel, rarely).  The result must be bit-identical to the plain kernel's.
 // Ablation builds (tools/bin/ffn_bench only; WRONG results by construction): ABL_NODMA stages nothing inside the chunk loop, ABL_NOGEGLU replaces
 // the GEGLU math by a plain product, ABL_NOREAD skips the fragment reads -- what each costs is the time that build does NOT take.
-enum { FF_PLAIN = 0, FF_JITTER = 1, ABL_NODMA = 2, ABL_NOGEGLU = 3, ABL_NOREAD = 4, FF_BULK = 5 };
+enum { FF_PLAIN = 0, FF_JITTER = 1, ABL_NODMA = 2, ABL_NOGEGLU = 3, ABL_NOREAD = 4, FF_BULK = 5, ABL_XHOT = 6 };
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per, int ntm) {
     constexpr bool JIT = MODE == FF_JITTER;
@@ -137,8 +137,10 @@ __global__ __launch_bounds__(512, 2) void ffn512_kernel(FfnGroup kargs, int per,
         if constexpr (I < 24) {
             constexpr int t = I / 3, r = I % 3;
             if constexpr (r == 0) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, FF_LDS_DST(dst), 16, v0, t * 128, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, FF_LDS_DST(dst + 8192), 16, v1, t * 128, 0, 0);
+                // (ABL_XHOT: every X piece re-reads k-tile 0 -- 16 KB per workgroup, always in the L2: what the re-streamed X tile costs in the memory system)
+                const int xo = (MODE == ABL_XHOT) ? 0 : t * 128;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, FF_LDS_DST(dst), 16, v0, xo, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, FF_LDS_DST(dst + 8192), 16, v1, xo, 0, 0);
             } else {
                 const int so = (cc * 256 + (r - 1) * 128) * 1024 + t * 128;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rs, FF_LDS_DST(dst), 16, v0, so, 0, 0);
@@ -343,6 +345,7 @@ int op_ffn_fused_group(const FfnArgs* as, int n, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<ABL_NOGEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
         HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<ABL_NOREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
         HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<FF_BULK>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)ffn512_kernel<ABL_XHOT>, hipFuncAttributeMaxDynamicSharedMemorySize, ff::LDS_TOTAL));
         attr_done[dev] = true;
     }
     PROF_WORK(n * 2.0 * M * (double)(2 * ff::H * ff::D + ff::H * ff::D),
@@ -356,6 +359,7 @@ int op_ffn_fused_group(const FfnArgs* as, int n, hipStream_t s) {
     if (pol && pol[0] == 'j') LAUNCH("ffn_fused", (ffn512_kernel<FF_JITTER>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
     else if (pol && !strcmp(pol, "abl_nodma")) LAUNCH("ffn_fused", (ffn512_kernel<ABL_NODMA>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
     else if (pol && !strcmp(pol, "abl_nogeglu")) LAUNCH("ffn_fused", (ffn512_kernel<ABL_NOGEGLU>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
+    else if (pol && !strcmp(pol, "abl_xhot")) LAUNCH("ffn_fused", (ffn512_kernel<ABL_XHOT>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
     else if (pol && !strcmp(pol, "bulk")) LAUNCH("ffn_fused", (ffn512_kernel<FF_BULK>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
     else if (pol && !strcmp(pol, "abl_noread")) LAUNCH("ffn_fused", (ffn512_kernel<ABL_NOREAD>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);
     else LAUNCH("ffn_fused", (ffn512_kernel<FF_PLAIN>), grid, blk, ff::LDS_TOTAL, s, g, per, ntm);

@@ -1287,3 +1287,47 @@ def test_captured_multi_lane_adapter_forward_many_replays(P, gpu):
     print("PARITY captured multi-lane adapter forward: 150 replays, %d (replay, output) pairs differ from the serial forward" % len(bad))
     assert not bad, "replays that differ from the serial forward (replay, output): %s" % bad[:10]
     del g
+
+
+def test_multi_controlnet_stream_lanes_equal_serial_and_replay(P, gpu):
+    """MultiControlNetModel (controlnet/multicontrolnet.py:45-99) runs its K independent nets on stream lanes (round 6): bit-identical to
+    the serial loop (CTRL_MULTI_CN_LANES=0) -- eager and as a captured graph replayed several times (the form bench.py --workload multi3 times)."""
+    from ctrl_adapter_amd import ops
+    torch.set_grad_enabled(False)
+    K, N, hs = 3, 4, 16
+    nets = [seeded_init(P.ControlNetModel(**cases.CONTROLNET_KW), seed=11 + 100 * k).to(gpu) for k in range(K)]
+    multi = P.MultiControlNetModel(nets)
+    inp = cases.controlnet_inputs(N=N, hs=hs, seed=4100)
+    sample, ehs = inp["sample"].half().to(gpu), inp["encoder_hidden_states"].half().to(gpu)
+    t = torch.tensor([499.0]).to(gpu)
+    conds = [seeded_tensor((N, 3, hs * 8, hs * 8), 4200 + k, kind="uniform").half().to(gpu) for k in range(K)]
+
+    def fwd():
+        d, m = multi(sample, t, ehs, conds, [1.0, 0.5, 2.0], return_dict=False)
+        return [x for dk in d for x in dk] + list(m)
+
+    prev = ops.set_policy("CTRL_MULTI_CN_LANES", "0")
+    try:
+        fwd()
+        serial = [x.clone() for x in fwd()]
+    finally:
+        ops.set_policy("CTRL_MULTI_CN_LANES", prev)
+    lanes = fwd()
+    torch.cuda.synchronize()
+    assert len(lanes) == K * 13 and all(torch.equal(a, b) for a, b in zip(lanes, serial)), "stream lanes changed a ControlNet output"
+    assert not torch.equal(serial[0], serial[12])            # (the nets really differ: different weights, images and scales)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fwd()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = fwd()
+    for rep in range(20):
+        g.replay()
+        torch.cuda.synchronize()
+        bad = [i for i, (a, b) in enumerate(zip(outs, serial)) if not torch.equal(a, b)]
+        assert not bad, "graph replay %d: outputs %s differ from the serial forward" % (rep, bad)
+    print("PARITY MultiControlNetModel on %d stream lanes: eager and 20 graph replays bit-identical to the serial loop" % K)
+    del g

@@ -23,6 +23,8 @@ def kernel_class(name):
     m = re.search(r"igemm8_kernel<\s*\d+,\s*(\d+)>", name) or re.search(r"igemm8_kernelILi\d+ELi(\d+)E", name)      # round 4's wide tile: <NI, MODE>
     if m:
         return {"0": "igemm_rows", "1": "igemm_conv", "2": "igemm_temporal"}[m.group(1)]
+    if "ffn512_kernel" in name:          # round 6: the fused GEGLU feed-forward (csrc/ffn.hip)
+        return "ffn_fused"
     for key in ("splitk_finish", "flash_attn", "temporal_attn", "gn_stats", "gn_apply", "gn_fused", "layernorm", "conv3x3_direct", "conv3x3_small_mfma",
                 "linear_small", "nchw_to_nhwc", "nhwc_to_nchw", "avgpool", "sincos", "blend", "add_rowvec", "merge", "fill_zero"):
         if key in name:
@@ -51,6 +53,8 @@ def symbol_of(name):
     if m:
         tf = lambda v: "true" if v == "1" else "false"
         return "flash_attn_kernel<%s, %s, %s, %s>" % (m.group(1), m.group(2), tf(m.group(3)), tf(m.group(4)))
+    if "ffn512_kernel" in name:
+        return "ffn512_kernel"
     m = re.search(r"((?:igemm8|igemm|flash_attn|flash_attn_d64|flash_attn_d64p)_kernel<[^>]*>)", name)
     if m:
         return re.sub(r",\s*", ", ", m.group(1))
