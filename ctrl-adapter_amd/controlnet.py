@@ -110,7 +110,7 @@ class ControlNetModel(ParamTreeModule):
         outs.append(torch.empty(N, self._slot_channels[-1], max(Hs // 8, 1), max(Ws // 8, 1), dtype=out_dtype, device=sample.device))
         sample_c, ehs_c, cond_c = sample.contiguous(), ehs.contiguous(), controlnet_cond.contiguous()
         ptrs = (C.c_void_p * 13)(*[o.data_ptr() for o in outs])
-        flags = (1 if skip_conv_in else 0) | (2 if skip_time_emb else 0) | (4 if guess_mode else 0)
+        flags = (1 if skip_conv_in else 0) | (2 if skip_time_emb else 0) | (4 if guess_mode else 0) | (32 if getattr(self, "_no_aux_lane", False) else 0)
         if self.cache_condition:
             # same tensor object, not written to since the forward that cached it (and same plan): the embedder's hidden
             # map is still valid.  The reference recomputes it on each of the ~50 steps.
@@ -182,9 +182,15 @@ class MultiControlNetModel(torch.nn.Module):
                 guess_mode=False, return_dict=True, skip_conv_in=False, skip_time_emb=False):
         jobs = list(zip(controlnet_cond, conditioning_scale, self.nets))                # positional zip (quirk N6)
 
-        def run(image, scale, net):
-            return net(sample, timestep, encoder_hidden_states, image, scale, guess_mode=guess_mode, return_dict=False,
-                       skip_conv_in=skip_conv_in, skip_time_emb=skip_time_emb)
+        def run(image, scale, net, on_lane=False):
+            # (a net on a lane of its own keeps to that one stream: its auxiliary lane would be a fork inside a fork, which crashes
+            #  hipGraph's end-of-capture on ROCm 7.2 -- CTRL_NO_AUX_LANE; same kernels, same results)
+            net._no_aux_lane = on_lane
+            try:
+                return net(sample, timestep, encoder_hidden_states, image, scale, guess_mode=guess_mode, return_dict=False,
+                           skip_conv_in=skip_conv_in, skip_time_emb=skip_time_emb)
+            finally:
+                net._no_aux_lane = False
 
         from . import ops
         lanes = len(jobs) > 1 and sample.is_cuda and (ops.policy().get("CTRL_MULTI_CN_LANES", "1") != "0")
@@ -203,8 +209,8 @@ class MultiControlNetModel(torch.nn.Module):
                 s = self._lanes[k - 1]
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
-                    outs[k] = run(*j)
-            outs[0] = run(*jobs[0])                       # net 0 on the caller's stream, beside the others
+                    outs[k] = run(*j, on_lane=True)
+            outs[0] = run(*jobs[0], on_lane=True)         # net 0 on the caller's stream, beside the others
             for k in range(1, len(jobs)):
                 cur.wait_stream(self._lanes[k - 1])
                 for t_ in list(outs[k][0]) + [outs[k][1]]:

@@ -596,7 +596,7 @@ static int controlnet_forward_impl(ctrl_controlnet* h, const void* sample, int s
     const bool aux_env = policy_int(P_CN_AUX, 1) != 0;
     FwdArgs a = {sample, sample_dtype, N, Hs, Ws, timesteps, t_count, encoder_hidden_states, ehs_dtype, Lk,
                  controlnet_cond, cond_dtype, conditioning_scale, flags, outs, out_dtype, out_ev, cache, reuse,
-                 h, aux_env && !g_prof_on && out_ev == nullptr};
+                 h, aux_env && !g_prof_on && out_ev == nullptr && !(flags & CTRL_NO_AUX_LANE)};
     // (off while the per-launch profiler records -- one kernel at a time -- and in the fused step, whose ControlNet already
     //  overlaps with the adapter: capturing fused + auxiliary lane into a hipGraph crashed hipGraphInstantiate on ROCm 7.2)
     // sizing pass (no launches) -> workspace; then the real pass

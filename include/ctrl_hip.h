@@ -288,7 +288,10 @@ enum { CTRL_SKIP_CONV_IN = 1, CTRL_SKIP_TIME_EMB = 2, CTRL_GUESS_MODE = 4,
         * same on every denoise step of a request.  KEEP = also store the embedder's last hidden map (256 ch at the latent
         * resolution) in plan-owned memory; REUSE = controlnet_cond is unchanged since the forward that stored it: start
         * from the stored map (only the final zero-initialised 3x3 conv runs).  Results are bit-identical either way. */
-       CTRL_COND_KEEP = 8, CTRL_COND_REUSE = 16 };
+       CTRL_COND_KEEP = 8, CTRL_COND_REUSE = 16,
+       /* everything on the launch stream, no auxiliary lane: for callers that already run this forward on a forked lane of their own
+        * (MultiControlNetModel's per-net lanes) -- a fork inside a fork crashes hipGraph's end-of-capture on ROCm 7.2 */
+       CTRL_NO_AUX_LANE = 32 };
 /* sample [N][4][Hs][Ws], timesteps fp32 device [t_count] (1 or N), encoder_hidden_states [N][Lk][cross],
  * controlnet_cond [N][3][8*Hs][8*Ws]; outs[0..11] = down_block_res_samples, outs[12] = mid_block_res_sample,
  * all NCHW in out_dtype, already multiplied by conditioning_scale. */
