@@ -97,7 +97,7 @@ EXPORTS = [
     "ctrl_op_conv3x3_direct", "ctrl_op_conv3x3_small_mfma", "ctrl_op_pack_conv_w", "ctrl_op_pack_conv_w_direct", "ctrl_op_pack_linear_w",
     "ctrl_op_pack_vec",
     "ctrl_controlnet_param_count", "ctrl_controlnet_param_spec", "ctrl_controlnet_create",
-    "ctrl_controlnet_destroy", "ctrl_controlnet_forward",
+    "ctrl_controlnet_destroy", "ctrl_controlnet_clone", "ctrl_controlnet_forward",
     "ctrl_adapter_param_count", "ctrl_adapter_param_spec", "ctrl_adapter_create", "ctrl_adapter_destroy",
     "ctrl_adapter_forward",
     "ctrl_adapter_forward_scatter", "ctrl_adapter_forward_clip_sharded", "ctrl_controlnet_text_cache", "ctrl_adapter_text_cache", "ctrl_controlnet_trim", "ctrl_adapter_trim", "ctrl_controlnet_selection", "ctrl_adapter_selection",

@@ -97,7 +97,60 @@ class ControlNetModel(ParamTreeModule):
 
     def _drop_plan(self):
         self._cond_ref, self._cond_version, self._cond_key = None, -1, None      # the cache lives in the plan
+        if getattr(self, "_plan_b", None) is not None:
+            self._destroy(self._plan_b)
+        self._plan_b = None
         super()._drop_plan()
+
+    # -- batch lanes (round 6): the two halves of a batch on two stream lanes --
+    # A ControlNet forward at the pipelines' batch sizes is a dependent chain of ~220 launches most of which fill a fraction of the chip
+    # (M = 512 .. 32768 rows at b = 8: 0.10 of the MFMA peak, 7 of its 8 ms in launches below a quarter of either roof).  Images are
+    # independent, so images [0, N/2) run on the caller's stream and [N/2, N) on a lane of the module's own through a CLONE of the plan
+    # (same packed weights, its own workspace: ctrl_controlnet_clone), forked / joined with events -- the two chains interleave on the
+    # chip.  Every image is computed exactly as in a forward of N/2 images (tile choices follow the batch the dispatcher sees, so the
+    # last bits can differ from the one-batch forward, like any other batch size).  MEASURED AND NOT ADOPTED: SDXL b = 8 29.05 / 29.10 ms
+    # without against 29.31 / 29.32 ms with it (same box, two rounds each, profiles/r06_cn_batch_lanes.txt) -- the half-batch kernels are not
+    # half as long and the two chains contend; what does pay is lanes over INDEPENDENT nets (MultiControlNetModel: -7 %).  Opt-in:
+    # CTRL_CN_BATCH_LANES=1; never while the per-launch profiler records, with the step-invariant caches or below 8 images.
+    BATCH_LANES_MIN = 8
+
+    def _batch_lanes_apply(self, N, timestep):
+        from . import ops
+        if N < self.BATCH_LANES_MIN or N % 2 or self.cache_condition or self.cache_text or ops.profiling() or getattr(self, "_no_aux_lane", False):
+            return False          # (_no_aux_lane: this forward already runs on a lane of MultiControlNetModel -- no fork inside a fork)
+        return ops.policy().get("CTRL_CN_BATCH_LANES", "0") == "1"
+
+    def _forward_batch_lanes(self, args, outs, N, device):
+        lib = L.lib()
+        plan_a = self._ensure_plan()
+        if getattr(self, "_plan_b", None) is None:
+            h = C.c_void_p()
+            L.check(lib.ctrl_controlnet_clone(plan_a, C.byref(h)))
+            self._plan_b = h
+            self._lane = torch.cuda.Stream(device=device)
+        # args (see _launch_args): sample, dt, N, Hs, Ws, t, t_count, ehs, dt, Lk, cond, dt, scale, flags, out pointers, out dtype
+        sample_p, sdt, _, Hs, Ws, t_p, t_n, ehs_p, edt, Lk, cond_p, cdt, scale, flags, ptrs, odt = args
+        h = N // 2
+        esz = {L.F32: 4, L.F16: 2, L.BF16: 2}
+
+        def off(p, nbytes):
+            return C.c_void_p((p.value or 0) + nbytes)
+
+        cross = self.config.cross_attention_dim
+        cc = int(self.config.get("conditioning_channels", 3))
+        ptrs_b = (C.c_void_p * 13)()
+        for i, o in enumerate(outs):
+            ptrs_b[i] = o.data_ptr() + h * o.stride(0) * o.element_size()
+        args_a = [sample_p, sdt, h, Hs, Ws, t_p, min(t_n, h) if t_n > 1 else 1, ehs_p, edt, Lk, cond_p, cdt, scale, flags | 32, ptrs, odt]
+        cin = int(self.config.get("in_channels", 4))
+        args_b = [off(sample_p, h * cin * Hs * Ws * esz[sdt]), sdt, h, Hs, Ws, off(t_p, h * 4) if t_n > 1 else t_p, h if t_n > 1 else 1,
+                  off(ehs_p, h * Lk * cross * esz[edt]), edt, Lk, off(cond_p, h * cc * 64 * Hs * Ws * esz[cdt]), cdt, scale, flags | 32, ptrs_b, odt]
+        cur = torch.cuda.current_stream(device)
+        self._lane.wait_stream(cur)
+        with torch.cuda.stream(self._lane):
+            L.check(lib.ctrl_controlnet_forward(self._plan_b, *args_b, L.cur_stream()))
+        L.check(lib.ctrl_controlnet_forward(plan_a, *args_a, L.cur_stream()))
+        cur.wait_stream(self._lane)
 
     def _launch_args(self, sample, timestep, ehs, controlnet_cond, conditioning_scale, guess_mode, skip_conv_in,
                      skip_time_emb, out_dtype):
@@ -159,7 +212,10 @@ class ControlNetModel(ParamTreeModule):
                                               skip_conv_in, skip_time_emb, out_dtype)
         with torch.cuda.device(sample.device):      # plan, stream and launches follow the tensors' device, not the current one
             self._text_cache_mode(encoder_hidden_states, L.lib().ctrl_controlnet_text_cache)
-            L.check(L.lib().ctrl_controlnet_forward(self._ensure_plan(), *args, L.cur_stream()))
+            if self._batch_lanes_apply(N, timestep):
+                self._forward_batch_lanes(args, outs, N, sample.device)
+            else:
+                L.check(L.lib().ctrl_controlnet_forward(self._ensure_plan(), *args, L.cur_stream()))
             L.raise_if_out_of_range("ControlNetModel.forward")
         if pool:       # controlnet/controlnet.py:870-874: torch.mean(sample, dim=(2, 3), keepdim=True) of every output
             from . import ops

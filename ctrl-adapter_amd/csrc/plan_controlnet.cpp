@@ -200,7 +200,7 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
 
 struct ctrl_controlnet : PlanBase {
     ControlNetW w;
-    std::unique_ptr<Packer> packer;
+    std::shared_ptr<Packer> packer;      // owns the packed weights; shared with the plan's clones (ctrl_controlnet_clone)
     Arena arena;
     KvCache kvc;                         // text K/V cache (ctrl_*_text_cache)
     // fused step (ctrl_step_forward): the network runs on its own stream and signals every output with an event
@@ -229,7 +229,7 @@ struct ctrl_controlnet : PlanBase {
         return 0;
     }
     ~ctrl_controlnet() {
-        if (packer) packer->release_all();
+        if (packer && packer.use_count() == 1) packer->release_all();      // (the last plan over these weights frees them: ctrl_controlnet_clone)
         if (cond_cache) (void)hipFree(cond_cache);
         for (void* p : cond_retired) (void)hipFree(p);
         if (side) (void)hipStreamDestroy(side);
@@ -527,6 +527,21 @@ int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_
     TRY(h->init_async());
     TRY(h->packer->finish());            // sync: packed copies are complete (source tensors may be freed); fp16 range check
     *out = h.release();
+    return 0;
+}
+
+// A second plan over the SAME packed weights (shared, reference-counted) with a workspace, streams and events of its own: two forwards
+// of the module can then be in flight at once -- the Python mirror runs the two halves of a batch on two stream lanes through it
+// (ControlNetModel.forward, round 6).  Destroy like any plan; the weights go with the last plan that holds them.
+int ctrl_controlnet_clone(ctrl_controlnet* h, ctrl_controlnet** out) {
+    CTRL_CHECK(h && out, "controlnet_clone: null argument");
+    std::unique_ptr<ctrl_controlnet> c(new ctrl_controlnet());
+    c->device = h->device;
+    DeviceGuard dg(h->device);
+    c->w = h->w;
+    c->packer = h->packer;
+    TRY(c->init_async());
+    *out = c.release();
     return 0;
 }
 

@@ -13,7 +13,7 @@ const char* const kNames[P_COUNT] = {
     "CTRL_CN_SPLIT_RESNET_LEVELS", "CTRL_SMALLCONV_MFMA", "CTRL_CN_AUX", "CTRL_STEP_OVERLAP", "CTRL_CHECK_FINITE", "CTRL_PROF_DUMP",
     "CTRL_STREAM_F32", "CTRL_ADAPTER_TOK_F16", "CTRL_ADAPTER_H1_F16", "CTRL_ATTN_NW4", "CTRL_ATTN_VARIANT", "CTRL_IGEMM_ORDER", "CTRL_IGEMM8",
     "CTRL_SPLITK_INLAUNCH", "CTRL_IGEMM_FORCE", "CTRL_SHORTK_PAIR", "CTRL_SMALL_TILES", "CTRL_GN_FUSED", "CTRL_FF_FUSED",
-    "CTRL_MULTI_CN_LANES",
+    "CTRL_MULTI_CN_LANES", "CTRL_CN_BATCH_LANES",
 };
 struct Entry { bool set = false; std::string v; };
 Entry g_tab[P_COUNT];

@@ -31,6 +31,7 @@ enum PolicyKey {
     P_GN_FUSED,                // CTRL_GN_FUSED=1: one-launch GroupNorm of small maps (measured slower: off)
     P_FF_FUSED,                // CTRL_FF_FUSED=0|1: the fused GEGLU feed-forward kernel (ffn.hip) for dim-512 token GEMM pairs
     P_MULTI_CN_LANES,          // CTRL_MULTI_CN_LANES=0: MultiControlNetModel runs its nets one after the other (read by the Python mirror)
+    P_CN_BATCH_LANES,          // CTRL_CN_BATCH_LANES=1: ControlNetModel.forward splits a batch >= 8 over two stream lanes (Python mirror; measured: no gain)
     P_COUNT
 };
 // the variable's value as getenv() would return it (nullptr = unset), from the table: environment snapshot or ctrl_policy_set override

@@ -366,14 +366,26 @@ def router_merge(experts, weights_row, widx):
     return out
 
 
+_profiling = False
+
+
+def profiling():
+    """True while a Profiler block records (one kernel at a time: the mirrors keep to one stream then)"""
+    return _profiling
+
+
 class Profiler:
     """HIP-event profiler over kernel classes (see ctrl_prof_* in include/ctrl_hip.h)."""
 
     def __enter__(self):
+        global _profiling
         L.check(L.lib().ctrl_prof_begin())
+        _profiling = True
         return self
 
     def __exit__(self, *exc):
+        global _profiling
+        _profiling = False
         lib = L.lib()
         L.check(lib.ctrl_prof_end())
         self.rows = {}

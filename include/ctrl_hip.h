@@ -281,6 +281,9 @@ int ctrl_controlnet_param_spec(const ctrl_controlnet_config* cfg, int i, char* n
 /* builds a plan: packs the weights (fp16, MFMA-friendly layouts) into memory owned by the plan */
 int ctrl_controlnet_create(const ctrl_controlnet_config* cfg, const ctrl_tensor_ref* tensors, int n_tensors,
                            void* stream, ctrl_controlnet** out);
+/* a second plan over the SAME packed weights (reference-counted) with its own workspace / streams / events: lets two forwards of one
+   module be in flight at once (the mirror's batch lanes).  ctrl_controlnet_destroy frees it; the weights go with the last holder. */
+int ctrl_controlnet_clone(ctrl_controlnet* h, ctrl_controlnet** out);
 void ctrl_controlnet_destroy(ctrl_controlnet* h);
 
 enum { CTRL_SKIP_CONV_IN = 1, CTRL_SKIP_TIME_EMB = 2, CTRL_GUESS_MODE = 4,

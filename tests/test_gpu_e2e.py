@@ -1331,3 +1331,62 @@ def test_multi_controlnet_stream_lanes_equal_serial_and_replay(P, gpu):
         assert not bad, "graph replay %d: outputs %s differ from the serial forward" % (rep, bad)
     print("PARITY MultiControlNetModel on %d stream lanes: eager and 20 graph replays bit-identical to the serial loop" % K)
     del g
+
+
+def test_controlnet_batch_lanes_equal_half_batches_and_oracle(P, gpu):
+    """ControlNetModel.forward at N >= 8 runs the two halves of the batch on two stream lanes through a clone of its plan (round 6:
+    ctrl_controlnet_clone, the same packed weights).  Every image must come out exactly as in a forward of its half alone (bit-identical:
+    same kernels, same tiles), within the last-bit band of the one-batch forward (another batch size for the tile dispatcher), inside the
+    oracle bound -- eager and as a captured graph replayed several times; with per-image timesteps and conditioning_scale."""
+    from ctrl_adapter_amd import ops
+    from oracle.controlnet import ControlNetOracle
+    torch.set_grad_enabled(False)
+    N, hs = 8, 16
+    cn = seeded_init(P.ControlNetModel(**cases.CONTROLNET_KW), seed=11).to(gpu)
+    inp = cases.controlnet_inputs(N=N, hs=hs, seed=4300)
+    sample, ehs = inp["sample"].half().to(gpu), inp["encoder_hidden_states"].half().to(gpu)
+    cond = inp["controlnet_cond"].half().to(gpu)
+    t = torch.tensor([999.0, 749.0, 499.0, 249.0, 20.0, 980.0, 500.0, 1.0])
+
+    def fwd(s=slice(None)):
+        d, m = cn(sample[s], t[s].to(gpu), ehs[s], cond[s], conditioning_scale=0.75, return_dict=False)
+        return list(d) + [m]
+
+    one = [x.clone() for x in fwd()]
+    lo = [x.clone() for x in fwd(slice(0, N // 2))]
+    hi = [x.clone() for x in fwd(slice(N // 2, N))]
+    prev = ops.set_policy("CTRL_CN_BATCH_LANES", "1")          # (opt-in: measured, no gain on the benched step)
+    try:
+        _batch_lanes_body(P, gpu, cn, fwd, one, lo, hi, inp, t, sample, ehs, cond, N)
+    finally:
+        ops.set_policy("CTRL_CN_BATCH_LANES", prev)
+
+
+def _batch_lanes_body(P, gpu, cn, fwd, one, lo, hi, inp, t, sample, ehs, cond, N):
+    from oracle.controlnet import ControlNetOracle
+    lanes = fwd()
+    torch.cuda.synchronize()
+    for i, (a, l, h) in enumerate(zip(lanes, lo, hi)):
+        assert torch.equal(a[:N // 2], l) and torch.equal(a[N // 2:], h), "output %d: a batch lane differs from the forward of its half alone" % i
+    e_one = max(rel_inf(a, b) for a, b in zip(lanes, one))
+    oc = seeded_init(ControlNetOracle(**cases.CONTROLNET_KW).eval(), seed=11)
+    rd, rm = oc(inp["sample"], t, inp["encoder_hidden_states"], inp["controlnet_cond"], conditioning_scale=0.75)
+    e_or = max(rel_inf(a, b) for a, b in zip(lanes, list(rd) + [rm]))
+    print("PARITY ControlNet batch lanes (N=8): halves bit-identical; vs the one-batch forward %.2e; vs oracle %.2e" % (e_one, e_or))
+    assert e_one <= 3e-4 and e_or <= TOL
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fwd()
+    torch.cuda.current_stream().wait_stream(s)
+    tg = t.to(gpu)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        d, m = cn(sample, tg, ehs, cond, conditioning_scale=0.75, return_dict=False)
+        outs = list(d) + [m]
+    for rep in range(20):
+        g.replay()
+        torch.cuda.synchronize()
+        bad = [i for i, (a, b) in enumerate(zip(outs, lanes)) if not torch.equal(a, b)]
+        assert not bad, "graph replay %d: outputs %s differ from the eager forward" % (rep, bad)
+    del g
