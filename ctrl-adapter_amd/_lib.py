@@ -87,7 +87,7 @@ class ClipComm(C.Structure):
 
 
 # every symbol include/ctrl_hip.h declares (tests check the library exports all of them)
-ABI_VERSION = 6       # CTRL_ABI_VERSION of include/ctrl_hip.h
+ABI_VERSION = 7       # CTRL_ABI_VERSION of include/ctrl_hip.h
 EXPORTS = [
     "ctrl_abi_version", "ctrl_last_error", "ctrl_prof_begin", "ctrl_prof_end", "ctrl_prof_count", "ctrl_prof_get",
     "ctrl_prof_launch_count", "ctrl_prof_launch_get",

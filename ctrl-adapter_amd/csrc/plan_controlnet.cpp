@@ -62,18 +62,20 @@ int cn_split_levels() {
     const int v = policy_int(P_CN_SPLIT_LEVELS, 3);
     return v < 0 ? 0 : (v > 5 ? 5 : v);
 }
-// The same depth for the ResNets' 3x3 convolutions alone (CTRL_CN_SPLIT_RESNET_LEVELS, default = CTRL_CN_SPLIT_LEVELS): the CPU emulation
-// per conv kind (tools/experiments/split_per_conv.py, round 4) says the 3x3 convolutions of the 640- and 1280-channel levels can take plain
-// operands at unchanged ControlNet / chain errors (6.2e-4 / 7.6e-4 against 6.8e-4 / 7.1e-4) while the 1x1 shortcuts, proj_in / proj_out,
-// down-samplers and zero-convs cannot; "1" halves the matrix work of 12 of the most expensive split launches (-0.46 ms of convolution time per
-// SDXL step, ~-2 ms per video step).  Round 5 ran the full GPU suite with "1" as the default (profiles/r05_e2e_parity_v1.log): every
-// at-shape chain stayed inside 1e-3 (SVD-16 9.6e-4) but the config-5 miniature chain (8 x 8 latents, three nets -> router -> merge -> video
-// adapter) came out at 1.001e-3 on one tensor -- the emulation's +0.5e-4 on that very chain is real, and the margins of this path are
-// thinner than that.  So the default stays = CTRL_CN_SPLIT_LEVELS (every convolution of down blocks 0-2 split) and "1" remains an opt-in.
+// The same depth for the ResNets' 3x3 convolutions alone (CTRL_CN_SPLIT_RESNET_LEVELS, default 1 since round 6): the 3x3 convolutions of the
+// 640- and 1280-channel levels take PLAIN operands -- half the matrix work of 12 of the most expensive split launches -- while the 1x1
+// shortcuts, proj_in / proj_out, down-samplers and zero-convs of those levels, and everything of level 0, keep the split.  History: the CPU
+// emulation per conv kind said so in round 4 (tools/experiments/split_per_conv.py); round 5 ran the full GPU suite with it and reverted it over
+// ONE tensor of the config-5 miniature chain at 1.001e-3 -- then confined the adapter's fp16 token stream, which is what that tensor had
+// really been paying for (1.00e-3 -> 7.1e-4).  Round 6 measured every selectable rounding point on its own, on three chains against the
+// oracle (tests/error_attribution.py -> profiles/r06_error_attribution.md): with "1" the SVD-16, SDXL and config-5 miniature chains move by
+// +0 / +2.4e-5 / +0 (8.52e-4 / 6.92e-4 / 8.76e-4; the ControlNet's own outputs 7.06e-4 / 6.14e-4 / 6.46e-4), for -1.6 ms per eager SVD-16
+// step; "0" (level 0 plain too) is another -0.4 ms but puts the ControlNet's outputs at 8.6e-4, and un-splitting the 1x1 kinds
+// (CTRL_CN_SPLIT_LEVELS=2) moves the chains by +2e-5...1e-4 -- both left alone.  "3" = the round-5 default.
 int cn_split_resnet_levels() {
     const char* e = policy_raw(P_CN_SPLIT_RESNET_LEVELS);
     const int lv = cn_split_levels();
-    if (!e) return lv;
+    if (!e) return lv < 1 ? lv : 1;
     const int v = atoi(e);
     return v < 0 ? 0 : (v > lv ? lv : v);
 }
@@ -145,7 +147,7 @@ int build_controlnet(ParamSink& ps, const ctrl_controlnet_config& c, ControlNetW
     // per-conv selection of the split operands; a checkpoint whose normalisation scales have outlier channels keeps them on every level
     // the 1x1 convolutions take them on (ParamSink::norm_scale_spread)
     const int levels = cn_split_levels();
-    // (an opt-in CTRL_CN_SPLIT_RESNET_LEVELS < levels is ignored for a checkpoint with outlier norm scales)
+    // (CTRL_CN_SPLIT_RESNET_LEVELS < levels -- the default -- is not applied to a checkpoint with outlier norm scales)
     const float spread = ps.norm_scale_spread("");
     const bool outliers = spread > kNormSpreadGate;
     const int res_levels = outliers ? levels : cn_split_resnet_levels();

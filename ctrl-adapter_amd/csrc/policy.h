@@ -11,7 +11,7 @@ enum PolicyKey {
     P_QKV_ONE,                 // CTRL_QKV_ONE=0: Q|K and V projections as two launches
     P_CN_SPLIT,                // CTRL_CN_SPLIT: split [hi | lo] operands of the ControlNet convolutions (0 off, "dup" packed twice)
     P_CN_SPLIT_LEVELS,         // CTRL_CN_SPLIT_LEVELS: down-block levels whose convolutions take split operands
-    P_CN_SPLIT_RESNET_LEVELS,  // CTRL_CN_SPLIT_RESNET_LEVELS: levels whose ResNet conv1 / conv2 take them too
+    P_CN_SPLIT_RESNET_LEVELS,  // CTRL_CN_SPLIT_RESNET_LEVELS: levels whose ResNet conv1 / conv2 take them too (default 1; 3 = all of CTRL_CN_SPLIT_LEVELS)
     P_SMALLCONV_MFMA,          // CTRL_SMALLCONV_MFMA=0: the conditioning embedder's 16/32-channel convolutions on the VALU kernel
     P_CN_AUX,                  // CTRL_CN_AUX=0: no auxiliary stream lane in the ControlNet forward
     P_STEP_OVERLAP,            // CTRL_STEP_OVERLAP=0: ctrl_step_forward runs the two modules back to back on one stream

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTRL_ABI_VERSION 6
+#define CTRL_ABI_VERSION 7
 
 /* element types of boundary tensors */
 enum { CTRL_F32 = 0, CTRL_F16 = 1, CTRL_BF16 = 2 };

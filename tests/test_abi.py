@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libctrlhip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.ctrl_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.ctrl_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_sizes_match_header():
