@@ -530,6 +530,19 @@ def main():
             except Exception as e:
                 others[name] = {"error": str(e).split("\n")[0][:120]}
                 torch.cuda.synchronize()
+        # the headline once more under the CONSERVATIVE precision selection -- what plan creation picks by itself for a checkpoint whose
+        # normalisation scales have outlier channels (module.selection): split operands on every ResNet convolution of the ControlNet's
+        # levels 0-2, fp32 adapter token stream.  The price of that fallback, on record beside the number it protects.
+        from ctrl_adapter_amd import ops as _ops
+        prev = {k: _ops.set_policy(k, v) for k, v in (("CTRL_CN_SPLIT_RESNET_LEVELS", "3"), ("CTRL_ADAPTER_TOK_F16", "0"))}
+        try:
+            others["sdxl_b8_conservative_selection"] = quick_time(dev, "sdxl", 8, 20, 3, world)
+        except Exception as e:
+            others["sdxl_b8_conservative_selection"] = {"error": str(e).split("\n")[0][:120]}
+            torch.cuda.synchronize()
+        finally:
+            for k, v in prev.items():
+                _ops.set_policy(k, v)
 
     out = None
     if rank == 0:

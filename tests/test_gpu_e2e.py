@@ -1040,9 +1040,9 @@ WEIGHT_SWEEP = {
     "gain2": (dict(gain=2.0), 2.5e-3),
     "student_t4": (dict(dist="student4"), 1e-3),
     # outlier norm scales: gated to the conservative selection at plan creation (see the docstring below); 8.7e-4 ... 9.95e-4 across the
-    # equal-precision builds of round 5 (profiles/r05_margin_sweep.txt) -- inside 1e-3 every time but within its re-roll noise, so the
-    # assertion for this synthetic stress distribution is 1.2e-3
-    "gamma_outliers": (dict(gamma_outliers=0.01, gamma_outlier_scale=8.0), 1.2e-3),
+    # equal-precision builds of round 5 (profiles/r05_margin_sweep.txt), 8.97e-4 in every build since -- asserted at the north-star bound
+    # again (round 5 had it at 1.2e-3)
+    "gamma_outliers": (dict(gamma_outliers=0.01, gamma_outlier_scale=8.0), 1e-3),
 }
 
 
