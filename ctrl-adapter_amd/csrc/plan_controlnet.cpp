@@ -67,8 +67,8 @@ int cn_split_levels() {
 // shortcuts, proj_in / proj_out, down-samplers and zero-convs of those levels, and everything of level 0, keep the split.  History: the CPU
 // emulation per conv kind said so in round 4 (tools/experiments/split_per_conv.py); round 5 ran the full GPU suite with it and reverted it over
 // ONE tensor of the config-5 miniature chain at 1.001e-3 -- then confined the adapter's fp16 token stream, which is what that tensor had
-// really been paying for (1.00e-3 -> 7.1e-4).  Round 6 measured every selectable rounding point on its own, on three chains against the
-// oracle (tests/error_attribution.py -> profiles/r06_error_attribution.md): with "1" the SVD-16, SDXL and config-5 miniature chains move by
+// really been paying for (1.00e-3 -> 7.1e-4).  Round 6 measured every selectable rounding point on its own, on three chains against the fp32
+// CPU restatement (tests/error_attribution.py -> profiles/r06_error_attribution.md): with "1" the SVD-16, SDXL and config-5 miniature chains move by
 // +0 / +2.4e-5 / +0 (8.52e-4 / 6.92e-4 / 8.76e-4; the ControlNet's own outputs 7.06e-4 / 6.14e-4 / 6.46e-4), for -1.6 ms per eager SVD-16
 // step; "0" (level 0 plain too) is another -0.4 ms but puts the ControlNet's outputs at 8.6e-4, and un-splitting the 1x1 kinds
 // (CTRL_CN_SPLIT_LEVELS=2) moves the chains by +2e-5...1e-4 -- both left alone.  "3" = the round-5 default.
