@@ -11,7 +11,7 @@ weights of the real architectures (361 M + 184 M / 587 M parameters).
 `--gpus N` with N > 1 launches the N ranks itself (re-executes under `python -m torch.distributed.run`, one rank per
 GPU over RCCL, 127.0.0.1 rendezvous); started under a launcher already (RANK / WORLD_SIZE in the environment) it joins it.
 
-Rank 0 prints the headline as the LAST stdout line, ONE JSON object of < 2 KB.  Besides the driver contract it carries:
+Rank 0 prints the headline as the LAST stdout line, ONE JSON object of about 3 KB (the driver keeps an 8 KB tail of stdout).  Besides the driver contract it carries:
   roofline      ONE kernel (symbol with template arguments + shape): algorithmic FLOPs per launch / HIP-event time per
                 launch on the launch stream, vs the dense fp16 MFMA peak; `traffic` = PMC HBM bytes per launch of that
                 kernel from the committed rocprofv3 passes (profiles/, tools/profile_round.sh)
@@ -161,7 +161,7 @@ def quick_time(dev, wname, batch, steps, warmup, world):
     ms = el / steps * 1e3
     fl = step_flops(w, n)
     res = {"value": round(dp.aggregate_throughput(1, steps, el, world), 3), "ms_per_step": round(ms, 3),      # (unit: the headline's)
-           "mfma_frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "baseline_config": w["config"], "batch_per_gpu": n, "steps": steps}
+           "mfma_frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "baseline_config": w["config"], "batch_per_gpu": n}      # (20 steps each)
     del graph, keep, cns, ad, router, x
     torch.cuda.synchronize()
     torch.cuda.empty_cache()

@@ -249,7 +249,8 @@ class MultiControlNetModel(torch.nn.Module):
                 net._no_aux_lane = False
 
         from . import ops
-        lanes = len(jobs) > 1 and sample.is_cuda and (ops.policy().get("CTRL_MULTI_CN_LANES", "1") != "0")
+        # (not while the per-launch profiler records: overlapping kernels would each be charged the others' time)
+        lanes = len(jobs) > 1 and sample.is_cuda and (ops.policy().get("CTRL_MULTI_CN_LANES", "1") != "0") and not ops.profiling()
         if not lanes:
             outs = [run(*j) for j in jobs]
         else:
