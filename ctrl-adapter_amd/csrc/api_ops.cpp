@@ -36,6 +36,10 @@ int ctrl_attn_set_variant(int v) {
     CTRL_CHECK(v >= -1 && v <= 14, "attn_set_variant: variant out of range (-1 = default, 0 = round-2 kernel, 1..14 = attention_d64.hip)");
     return attn_set_variant(v);
 }
+int ctrl_attn_work_map(int gbid, int qtiles, int pairs, int* pair, int* qtile) {
+    if (!pair || !qtile || gbid < 0 || qtiles < 1 || pairs < 1) return 0;
+    return attn_work_map(gbid, qtiles, pairs, pair, qtile) ? 1 : 0;
+}
 int ctrl_op_temporal_attn(const ctrl_tattn_desc* d, void* stream) {
     CTRL_CHECK(d != nullptr, "temporal_attn: null descriptor");
     return op_temporal_attn(*d, S(stream));

@@ -60,11 +60,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
     // pairs p = x, x+8, x+16, ... and walks their query tiles back to back, so the workgroups resident on one XCD at any
     // time stream the SAME K/V tiles through that XCD's private L2 (K+V of one pair at L = 16384 is 4 MiB = one L2).
     const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
-    const int xcd = gbid & 7, j = gbid >> 3;
-    const int pair = (j / qtiles) * 8 + xcd;
-    if (pair >= a.B * a.heads) return;
+    int pair, qt;
+    if (!attn_work_map(gbid, qtiles, a.B * a.heads, &pair, &qt)) return;      // (ops.h: whole pairs per XCD, the last partial round dealt over all XCDs)
     const int b = pair / a.heads, h = pair - b * a.heads;
-    const int q0 = (j % qtiles) * (NW * 32) + wave * 32;
+    const int q0 = qt * (NW * 32) + wave * 32;
     const int Lq = a.Lq, Lk = a.Lk;
     // softmax in the exp2 domain.  FOLD: K rows arrive pre-multiplied by scale*log2(e) (ctrl_attn_desc::k_prescaled), so the
     // MFMA output needs no scaling, and the running maximum is subtracted by INITIALISING the QK^T accumulator with -m

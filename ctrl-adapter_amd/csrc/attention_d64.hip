@@ -46,11 +46,10 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
     const int hi = lane >> 5, lq = lane & 31;
     // XCD-aware work map, see flash_attn_kernel: every XCD owns whole (batch, head) pairs
     const int qtiles = (a.Lq + NW * QPW - 1) / (NW * QPW);
-    const int xcd = gbid & 7, j = gbid >> 3;
-    const int pair = (j / qtiles) * 8 + xcd;
-    if (pair >= a.B * a.heads) return;
+    int pair, qt;
+    if (!attn_work_map(gbid, qtiles, a.B * a.heads, &pair, &qt)) return;
     const int b = pair / a.heads, h = pair - b * a.heads;
-    const int q0 = (j % qtiles) * (NW * QPW) + wave * QPW;
+    const int q0 = qt * (NW * QPW) + wave * QPW;
     const int Lq = a.Lq, Lk = a.Lk;
 
     // ---- Q fragments (B operand: column = query, k = hi*8 + j) ----
@@ -321,11 +320,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64p_kernel(AttnGroup kargs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
     const int qtiles = (a.Lq + 255) / 256;
-    const int xcd = gbid & 7, j = gbid >> 3;
-    const int pair = (j / qtiles) * 8 + xcd;
-    if (pair >= a.B * a.heads) return;
+    int pair, qt;
+    if (!attn_work_map(gbid, qtiles, a.B * a.heads, &pair, &qt)) return;
     const int b = pair / a.heads, h = pair - b * a.heads;
-    const int q0 = (j % qtiles) * 256 + wave * 64;
+    const int q0 = qt * 256 + wave * 64;
     const int Lq = a.Lq, Lk = a.Lk;
 
     h8 qf[2][4];

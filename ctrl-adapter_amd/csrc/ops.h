@@ -59,6 +59,30 @@ int op_flash_attn_group(const AttnArgs* a, int n, hipStream_t s);      // same-s
 // index & 7).  A plain launch is a group of one.
 struct AttnGroup { AttnArgs a[kMaxGroup]; };
 #define ATTN_GROUP_ARGS(gp) (((const AttnArgs*)__builtin_amdgcn_kernarg_segment_ptr())[gp])
+// XCD-aware work map of the attention kernels (1-D grid of 8 * ceil(pairs / 8) * qtiles workgroups per problem; workgroup id -> XCD
+// id & 7, the observed dispatch order): XCD x owns the whole (batch, head) pairs x, x + 8, ... and walks their query tiles back to back, so the
+// workgroups resident on one XCD stream the SAME K / V tiles through that XCD's L2.  Round 6: when pairs is not a multiple of 8 the LAST
+// round used to leave 8 - pairs % 8 XCDs without work (B = 2, 5 heads: 10 pairs in 16 slots -- the config-1 step ran its self-attention at 0.29
+// of the peak instead of 0.39); the query tiles of those last pairs are now dealt round-robin over all eight XCDs.  false = no work.
+#ifdef __HIPCC__
+__host__ __device__ __forceinline__ bool attn_work_map(int gbid, int qtiles, int pairs, int* pair, int* qt) {
+    const int xcd = gbid & 7, j = gbid >> 3;
+    const int full = pairs & ~7;
+    const int jr = j - (full >> 3) * qtiles;          // row inside the remainder round (negative before it)
+    if (jr < 0) {
+        const int r = j / qtiles;
+        *pair = r * 8 + xcd;
+        *qt = j - r * qtiles;
+        return true;
+    }
+    const int t = jr * 8 + xcd;
+    if (t >= (pairs - full) * qtiles) return false;
+    const int r = t / qtiles;
+    *pair = full + r;
+    *qt = t - r * qtiles;
+    return true;
+}
+#endif
 // descriptors of the grouped launch being dispatched (op_flash_attn_group); [0] is the problem the dispatcher sees
 extern thread_local const AttnArgs* t_attn_grp;
 extern thread_local int t_attn_grp_n;

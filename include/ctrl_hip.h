@@ -182,6 +182,10 @@ int ctrl_op_flash_attn(const ctrl_attn_desc* d, void* stream);
    > 0 = the round-3 family (what each number selects is listed in that file); performance only, every variant computes the
    same function.  -1 = back to the default (CTRL_ATTN_VARIANT or the best measured).  Used by tools/attn_bench.cpp. */
 int ctrl_attn_set_variant(int v);
+/* The attention kernels' workgroup -> (batch * heads + head, query tile) map, evaluated on the host (CPU tests: every (pair, tile) exactly once,
+   whole pairs per XCD, the last partial round balanced over the eight XCDs -- csrc/ops.h attn_work_map).  Returns 1 and fills pair / qtile when
+   workgroup `gbid` of a grid of 8 * ceil(pairs / 8) * qtiles has work, 0 when it exits at once. */
+int ctrl_attn_work_map(int gbid, int qtiles, int pairs, int* pair, int* qtile);
 
 typedef struct ctrl_tattn_desc {
     const void* Q; int64_t ld;       /* [(b*Fq+f)*HW + p][ld], head h at column h*64; unsharded: rows are q | k | v, 3*C wide */
