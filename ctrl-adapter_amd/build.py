@@ -18,6 +18,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdg
          "-Wno-unused-result"]
 
 
+# per-source additions to FLAGS.  The attention loops: hipcc's SLP vectoriser turns adjacent f32 adds / multiplies of the online softmax (row sums,
+# the rescale) into v_pk_add_f32 / v_pk_mul_f32, which MI355X_MICROARCH.md prices as an anti-lever beside MFMAs.  Same-box A/B (round 6,
+# profiles/r06_ab_slp.txt): the 128^2 self-attention launch 8.34 -> 8.20 ms in the step (-1.6 %), 2.81 -> 2.78 ms alone; the fused feed-forward
+# (whose erf polynomial is packed the same way) does not move (0.901 vs 0.903 ms) and keeps the default flags.  CTRL_BUILD_SLP=1 builds the
+# attention files with the vectoriser on (the rounds 2-5 build) for A/B runs.
+EXTRA_FLAGS = {}
+if os.environ.get("CTRL_BUILD_SLP", "0") != "1":
+    for _f in ("attention_d64.hip", "attention.hip"):
+        EXTRA_FLAGS[_f] = ["-fno-slp-vectorize"]
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -28,7 +39,7 @@ def _digest(path):
             [os.path.join(HERE, "..", "include", "ctrl_hip.h")]:
         with open(dep, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(os.path.basename(path), [])).encode())
     return h.hexdigest()
 
 
@@ -39,7 +50,7 @@ def _compile(src):
     dig = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-x", "hip", "-c", path, "-o", obj]
     audit = src == "igemm.hip" and os.environ.get("CTRL_BUILD_AUDIT", "1") != "0"      # (=0: faster edit-compile cycles)
     if audit:
         # the register / spill audit of the implicit-GEMM kernels (tools/igemm_resources.py, tests/test_kernel_resources.py) rides on
