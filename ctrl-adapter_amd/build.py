@@ -29,6 +29,11 @@ if os.environ.get("CTRL_BUILD_SLP", "0") != "1":
         EXTRA_FLAGS[_f] = ["-fno-slp-vectorize"]
 
 
+if os.environ.get("CTRL_BUILD_FMAXF", "0") == "1":          # A/B: fmaxf (maxnum + canonicalising v_max) instead of v_maximum3_f32 in the attention loops
+    for _f in ("attention_d64.hip", "attention.hip"):
+        EXTRA_FLAGS[_f] = EXTRA_FLAGS.get(_f, []) + ["-DCTRL_ATTN_FMAXF"]
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 

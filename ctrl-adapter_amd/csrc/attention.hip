@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mb][r]);
+            for (int r = 0; r < 16; ++r) mx = vmaxf(mx, sacc[mb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float psum = 0.f;
         h8 pf[2][2];

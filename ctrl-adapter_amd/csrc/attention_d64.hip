@@ -180,10 +180,10 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
 #pragma unroll
                 for (int mi = 0; mi < KB; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][mi][r]);
+                    for (int r = 0; r < 16; ++r) mx = vmaxf(mx, sacc[qb][mi][r]);
                 {
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                    mx = vmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                 }
                 // mx > 0 <=> the row maximum moved (first step: m_run = 0 stands for "none yet" and the update is forced).
                 // AO_DEFER: the reference point is only moved when a score exceeds it by more than 2^4 -- p <= 16 is as exact
@@ -423,10 +423,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64p_kernel(AttnGroup kargs
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[qb][mb][r]);
+            for (int r = 0; r < 16; ++r) mx = vmaxf(mx, sc[qb][mb][r]);
         {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            mx = vmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
         constexpr float THR = (OPT & AO_DEFER) ? 4.f : 0.f;
         if (first || __any(mx > THR)) {

@@ -65,6 +65,14 @@ struct AttnGroup { AttnArgs a[kMaxGroup]; };
 // round used to leave 8 - pairs % 8 XCDs without work (B = 2, 5 heads: 10 pairs in 16 slots -- the config-1 step ran its self-attention at 0.29
 // of the peak instead of 0.39); the query tiles of those last pairs are now dealt round-robin over all eight XCDs.  false = no work.
 #ifdef __HIPCC__
+// max of two scores as IEEE-754-2019 maximum (v_maximum3_f32 on gfx950): fmaxf() is maxnum, for which hipcc first QUIETS every operand it has
+// not seen produced -- a canonicalising v_max_f32 x, x, x per MFMA output, 5 extra VALU per 64-key tile beside the MFMAs of the attention
+// loops (round 6, profiles/r06_attention_pmc.txt).  Same value for every non-NaN input.
+#ifdef CTRL_ATTN_FMAXF          // (build.py CTRL_BUILD_FMAXF=1: the rounds 2-5 form, for A/B runs)
+__device__ __forceinline__ float vmaxf(float a, float b) { return fmaxf(a, b); }
+#else
+__device__ __forceinline__ float vmaxf(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+#endif
 __host__ __device__ __forceinline__ bool attn_work_map(int gbid, int qtiles, int pairs, int* pair, int* qt) {
     const int xcd = gbid & 7, j = gbid >> 3;
     const int full = pairs & ~7;
