@@ -40,7 +40,7 @@ struct ControlNetW {
     // split-operand convolutions (CTRL_CN_SPLIT, default on): every convolution fed by a GroupNorm output or by the fp32
     // residual stream takes its A operand as [hi | lo] fp16 halves, so the operand is exact to ~2^-22 instead of 2^-11.
     // The ControlNet's ~25 residual branches otherwise accumulate the fp16 operand rounding to ~1e-3 rel-inf on its outputs
-    // (tools/experiments/fp16_error_budget.py), which the adapter chain inherits; costs 2 x the MFMA work of those convs.
+    // (tests/experiments/fp16_error_budget.py), which the adapter chain inherits; costs 2 x the MFMA work of those convs.
     bool split = true;
     // what plan creation selected (ctrl_controlnet_selection): levels with split operands, levels whose ResNet 3x3 convolutions take them, and
     // the largest max|gamma| / median|gamma| of the checkpoint's normalisation scales that decided it
@@ -54,7 +54,7 @@ bool cn_split_enabled() {
 }
 // How deep the split goes (CTRL_CN_SPLIT_LEVELS, default 3): down blocks 0 .. levels-1 take split operands (mid block =
 // level 4); the 13 zero-convs always do.  Round 3: the 8x8 level (down block 3 + mid block) is where a split conv costs
-// most -- M = 64 rows per image, split-K 16, 0.07-0.19 of the MFMA peak -- and, by tools/experiments/fp16_error_budget.py
+// most -- M = 64 rows per image, split-K 16, 0.07-0.19 of the MFMA peak -- and, by tests/experiments/fp16_error_budget.py
 // with the rounding points of each selection, adds least: plain operands there leave the ControlNet outputs / the chain at
 // the all-exact level (+0..5e-5), while also un-splitting the 16x16 level costs ~1e-4 -- measured on the GPU at the SVD-16
 // shapes: chain mid output 1.01e-3 with levels = 2 (profiles/r03_split_levels.md), over the bound.
@@ -65,7 +65,7 @@ int cn_split_levels() {
 // The same depth for the ResNets' 3x3 convolutions alone (CTRL_CN_SPLIT_RESNET_LEVELS, default 1 since round 6): the 3x3 convolutions of the
 // 640- and 1280-channel levels take PLAIN operands -- half the matrix work of 12 of the most expensive split launches -- while the 1x1
 // shortcuts, proj_in / proj_out, down-samplers and zero-convs of those levels, and everything of level 0, keep the split.  History: the CPU
-// emulation per conv kind said so in round 4 (tools/experiments/split_per_conv.py); round 5 ran the full GPU suite with it and reverted it over
+// emulation per conv kind said so in round 4 (tests/experiments/split_per_conv.py); round 5 ran the full GPU suite with it and reverted it over
 // ONE tensor of the config-5 miniature chain at 1.001e-3 -- then confined the adapter's fp16 token stream, which is what that tensor had
 // really been paying for (1.00e-3 -> 7.1e-4).  Round 6 measured every selectable rounding point on its own, on three chains against the fp32
 // CPU restatement (tests/error_attribution.py -> profiles/r06_error_attribution.md): with "1" the SVD-16, SDXL and config-5 miniature chains move by

@@ -4,7 +4,7 @@ Every GEMM / conv A-operand of the HIP path is an fp16 rounding of an fp32 value
 fp16; boundary tensors are fp16.  This script applies those roundings to the oracle through forward pre-hooks and
 reports rel-inf against the exact oracle, per class of rounding, for the config-5 miniature chain of
 tests/test_gpu_e2e.py::test_multi_condition_router_pipeline_vs_oracle -- so the error budget of the chain can be
-studied without GPU time.   python tools/experiments/fp16_error_budget.py [what ...]
+studied without GPU time.   python tests/experiments/fp16_error_budget.py [what ...]
 """
 import os
 import sys

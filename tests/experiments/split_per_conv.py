@@ -3,7 +3,7 @@
 Same machinery as fp16_error_budget.py (the HIP path's rounding points applied to the fp32 oracle on the CPU, config-5 miniature chain):
 the baseline is what ships (CTRL_CN_SPLIT_LEVELS=3: every conv of down blocks 0-2 and every zero-conv exact, the 8x8 level and all
 Linear operands plain fp16); each trial makes ONE more group of convolutions plain and reports the ControlNet-output and chain errors.
-    python tools/experiments/split_per_conv.py
+    python tests/experiments/split_per_conv.py
 """
 import os
 import sys

@@ -7,7 +7,7 @@ import torch
 import cases
 import ctrl_adapter_amd as P
 from ctrl_adapter_amd import ops
-from oracle.init import seeded_init, seeded_tensor
+from ctrl_adapter_amd.synthetic import seeded_init, seeded_tensor
 torch.set_grad_enabled(False)
 gpu = torch.device("cuda:0")
 if len(sys.argv) > 1 and sys.argv[1] != "-":
