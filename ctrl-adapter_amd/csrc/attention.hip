@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void flash_attn_kernel(At
     half_t* Ks = (half_t*)smem_raw;             // [NSTAGE][64][DP]
     half_t* Vs = Ks + NSTAGE * TILE;            // [NSTAGE][DP][64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: LDS-DMA destinations and per-wave offsets stay in SGPRs)
     const int hi = lane >> 5, lq = lane & 31;
     // XCD-aware work map (1-D grid): workgroup id -> XCD id&7 (observed dispatch order); every XCD owns whole (batch, head)
     // pairs p = x, x+8, x+16, ... and walks their query tiles back to back, so the workgroups resident on one XCD at any

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 1 ? 4 : 2)) void flash_attn_d64_ker
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: LDS-DMA destinations and per-wave offsets stay in SGPRs)
     const int hi = lane >> 5, lq = lane & 31;
     // XCD-aware work map, see flash_attn_kernel: every XCD owns whole (batch, head) pairs
     const int qtiles = (a.Lq + NW * QPW - 1) / (NW * QPW);
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64p_kernel(AttnGroup kargs
     constexpr int PASSES = 512 / (NW * 64);            // 2
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: LDS-DMA destinations and per-wave offsets stay in SGPRs)
     const int hi = lane >> 5, lq = lane & 31;
     const int qtiles = (a.Lq + 255) / 256;
     int pair, qt;
