@@ -179,7 +179,7 @@ int halo_exchange_frames(Ctx& cx, half_t* np, const AFwd& a, int HW, int C) {
 // MLPs, the per-layer time projections, the single-key cross-attention vectors -- is computed for ALL blocks at the start of
 // the forward, one grouped launch per dependency level (instead of ~10 small-M launches inside every block)
 struct BlockPre {
-    float* temb = nullptr;                 // resnet_time_embedding(t) [N][C]
+    float* temb = nullptr;                 // SiLU(resnet_time_embedding(t)) [N][C]
     float* femb = nullptr;                 // transformer_time_embedding(frame index) [F][512]
     std::vector<float*> sres_tp, tres_tp;  // per layer: time_emb_proj(SiLU(temb)) [N][C]
     std::vector<float*> stb_ov, ttb_ov;    // per layer: to_out(to_v(context)) of the one-key cross-attentions
@@ -206,7 +206,10 @@ int precompute_small(Ctx& cx, const ctrl_adapter_config& c, const std::vector<co
             float* t1 = cx.f((size_t)N * C);
             P.temb = cx.f((size_t)N * C);
             L1.push_back({ts_by_c[ci], C, b.rte1.w, b.rte1.b, t1, C, N, C, C, 0, 1});
-            L2.push_back({t1, C, b.rte2.w, b.rte2.b, P.temb, C, N, C, C, 0, 0});
+            // (SiLU on the way OUT: the embedding's only consumers are the time_emb_proj linears of the block's resnets, each of which starts
+            //  with SiLU(temb) -- model/resnet_block_2d.py:191-192, TemporalResnetBlock likewise; applied once here instead of once per output
+            //  column of every consumer: the same fp32 values, bit-identical, and the level-3 launch of a video forward no longer spends its time in exp / rcp)
+            L2.push_back({t1, C, b.rte2.w, b.rte2.b, P.temb, C, N, C, C, 0, 1});
         }
         if (tt) {
             if (!fs_by_c[ci]) {
@@ -222,12 +225,12 @@ int precompute_small(Ctx& cx, const ctrl_adapter_config& c, const std::vector<co
             if (sr) {
                 float* tp = cx.f((size_t)N * C);
                 P.sres_tp.push_back(tp);
-                L3.push_back({P.temb, C, Lw.sres_temb.w, Lw.sres_temb.b, tp, C, N, C, C, 1, 0});
+                L3.push_back({P.temb, C, Lw.sres_temb.w, Lw.sres_temb.b, tp, C, N, C, C, 0, 0});
             }
             if (tr) {
                 float* tp = cx.f((size_t)N * C);
                 P.tres_tp.push_back(tp);
-                L3.push_back({P.temb, C, Lw.tres.temb.w, Lw.tres.temb.b, tp, C, N, C, C, 1, 0});
+                L3.push_back({P.temb, C, Lw.tres.temb.w, Lw.tres.temb.b, tp, C, N, C, C, 0, 0});
             }
             auto one_key = [&](const AttnW& w, const EhsCtx& e, std::vector<float*>* dst) {
                 float* v = cx.f((size_t)e.batch * w.inner);

@@ -291,9 +291,11 @@ int controlnet_run(Ctx& cx, const ControlNetW& w, const FwdArgs& a) {
     RUN(cx, op_linear_small(tsin, c0, w.te1.w, w.te1.b, t1, temb_dim, N, temb_dim, c0, 0, 1, cx.s));
     float* emb = cx.f((size_t)N * temb_dim);
     if (a.flags & CTRL_SKIP_TIME_EMB) RUN(cx, op_fill_zero(emb, (size_t)N * temb_dim * sizeof(float), cx.s));   // :809-811
-    else RUN(cx, op_linear_small(t1, temb_dim, w.te2.w, w.te2.b, emb, temb_dim, N, temb_dim, temb_dim, 0, 0, cx.s));
+    // (emb leaves linear_2 as SiLU(emb): its only consumer is the concatenated time_emb_proj of the resnets, which all start with SiLU(emb)
+    //  -- applied once per element here instead of once per element and OUTPUT COLUMN there; SiLU(0) = 0 keeps the skip_time_emb zeros)
+    else RUN(cx, op_linear_small(t1, temb_dim, w.te2.w, w.te2.b, emb, temb_dim, N, temb_dim, temb_dim, 0, 1, cx.s));
     float* tproj = cx.f((size_t)N * w.temb_total);
-    RUN(cx, op_linear_small(emb, temb_dim, w.temb_cat.w, w.temb_cat.b, tproj, w.temb_total, N, w.temb_total, temb_dim, 1, 0, cx.s));
+    RUN(cx, op_linear_small(emb, temb_dim, w.temb_cat.w, w.temb_cat.b, tproj, w.temb_total, N, w.temb_total, temb_dim, 0, 0, cx.s));
 
     // ---- encoder hidden states -> fp16 [N*Lk][cross] ----
     EhsCtx e;
