@@ -34,6 +34,11 @@ if os.environ.get("CTRL_BUILD_FMAXF", "0") == "1":          # A/B: fmaxf (maxnum
         EXTRA_FLAGS[_f] = EXTRA_FLAGS.get(_f, []) + ["-DCTRL_ATTN_FMAXF"]
 
 
+if os.environ.get("CTRL_BUILD_ATTN_SCHED"):          # A/B: LLVM's AMDGPU scheduling strategy for the attention files (max-ilp | max-memory-clause | iterative-ilp)
+    for _f in ("attention_d64.hip", "attention.hip"):
+        EXTRA_FLAGS[_f] = EXTRA_FLAGS.get(_f, []) + ["-mllvm", "-amdgpu-sched-strategy=" + os.environ["CTRL_BUILD_ATTN_SCHED"]]
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
